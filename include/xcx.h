@@ -1,0 +1,165 @@
+/*
+ * xcx.h -- C ABI of libxcx.so, the MI355X-native cross-correlation engine that
+ * replaces xcorr's CPU hot path.  Plain pointers and sizes only; no C++ or
+ * torch types cross this boundary.  Bound from Python through ctypes
+ * (xcorr_amd/_ffi.py); INTEGRATION.md shows the stub a maintainer of the
+ * reference would add.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative XCX_E* code;
+ *     xcx_last_error() returns the message of the calling thread's last error.
+ *   - the caller owns every data buffer; the library owns plans, twiddle
+ *     tables, workspaces and its HIP stream.  One xcx_ctx <-> one HIP device
+ *     <-> one stream; contexts share no mutable state (the reference runs one
+ *     Python thread per Dask worker, xcorr/scripts/utils.py:62-66).
+ *   - `on_device` != 0: data pointers are device pointers obtained from
+ *     xcx_malloc(); == 0: host pointers (the library stages through HBM).
+ *   - all arrays are C-contiguous float32 with the core dimension last, which
+ *     is what every xr.apply_ufunc closure of the reference receives
+ *     (xcorr/signal/correlate.py:121-127, filter.py:104-109, ...).
+ *
+ * Paths are relative to the reference checkout (psmsmets/xcorr).
+ */
+#ifndef XCX_H
+#define XCX_H
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct xcx_ctx xcx_ctx;
+typedef struct xcx_plan xcx_plan;
+
+enum {
+  XCX_OK = 0,
+  XCX_EINVAL = -1,     /* bad argument (length/shape mismatch, null pointer) */
+  XCX_ENOMEM = -2,     /* device allocation failed */
+  XCX_EHIP = -3,       /* HIP runtime error */
+  XCX_EUNSUPPORTED = -4, /* size outside the planner's table */
+  XCX_ENODEV = -5,     /* no usable GPU */
+  XCX_ERCCL = -6       /* RCCL error */
+};
+
+/* plan flags */
+enum {
+  XCX_NORMALIZE = 1,   /* divide by ||x|| ||y||   (util/cc.py:76-77)          */
+  XCX_UNBIAS = 2,      /* multiply by n/(n-|lag|) (util/cc.py:79,111-141)     */
+  XCX_STACK = 4,       /* time-stack: sum over windows (frequency domain)     */
+  XCX_ONEBIT = 8,      /* sign(x) per window            (self-defined)        */
+  XCX_WHITEN = 16,     /* X/|X| inside a band           (self-defined)        */
+  XCX_DEMEAN = 32      /* subtract the window mean (signal/detrend.py:110)    */
+};
+
+/* ---- context / memory / timing ---------------------------------------- */
+int xcx_device_count(int* count);
+int xcx_init(int device, xcx_ctx** ctx);
+int xcx_destroy(xcx_ctx* ctx);
+int xcx_last_error(char* buf, size_t len);
+int xcx_device_name(xcx_ctx* ctx, char* buf, size_t len);
+int xcx_malloc(xcx_ctx* ctx, size_t bytes, void** dptr);
+int xcx_free(xcx_ctx* ctx, void* dptr);
+int xcx_memset(xcx_ctx* ctx, void* dptr, int value, size_t bytes);
+int xcx_memcpy_h2d(xcx_ctx* ctx, void* dst, const void* src, size_t bytes);
+int xcx_memcpy_d2h(xcx_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* rows x width_bytes, with independent pitches (bytes) */
+int xcx_memcpy2d_d2h(xcx_ctx* ctx, void* dst, size_t dpitch, const void* src,
+                     size_t spitch, size_t width_bytes, size_t rows);
+int xcx_sync(xcx_ctx* ctx);
+/* HIP events on the context's stream (the stream every kernel is launched
+ * on); xcx_timer_stop synchronises and returns the elapsed milliseconds. */
+int xcx_timer_start(xcx_ctx* ctx);
+int xcx_timer_stop(xcx_ctx* ctx, float* ms);
+
+/* ---- cross-correlation plan (replaces util/cc.py:22-79 cc(), and the
+ *      _correlate1d closure of signal/correlate.py:108-113) ---------------
+ * n        : window length in samples (len(x) == len(y), util/cc.py:60-62)
+ * nfft     : transform length, 0 = smallest supported N >= 2n-1.  The
+ *            reference uses exactly 2n-1 (util/cc.py:67); any N >= 2n-1
+ *            yields the identical linear cross-correlation.
+ * idx_min, idx_max : retained slice of the 2n-1 lags, end exclusive
+ *            (core/process.py:155-162 `[index_min:index_max]`,
+ *            util/time.py:104-108); idx_max = 0 means 2n-1.
+ */
+int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min, int idx_max,
+                  int flags, xcx_plan** plan);
+int xcx_plan_destroy(xcx_plan* plan);
+/* whitening band in Hz (self-defined op): gain 1 in [fmin,fmax], raised-cosine
+ * ramps of width ftaper outside, 0 beyond. */
+int xcx_plan_set_whiten(xcx_plan* plan, double sampling_rate, double fmin,
+                        double fmax, double ftaper);
+/* tuning: pair-windows per launch batch (default 64) */
+int xcx_plan_set_batch(xcx_plan* plan, int pair_windows_per_batch);
+/* out[0..5] = N, N1, N2, L (= idx_max-idx_min), batch, spectrum floats */
+int xcx_plan_info(xcx_plan* plan, int* out6);
+
+/* All pairs x all windows (the hot loop of core/process.py:82-165, batched):
+ *   traces : S station records; window w of station s starts at
+ *            traces + s*stride_s + w*stride_w (elements) and has n samples
+ *   pairs  : P x 2 int32 station indices (i, j): R[k] = sum_t x_i[t+k] x_j[t]
+ *   out    : row (p*W + w) at out + (p*W + w)*ld_out, L floats each
+ *            (XCX_STACK: row p at out + p*ld_out, sum over the W windows)
+ *   ld_out : elements between consecutive rows, >= L; 0 means L.
+ */
+int xcx_cc1d_pairs(xcx_plan* plan, const float* traces, int S, int W,
+                   long stride_s, long stride_w, const int* pairs, int P,
+                   float* out, long ld_out, int on_device);
+
+/* Batched two-input form (util/cc.py:22 cc(x, y) / correlate1d(in1, in2)):
+ * x, y : [batch][n]; out : [batch][L]. */
+int xcx_cc1d(xcx_plan* plan, const float* x, const float* y, int batch,
+             float* out, int on_device);
+
+/* number of kernel launches and of pair-windows processed since plan
+ * creation (bench bookkeeping) */
+int xcx_plan_counters(xcx_plan* plan, long long* launches,
+                      long long* pair_windows);
+
+/* ---- row-wise signal ops on [batch][n] float32, in place ----------------
+ * norm1d  : x / ||x||_2                       (signal/normalize.py:73-80)
+ * demean  : x - mean(x)                       (signal/detrend.py:110)
+ * detrend_linear : x - (m t + b), least squares (signal/detrend.py:87-99)
+ * taper   : x * w, w = ones with `nmax` samples of a periodic Hann window of
+ *           length 2*nmax on both flanks      (signal/window.py:92-106,
+ *           signal/taper.py:67-69); wtype: 0 = hann, 1 = obspy cosine
+ * unbias  : x * n/(n-|lag|), lags idx_min..idx_max-1 of 2n-1
+ *                                             (signal/unbias.py:73-85)
+ * onebit  : sign(x)                           (self-defined)
+ * sosfiltfilt : zero-phase Butterworth, scipy semantics (odd padding of
+ *           3*ntaps samples, sosfilt_zi initial state) given `sos`
+ *           [n_sections][6] float64           (signal/filter.py:86-96)
+ * sosfilt : forward-only cascade from rest (ObsPy Trace.filter,
+ *           stream/process.py:279-282; unverified vs obspy)
+ */
+int xcx_norm1d(xcx_ctx* ctx, float* x, long batch, long n, int on_device);
+int xcx_demean(xcx_ctx* ctx, float* x, long batch, long n, int on_device);
+int xcx_detrend_linear(xcx_ctx* ctx, float* x, long batch, long n,
+                       int on_device);
+int xcx_taper(xcx_ctx* ctx, float* x, long batch, long n, long nmax,
+              int wtype, int on_device);
+int xcx_unbias(xcx_ctx* ctx, float* x, long batch, long npts, long idx_min,
+               long idx_max, int on_device);
+int xcx_onebit(xcx_ctx* ctx, float* x, long batch, long n, int on_device);
+int xcx_sosfiltfilt(xcx_ctx* ctx, float* x, long batch, long n,
+                    const double* sos, int n_sections, int on_device);
+int xcx_sosfilt(xcx_ctx* ctx, float* x, long batch, long n, const double* sos,
+                int n_sections, int on_device);
+
+/* ---- multi-GPU time-stack reduction (RCCL over xGMI) --------------------
+ * One communicator per process/GPU.  id_bytes is the 128-byte ncclUniqueId
+ * created by rank 0 with xcx_comm_unique_id() and distributed by the host
+ * launcher (torch.distributed store / file / MPI).
+ * xcx_stack_reduce sums `count` floats in place across ranks
+ * (ncclAllReduce) or leaves each rank with its count/nranks share
+ * (ncclReduceScatter, reduce_scatter != 0; recv = stack + rank*count/nranks).
+ */
+int xcx_comm_unique_id(char* id_bytes128);
+int xcx_comm_init(xcx_ctx* ctx, const char* id_bytes128, int nranks, int rank);
+int xcx_comm_destroy(xcx_ctx* ctx);
+int xcx_stack_reduce(xcx_ctx* ctx, float* stack, size_t count,
+                     int reduce_scatter);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XCX_H */

@@ -1,0 +1,336 @@
+// fft_device.h -- register/LDS FFT building blocks for gfx950 (wave64).
+//
+// A "sub-FFT" of compile-time length L = R0*R1*...  is computed for NB
+// independent sequences at once by one 256-thread workgroup, Stockham
+// autosort (natural order in, natural order out).  Data sits in LDS as
+// [position][sequence] (sequence index fastest, pitch NBP float2) so that the
+// 16 lanes that share a butterfly index touch 128 contiguous bytes: every
+// ds_read_b64 / ds_write_b64 of every stage is bank-conflict free, and the
+// global loads/stores of the first/last stage (fused into the stage through
+// functors) are full 128-byte lines.
+//
+// Radix butterflies are fully unrolled in registers; composite radices
+// (6, 8, 10, 12, 15, 16, ...) are built by compile-time Cooley-Tukey from the
+// hand-written 2/3/4/5 kernels with constexpr twiddles.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <type_traits>
+#include <utility>
+
+namespace xcx {
+
+typedef float2 cf;
+
+#define XCX_DEV __device__ __forceinline__
+
+XCX_DEV cf cadd(cf a, cf b) { return make_float2(a.x + b.x, a.y + b.y); }
+XCX_DEV cf csub(cf a, cf b) { return make_float2(a.x - b.x, a.y - b.y); }
+XCX_DEV cf cmul(cf a, cf b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+// a * conj(b)
+XCX_DEV cf cmulc(cf a, cf b) {
+  return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+XCX_DEV cf cconj(cf a) { return make_float2(a.x, -a.y); }
+XCX_DEV cf cscale(cf a, float s) { return make_float2(a.x * s, a.y * s); }
+// multiply by +i / -i
+XCX_DEV cf cmul_pi(cf a) { return make_float2(-a.y, a.x); }
+XCX_DEV cf cmul_mi(cf a) { return make_float2(a.y, -a.x); }
+// tables hold the forward factor e^{-i theta}; the inverse uses its conjugate
+template <bool INV> XCX_DEV cf ctw(cf a, cf w) {
+  return INV ? cmulc(a, w) : cmul(a, w);
+}
+
+// ---------------------------------------------------------------------------
+// constexpr trigonometry for compile-time twiddles: cos/sin(2*pi*m/N)
+// ---------------------------------------------------------------------------
+constexpr double kPi = 3.14159265358979323846264338327950288;
+
+constexpr double cx_sin_small(double x) {  // |x| <= pi/4
+  double x2 = x * x, term = x, sum = x;
+  for (int i = 1; i < 14; ++i) {
+    term *= -x2 / double((2 * i) * (2 * i + 1));
+    sum += term;
+  }
+  return sum;
+}
+constexpr double cx_cos_small(double x) {
+  double x2 = x * x, term = 1.0, sum = 1.0;
+  for (int i = 1; i < 14; ++i) {
+    term *= -x2 / double((2 * i - 1) * (2 * i));
+    sum += term;
+  }
+  return sum;
+}
+struct cx_cs { double c, s; };
+constexpr cx_cs cx_sincos2pi(long m, long N) {
+  m %= N;
+  if (m < 0) m += N;
+  long oct = (8 * m) / N;        // 0..7
+  long rem = 8 * m - oct * N;    // angle = (pi/4) * (oct + rem/N)
+  long quarter = 0;
+  double off = 0.0;
+  if (oct & 1) {
+    quarter = (oct + 1) / 2;
+    off = -(kPi / 4) * double(N - rem) / double(N);
+  } else {
+    quarter = oct / 2;
+    off = (kPi / 4) * double(rem) / double(N);
+  }
+  double c0 = cx_cos_small(off), s0 = cx_sin_small(off);
+  switch (quarter & 3) {
+    case 0: return {c0, s0};
+    case 1: return {-s0, c0};
+    case 2: return {-c0, -s0};
+    default: return {s0, -c0};
+  }
+}
+
+// multiply by the constant e^{-/+ 2 pi i M/N}  (- forward, + inverse)
+template <int M, int N, bool INV> XCX_DEV cf mul_wconst(cf a) {
+  constexpr int m = ((M % N) + N) % N;
+  if constexpr (m == 0) {
+    return a;
+  } else if constexpr (4 * m == N) {
+    return INV ? cmul_pi(a) : cmul_mi(a);
+  } else if constexpr (2 * m == N) {
+    return make_float2(-a.x, -a.y);
+  } else if constexpr (4 * m == 3 * N) {
+    return INV ? cmul_mi(a) : cmul_pi(a);
+  } else {
+    constexpr cx_cs cs = cx_sincos2pi(m, N);
+    constexpr float wr = float(cs.c);
+    constexpr float wi = INV ? float(cs.s) : float(-cs.s);
+    return make_float2(a.x * wr - a.y * wi, a.x * wi + a.y * wr);
+  }
+}
+
+// compile-time loop
+template <class F, int... Is>
+XCX_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, class F> XCX_DEV void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// ---------------------------------------------------------------------------
+// radix butterflies, in place on a register array v[R]
+// ---------------------------------------------------------------------------
+template <int R, bool INV> struct Bfly;
+
+template <bool INV> struct Bfly<1, INV> {
+  static XCX_DEV void run(cf (&v)[1]) {}
+};
+
+template <bool INV> struct Bfly<2, INV> {
+  static XCX_DEV void run(cf (&v)[2]) {
+    cf a = cadd(v[0], v[1]), b = csub(v[0], v[1]);
+    v[0] = a; v[1] = b;
+  }
+};
+
+template <bool INV> struct Bfly<3, INV> {
+  static XCX_DEV void run(cf (&v)[3]) {
+    constexpr float s = 0.86602540378443864676f;
+    cf t = cadd(v[1], v[2]);
+    cf d = csub(v[1], v[2]);
+    cf m = make_float2(v[0].x - 0.5f * t.x, v[0].y - 0.5f * t.y);
+    // forward: X1 = m - i s d, X2 = m + i s d
+    cf r = INV ? make_float2(-s * d.y, s * d.x) : make_float2(s * d.y, -s * d.x);
+    v[0] = cadd(v[0], t);
+    v[1] = cadd(m, r);
+    v[2] = csub(m, r);
+  }
+};
+
+template <bool INV> struct Bfly<4, INV> {
+  static XCX_DEV void run(cf (&v)[4]) {
+    cf a0 = cadd(v[0], v[2]), a1 = csub(v[0], v[2]);
+    cf a2 = cadd(v[1], v[3]), a3 = csub(v[1], v[3]);
+    cf r = INV ? cmul_pi(a3) : cmul_mi(a3);
+    v[0] = cadd(a0, a2);
+    v[2] = csub(a0, a2);
+    v[1] = cadd(a1, r);
+    v[3] = csub(a1, r);
+  }
+};
+
+template <bool INV> struct Bfly<5, INV> {
+  static XCX_DEV void run(cf (&v)[5]) {
+    constexpr float c1 = 0.30901699437494742410f;   // cos(2pi/5)
+    constexpr float c2 = -0.80901699437494742410f;  // cos(4pi/5)
+    constexpr float s1 = 0.95105651629515357212f;   // sin(2pi/5)
+    constexpr float s2 = 0.58778525229247312917f;   // sin(4pi/5)
+    cf t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
+    cf t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+    cf m1 = make_float2(v[0].x + c1 * t1.x + c2 * t2.x,
+                        v[0].y + c1 * t1.y + c2 * t2.y);
+    cf m2 = make_float2(v[0].x + c2 * t1.x + c1 * t2.x,
+                        v[0].y + c2 * t1.y + c1 * t2.y);
+    cf n1 = make_float2(s1 * t3.x + s2 * t4.x, s1 * t3.y + s2 * t4.y);
+    cf n2 = make_float2(s2 * t3.x - s1 * t4.x, s2 * t3.y - s1 * t4.y);
+    // forward: X1 = m1 - i n1, X4 = m1 + i n1, X2 = m2 - i n2, X3 = m2 + i n2
+    cf r1 = INV ? cmul_pi(n1) : cmul_mi(n1);
+    cf r2 = INV ? cmul_pi(n2) : cmul_mi(n2);
+    v[0] = make_float2(v[0].x + t1.x + t2.x, v[0].y + t1.y + t2.y);
+    v[1] = cadd(m1, r1);
+    v[4] = csub(m1, r1);
+    v[2] = cadd(m2, r2);
+    v[3] = csub(m2, r2);
+  }
+};
+
+// compile-time Cooley-Tukey: R = R1*R2,
+//   X[k1 + R1*k2] = sum_n2 w_R^{n2 k1} (sum_n1 x[n1*R2+n2] w_R1^{n1 k1}) w_R2^{n2 k2}
+template <int R1, int R2, bool INV> struct BflyCT {
+  static XCX_DEV void run(cf (&v)[R1 * R2]) {
+    cf a[R2][R1];
+    static_for<R2>([&](auto n2c) {
+      constexpr int n2 = decltype(n2c)::value;
+      cf t[R1];
+      static_for<R1>([&](auto n1c) {
+        constexpr int n1 = decltype(n1c)::value;
+        t[n1] = v[n1 * R2 + n2];
+      });
+      Bfly<R1, INV>::run(t);
+      static_for<R1>([&](auto k1c) {
+        constexpr int k1 = decltype(k1c)::value;
+        a[n2][k1] = mul_wconst<n2 * k1, R1 * R2, INV>(t[k1]);
+      });
+    });
+    static_for<R1>([&](auto k1c) {
+      constexpr int k1 = decltype(k1c)::value;
+      cf t[R2];
+      static_for<R2>([&](auto n2c) {
+        constexpr int n2 = decltype(n2c)::value;
+        t[n2] = a[n2][k1];
+      });
+      Bfly<R2, INV>::run(t);
+      static_for<R2>([&](auto k2c) {
+        constexpr int k2 = decltype(k2c)::value;
+        v[k1 + R1 * k2] = t[k2];
+      });
+    });
+  }
+};
+
+template <bool INV> struct Bfly<6, INV> : BflyCT<2, 3, INV> {};
+template <bool INV> struct Bfly<8, INV> : BflyCT<2, 4, INV> {};
+template <bool INV> struct Bfly<9, INV> : BflyCT<3, 3, INV> {};
+template <bool INV> struct Bfly<10, INV> : BflyCT<2, 5, INV> {};
+template <bool INV> struct Bfly<12, INV> : BflyCT<3, 4, INV> {};
+template <bool INV> struct Bfly<15, INV> : BflyCT<3, 5, INV> {};
+template <bool INV> struct Bfly<16, INV> : BflyCT<4, 4, INV> {};
+
+// ---------------------------------------------------------------------------
+// sub-FFT configuration: length and up to four radices (1 = unused)
+// ---------------------------------------------------------------------------
+template <int R0_, int R1_ = 1, int R2_ = 1, int R3_ = 1> struct Radices {
+  static constexpr int R0 = R0_, R1 = R1_, R2 = R2_, R3 = R3_;
+  static constexpr int L = R0_ * R1_ * R2_ * R3_;
+  static constexpr int S = 1 + (R1_ > 1) + (R2_ > 1) + (R3_ > 1);
+  static_assert(R1_ > 1 || (R2_ == 1 && R3_ == 1), "radices must be packed");
+  static_assert(R2_ > 1 || R3_ == 1, "radices must be packed");
+};
+
+// ---------------------------------------------------------------------------
+// one Stockham stage over NB sequences.
+//   butterfly b = tid + it*NT  ->  sequence c = b % NB, index j = b / NB
+//   inputs  j + t*L/R (t = 0..R-1), twiddle w_{NS*R}^{k t}, k = j % NS
+//   outputs (j-k)*R + k + t*NS
+// `ld(pos, c)` / `st(pos, c, value)` are functors (global memory, LDS, or
+// fused pre/post-processing).  SYNC inserts the barrier that separates the
+// read phase from the write phase when both go through the same LDS buffer.
+// `tw` is the length-L forward table e^{-2 pi i q / L}.
+// ---------------------------------------------------------------------------
+template <int L, int R, int NS, int NB, int NT, bool INV, bool SYNC,
+          class LoadF, class StoreF>
+XCX_DEV void fft_stage(const cf* __restrict__ tw, LoadF ld, StoreF st) {
+  constexpr int NBF = NB * (L / R);
+  constexpr int IT = (NBF + NT - 1) / NT;
+  constexpr bool GUARD = (NBF % NT) != 0;
+  const int tid = threadIdx.x;
+  cf v[IT][R];
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int b = tid + it * NT;
+    if (!GUARD || b < NBF) {
+      const int c = b % NB;
+      const int j = b / NB;
+#pragma unroll
+      for (int t = 0; t < R; ++t) v[it][t] = ld(j + t * (L / R), c);
+      if constexpr (NS > 1) {
+        const int k = j % NS;
+        constexpr int STEP = L / (NS * R);
+#pragma unroll
+        for (int t = 1; t < R; ++t) {
+          const cf w = tw[k * t * STEP];
+          v[it][t] = ctw<INV>(v[it][t], w);
+        }
+      }
+      Bfly<R, INV>::run(v[it]);
+    }
+  }
+  if constexpr (SYNC) __syncthreads();
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int b = tid + it * NT;
+    if (!GUARD || b < NBF) {
+      const int c = b % NB;
+      const int j = b / NB;
+      const int k = (NS > 1) ? (j % NS) : 0;
+      const int j0 = (j - k) * R + k;
+#pragma unroll
+      for (int t = 0; t < R; ++t) st(j0 + t * NS, c, v[it][t]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// whole sub-FFT: first stage reads through `in`, last stage writes through
+// `out`, intermediate stages exchange through `lds` ([L][NBP] float2).
+// IN_LDS: `in` itself reads `lds` (barrier needed before stage 0 overwrites).
+// On return the LDS buffer may still be being read by other threads only if
+// S > 1: callers that reuse `lds` afterwards must __syncthreads() first.
+// ---------------------------------------------------------------------------
+template <class RX, int NB, int NBP, int NT, bool INV, bool IN_LDS, class In,
+          class Out>
+XCX_DEV void subfft(cf* __restrict__ lds, const cf* __restrict__ tw, In in,
+                    Out out) {
+  constexpr int L = RX::L;
+  constexpr int R0 = RX::R0, R1 = RX::R1, R2 = RX::R2, R3 = RX::R3;
+  auto lds_ld = [=](int p, int c) -> cf { return lds[p * NBP + c]; };
+  auto lds_st = [=](int p, int c, cf v) { lds[p * NBP + c] = v; };
+  if constexpr (RX::S == 1) {
+    fft_stage<L, R0, 1, NB, NT, INV, false>(tw, in, out);
+  } else {
+    fft_stage<L, R0, 1, NB, NT, INV, IN_LDS>(tw, in, lds_st);
+    __syncthreads();
+    if constexpr (RX::S == 2) {
+      fft_stage<L, R1, R0, NB, NT, INV, false>(tw, lds_ld, out);
+    } else {
+      fft_stage<L, R1, R0, NB, NT, INV, true>(tw, lds_ld, lds_st);
+      __syncthreads();
+      if constexpr (RX::S == 3) {
+        fft_stage<L, R2, R0 * R1, NB, NT, INV, false>(tw, lds_ld, out);
+      } else {
+        fft_stage<L, R2, R0 * R1, NB, NT, INV, true>(tw, lds_ld, lds_st);
+        __syncthreads();
+        fft_stage<L, R3, R0 * R1 * R2, NB, NT, INV, false>(tw, lds_ld, out);
+      }
+    }
+  }
+}
+
+// two-level table lookup of w_N^q (forward e^{-2 pi i q/N}), q in [0, N/2]:
+// tab[0..QL) = w_N^{ql},  tab[QL + qh] = w_N^{QL*qh}
+constexpr int kTwQL = 512;
+XCX_DEV cf twN_lookup(const cf* __restrict__ tab, unsigned q) {
+  const cf lo = tab[q & (kTwQL - 1)];
+  const cf hi = tab[kTwQL + (q >> 9)];
+  return cmul(lo, hi);
+}
+
+}  // namespace xcx

@@ -1,0 +1,216 @@
+// ops.hip -- row-wise signal operations on [batch][n] float32, in place.
+// Reference semantics are cited per entry point in include/xcx.h.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "../../include/xcx.h"
+#include "xcx_internal.h"
+
+using namespace xcx;
+
+#define HIP_TRY(expr)                                                     \
+  do {                                                                    \
+    hipError_t e_ = (expr);                                               \
+    if (e_ != hipSuccess)                                                 \
+      return set_err(e_ == hipErrorOutOfMemory ? XCX_ENOMEM : XCX_EHIP,   \
+                     "%s: %s (%s:%d)", #expr, hipGetErrorString(e_),      \
+                     __FILE__, __LINE__);                                 \
+  } while (0)
+
+namespace {
+
+constexpr int NT = 256;
+
+// block-wide sum in double, fixed order; result broadcast to all threads
+__device__ inline double block_sum(double v, double* red) {
+  const int tid = threadIdx.x;
+  red[tid] = v;
+  __syncthreads();
+  for (int o = NT / 2; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+enum { OP_NORM = 0, OP_DEMEAN = 1, OP_DETREND = 2 };
+
+// one workgroup per row; the row is read twice (second time from L2)
+template <int OP>
+__global__ __launch_bounds__(NT) void k_row_reduce_apply(float* __restrict__ x, long n) {
+  __shared__ double red[NT];
+  float* __restrict__ row = x + (size_t)blockIdx.x * n;
+  const int tid = threadIdx.x;
+  if (OP == OP_NORM) {
+    double acc = 0.0;
+    for (long i = tid; i < n; i += NT) { double v = row[i]; acc += v * v; }
+    const double nrm = sqrt(block_sum(acc, red));
+    // x / ||x|| in the input precision (signal/normalize.py:80 `y = x/n`)
+    const float fn = (float)nrm;
+    for (long i = tid; i < n; i += NT) row[i] = row[i] / fn;
+  } else if (OP == OP_DEMEAN) {
+    double acc = 0.0;
+    for (long i = tid; i < n; i += NT) acc += (double)row[i];
+    const float mean = (float)(block_sum(acc, red) / (double)n);
+    for (long i = tid; i < n; i += NT) row[i] = row[i] - mean;
+  } else {
+    // least-squares line over t = 0..n-1 (scipy.stats.linregress)
+    const double tbar = 0.5 * (double)(n - 1);
+    double sy = 0.0, sty = 0.0;
+    for (long i = tid; i < n; i += NT) {
+      double v = row[i];
+      sy += v;
+      sty += ((double)i - tbar) * v;
+    }
+    sy = block_sum(sy, red);
+    sty = block_sum(sty, red);
+    const double stt = (double)n * ((double)n * (double)n - 1.0) / 12.0;
+    const double m = (n > 1) ? sty / stt : 0.0;
+    const double b = sy / (double)n - m * tbar;
+    for (long i = tid; i < n; i += NT)
+      row[i] = (float)((double)row[i] - (m * (double)i + b));
+  }
+}
+
+// taper: both flanks of nmax samples.  wtype 0: periodic Hann of length
+// 2*nmax (scipy.signal.windows.hann(2*nmax, False)); 1: ObsPy cosine flank
+__global__ void k_taper(float* __restrict__ x, long batch, long n, long nmax, int wtype) {
+  const long per = 2 * nmax;
+  const long total = batch * per;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const long r = idx / per, q = idx % per;
+    long i;      // sample index
+    double w;
+    if (q < nmax) {                  // left flank, unless overwritten by the right one
+      i = q;
+      if (i >= n - nmax) continue;   // right flank wins on overlap (window.py:105-106)
+      w = (wtype == 0) ? 0.5 * (1.0 - cos(M_PI * (double)q / (double)nmax))
+                       : ((nmax > 1) ? 0.5 * (1.0 - cos(M_PI * (double)q / (double)(nmax - 1))) : 0.0);
+    } else {
+      const long e = q - nmax;       // 0..nmax-1 from the start of the right flank
+      i = n - nmax + e;
+      if (i < 0) continue;
+      w = (wtype == 0) ? 0.5 * (1.0 + cos(M_PI * (double)e / (double)nmax))
+                       : ((nmax > 1) ? 0.5 * (1.0 - cos(M_PI * (double)(nmax - 1 - e) / (double)(nmax - 1))) : 0.0);
+    }
+    float* p = x + (size_t)r * n + i;
+    *p = *p * (float)w;
+  }
+}
+
+__global__ void k_unbias(float* __restrict__ x, long batch, long L, long npts, long idx_min) {
+  const long total = batch * L;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const long o = idx % L;
+    long lag = idx_min + o - (npts - 1);
+    if (lag < 0) lag = -lag;
+    const float w = (float)((double)npts / (double)(npts - lag));
+    x[idx] = x[idx] * w;
+  }
+}
+
+__global__ void k_onebit(float* __restrict__ x, long total) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const float v = x[idx];
+    x[idx] = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
+  }
+}
+
+// stage host data on the device when on_device == 0
+struct Staged {
+  xcx_ctx* ctx; float* host; float* dev; size_t bytes; bool staged;
+  int begin(xcx_ctx* c, float* x, size_t nbytes, int on_device) {
+    ctx = c; host = x; bytes = nbytes; staged = !on_device; dev = x;
+    if (staged) {
+      HIP_TRY(hipMalloc((void**)&dev, bytes ? bytes : 1));
+      HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return XCX_OK;
+  }
+  int end() {
+    if (staged) {
+      HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+      HIP_TRY(hipFree(dev));
+    }
+    return XCX_OK;
+  }
+};
+
+inline int grid_for(long total) {
+  long g = (total + NT - 1) / NT;
+  return (int)std::max(1L, std::min(g, 256L * 8));
+}
+
+template <int OP> int row_op(xcx_ctx* ctx, float* x, long batch, long n, int on_device) {
+  if (!ctx || !x) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || n < 1) return set_err(XCX_EINVAL, "batch and n must be >= 1");
+  HIP_TRY(hipSetDevice(ctx->device));
+  Staged st;
+  int rc = st.begin(ctx, x, (size_t)batch * n * sizeof(float), on_device);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_row_reduce_apply<OP>, dim3((unsigned)batch), dim3(NT), 0, ctx->stream, st.dev, n);
+  HIP_TRY(hipGetLastError());
+  return st.end();
+}
+
+}  // namespace
+
+extern "C" int xcx_norm1d(xcx_ctx* ctx, float* x, long batch, long n, int on_device) {
+  return row_op<OP_NORM>(ctx, x, batch, n, on_device);
+}
+extern "C" int xcx_demean(xcx_ctx* ctx, float* x, long batch, long n, int on_device) {
+  return row_op<OP_DEMEAN>(ctx, x, batch, n, on_device);
+}
+extern "C" int xcx_detrend_linear(xcx_ctx* ctx, float* x, long batch, long n, int on_device) {
+  return row_op<OP_DETREND>(ctx, x, batch, n, on_device);
+}
+
+extern "C" int xcx_taper(xcx_ctx* ctx, float* x, long batch, long n, long nmax, int wtype, int on_device) {
+  if (!ctx || !x) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || n < 1) return set_err(XCX_EINVAL, "batch and n must be >= 1");
+  if (nmax < 1 || nmax > n)
+    return set_err(XCX_EINVAL, "taper length nmax=%ld must be in [1, n=%ld]", nmax, n);
+  if (wtype != 0 && wtype != 1) return set_err(XCX_EINVAL, "wtype must be 0 (hann) or 1 (obspy cosine)");
+  HIP_TRY(hipSetDevice(ctx->device));
+  Staged st;
+  int rc = st.begin(ctx, x, (size_t)batch * n * sizeof(float), on_device);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_taper, dim3(grid_for(batch * 2 * nmax)), dim3(NT), 0, ctx->stream, st.dev, batch, n, nmax, wtype);
+  HIP_TRY(hipGetLastError());
+  return st.end();
+}
+
+extern "C" int xcx_unbias(xcx_ctx* ctx, float* x, long batch, long npts, long idx_min, long idx_max, int on_device) {
+  if (!ctx || !x) return set_err(XCX_EINVAL, "null argument");
+  if (idx_max == 0) idx_max = 2 * npts - 1;
+  if (batch < 1 || npts < 1 || idx_min < 0 || idx_max > 2 * npts - 1 || idx_min >= idx_max)
+    return set_err(XCX_EINVAL, "bad unbias arguments");
+  const long L = idx_max - idx_min;
+  HIP_TRY(hipSetDevice(ctx->device));
+  Staged st;
+  int rc = st.begin(ctx, x, (size_t)batch * L * sizeof(float), on_device);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_unbias, dim3(grid_for(batch * L)), dim3(NT), 0, ctx->stream, st.dev, batch, L, npts, idx_min);
+  HIP_TRY(hipGetLastError());
+  return st.end();
+}
+
+extern "C" int xcx_onebit(xcx_ctx* ctx, float* x, long batch, long n, int on_device) {
+  if (!ctx || !x) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || n < 1) return set_err(XCX_EINVAL, "batch and n must be >= 1");
+  HIP_TRY(hipSetDevice(ctx->device));
+  Staged st;
+  int rc = st.begin(ctx, x, (size_t)batch * n * sizeof(float), on_device);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_onebit, dim3(grid_for(batch * n)), dim3(NT), 0, ctx->stream, st.dev, batch * n);
+  HIP_TRY(hipGetLastError());
+  return st.end();
+}

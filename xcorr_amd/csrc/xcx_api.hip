@@ -1,0 +1,634 @@
+// xcx_api.hip -- C ABI (include/xcx.h): context, planner, and the
+// pair x window cross-correlation driver.  No exceptions cross the boundary.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/xcx.h"
+#include "cc_launch.h"
+#include "xcx_internal.h"
+
+using namespace xcx;
+
+// ---------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------
+namespace xcx {
+static thread_local std::string g_err;
+int set_err(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+}  // namespace xcx
+
+#define HIP_TRY(expr)                                                     \
+  do {                                                                    \
+    hipError_t e_ = (expr);                                               \
+    if (e_ != hipSuccess)                                                 \
+      return set_err(e_ == hipErrorOutOfMemory ? XCX_ENOMEM : XCX_EHIP,   \
+                     "%s: %s (%s:%d)", #expr, hipGetErrorString(e_),      \
+                     __FILE__, __LINE__);                                 \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// launch tables
+// ---------------------------------------------------------------------------
+#define XCX_COL_ROW(L) {L, launch_fwd_cols_##L, launch_pair_cols_##L},
+#define XCX_ROW_ROW(L) {L, launch_fwd_rows_##L, launch_pair_rows_##L},
+static const ColEntry kCols[] = {XCX_COL_LIST(XCX_COL_ROW)};
+static const RowEntry kRows[] = {XCX_ROW_LIST(XCX_ROW_ROW)};
+static const int kNCols = sizeof(kCols) / sizeof(kCols[0]);
+static const int kNRows = sizeof(kRows) / sizeof(kRows[0]);
+
+// ---------------------------------------------------------------------------
+// k_stats: one workgroup per station-window; mean (optional) and the scale
+//   1 / (||x'|| * sqrt(N))   with x' the demeaned / one-bit window
+// (normalize off: 1/sqrt(N)).  Double accumulation, fixed order.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kNT) void k_stats(
+    const float* __restrict__ traces, long stride_s, long stride_w, int W,
+    int w0, int sw0, int n, int N, int flags, float fixed_norm,
+    SwStat* __restrict__ stats) {
+  __shared__ double red[kNT];
+  const int sw = sw0 + blockIdx.x;    // s * W + wl
+  const int s = sw / W, wl = sw % W;
+  const float* x = traces + (long)s * stride_s + (long)(w0 + wl) * stride_w;
+  const int tid = threadIdx.x;
+  double mean = 0.0;
+  if (flags & XCX_F_DEMEAN) {
+    double acc = 0.0;
+    for (int i = tid; i < n; i += kNT) acc += (double)x[i];
+    red[tid] = acc;
+    __syncthreads();
+    for (int o = kNT / 2; o > 0; o >>= 1) {
+      if (tid < o) red[tid] += red[tid + o];
+      __syncthreads();
+    }
+    mean = red[0] / (double)n;
+    __syncthreads();
+  }
+  const float fmean = (float)mean;
+  double acc = 0.0;
+  for (int i = tid; i < n; i += kNT) {
+    float v = x[i] - fmean;
+    if (flags & XCX_F_ONEBIT) v = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
+    acc += (double)v * (double)v;
+  }
+  red[tid] = acc;
+  __syncthreads();
+  for (int o = kNT / 2; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    double nrm = 1.0;
+    if (flags & XCX_F_NORMALIZE)
+      nrm = (flags & XCX_F_WHITEN) ? (double)fixed_norm : sqrt(red[0]);
+    SwStat st;
+    st.mean = fmean;
+    st.scale = (float)(1.0 / (nrm * sqrt((double)N)));
+    stats[blockIdx.x] = st;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------
+extern "C" int xcx_device_count(int* count) {
+  if (!count) return set_err(XCX_EINVAL, "count is null");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess) { *count = 0; return set_err(XCX_ENODEV, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+  *count = c;
+  return XCX_OK;
+}
+
+extern "C" int xcx_init(int device, xcx_ctx** out) {
+  if (!out) return set_err(XCX_EINVAL, "ctx out pointer is null");
+  int c = 0;
+  hipError_t e = hipGetDeviceCount(&c);
+  if (e != hipSuccess || c == 0)
+    return set_err(XCX_ENODEV, "no HIP device available (%s)",
+                   e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+  if (device < 0 || device >= c)
+    return set_err(XCX_EINVAL, "device %d out of range [0,%d)", device, c);
+  HIP_TRY(hipSetDevice(device));
+  xcx_ctx* ctx = new (std::nothrow) xcx_ctx();
+  if (!ctx) return set_err(XCX_ENOMEM, "host allocation failed");
+  ctx->device = device;
+  HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  HIP_TRY(hipEventCreate(&ctx->ev0));
+  HIP_TRY(hipEventCreate(&ctx->ev1));
+  *out = ctx;
+  return XCX_OK;
+}
+
+extern "C" int xcx_destroy(xcx_ctx* ctx) {
+  if (!ctx) return XCX_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  xcx_comm_destroy(ctx);
+  hipEventDestroy(ctx->ev0);
+  hipEventDestroy(ctx->ev1);
+  hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return XCX_OK;
+}
+
+extern "C" int xcx_last_error(char* buf, size_t len) {
+  if (!buf || len == 0) return XCX_EINVAL;
+  snprintf(buf, len, "%s", g_err.c_str());
+  return XCX_OK;
+}
+
+extern "C" int xcx_device_name(xcx_ctx* ctx, char* buf, size_t len) {
+  if (!ctx || !buf) return set_err(XCX_EINVAL, "null argument");
+  hipDeviceProp_t p;
+  HIP_TRY(hipGetDeviceProperties(&p, ctx->device));
+  snprintf(buf, len, "%s %s cu=%d", p.name, p.gcnArchName, p.multiProcessorCount);
+  return XCX_OK;
+}
+
+extern "C" int xcx_malloc(xcx_ctx* ctx, size_t bytes, void** dptr) {
+  if (!ctx || !dptr) return set_err(XCX_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipMalloc(dptr, bytes ? bytes : 1));
+  return XCX_OK;
+}
+extern "C" int xcx_free(xcx_ctx* ctx, void* dptr) {
+  if (!ctx) return set_err(XCX_EINVAL, "null ctx");
+  if (!dptr) return XCX_OK;
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  HIP_TRY(hipFree(dptr));
+  return XCX_OK;
+}
+extern "C" int xcx_memset(xcx_ctx* ctx, void* dptr, int value, size_t bytes) {
+  if (!ctx || !dptr) return set_err(XCX_EINVAL, "null argument");
+  HIP_TRY(hipMemsetAsync(dptr, value, bytes, ctx->stream));
+  return XCX_OK;
+}
+extern "C" int xcx_memcpy_h2d(xcx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || !dst || !src) return set_err(XCX_EINVAL, "null argument");
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return XCX_OK;
+}
+extern "C" int xcx_memcpy_d2h(xcx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || !dst || !src) return set_err(XCX_EINVAL, "null argument");
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return XCX_OK;
+}
+extern "C" int xcx_memcpy2d_d2h(xcx_ctx* ctx, void* dst, size_t dpitch, const void* src,
+                                size_t spitch, size_t width_bytes, size_t rows) {
+  if (!ctx || !dst || !src) return set_err(XCX_EINVAL, "null argument");
+  HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows,
+                           hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return XCX_OK;
+}
+extern "C" int xcx_sync(xcx_ctx* ctx) {
+  if (!ctx) return set_err(XCX_EINVAL, "null ctx");
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return XCX_OK;
+}
+extern "C" int xcx_timer_start(xcx_ctx* ctx) {
+  if (!ctx) return set_err(XCX_EINVAL, "null ctx");
+  HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  return XCX_OK;
+}
+extern "C" int xcx_timer_stop(xcx_ctx* ctx, float* ms) {
+  if (!ctx || !ms) return set_err(XCX_EINVAL, "null argument");
+  HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(hipEventSynchronize(ctx->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+  return XCX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// workspace helper
+// ---------------------------------------------------------------------------
+namespace xcx {
+int DevBuf::ensure(xcx_ctx* ctx, size_t need) {
+  if (need <= bytes) return XCX_OK;
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (ptr) HIP_TRY(hipFree(ptr));
+  ptr = nullptr;
+  bytes = 0;
+  HIP_TRY(hipMalloc(&ptr, need));
+  bytes = need;
+  return XCX_OK;
+}
+void DevBuf::release() {
+  if (ptr) hipFree(ptr);
+  ptr = nullptr;
+  bytes = 0;
+}
+}  // namespace xcx
+
+// ---------------------------------------------------------------------------
+// plan
+// ---------------------------------------------------------------------------
+struct xcx_plan {
+  xcx_ctx* ctx = nullptr;
+  Geom g{};
+  const ColEntry* col = nullptr;
+  const RowEntry* row = nullptr;
+  int L = 0;                 // retained lags
+  int batch = 64;            // pair-windows per launch batch
+  size_t spec_pitch = 0;     // float2 per spectrum slot
+  // whitening
+  float wb[4] = {0, 0, 0, 0};
+  float fixed_norm = 1.f;
+  bool whiten_set = false;
+  // tables
+  DevBuf tw_N1, tw_N2h, tw_unt, tw_N;
+  // workspaces
+  DevBuf stats, Tm_f, Tn_f, spectra, T, descs, dtraces, dout, dpairs;
+  std::vector<PwDesc> hdescs;
+  unsigned long long desc_key = 0;
+  long long launches = 0, pair_windows = 0;
+};
+
+static void fill_table(std::vector<float2>& v, int count, int L, int mul = 1) {
+  v.resize(count);
+  for (int q = 0; q < count; ++q) {
+    // exact reduction of (q*mul) mod L before the trig call
+    long long a = ((long long)q * mul) % L;
+    double th = -2.0 * M_PI * (double)a / (double)L;
+    v[q] = make_float2((float)cos(th), (float)sin(th));
+  }
+}
+
+static int upload(xcx_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
+  int rc = b.ensure(ctx, bytes);
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(b.ptr, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return XCX_OK;
+}
+
+extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
+                             int idx_max, int flags, xcx_plan** out) {
+  if (!ctx || !out) return set_err(XCX_EINVAL, "null argument");
+  if (n < 1) return set_err(XCX_EINVAL, "n must be >= 1 (got %d)", n);
+  const long long full = 2LL * n - 1;
+  if (idx_max == 0) idx_max = (int)full;
+  if (idx_min < 0 || idx_max > full || idx_min >= idx_max)
+    return set_err(XCX_EINVAL, "lag slice [%d,%d) outside [0,%lld)", idx_min,
+                   idx_max, full);
+  // choose N = 2*N1*N2h: smallest supported >= 2n-1 (or == nfft)
+  long long best = -1;
+  const ColEntry* bc = nullptr;
+  const RowEntry* br = nullptr;
+  for (int i = 0; i < kNCols; ++i)
+    for (int j = 0; j < kNRows; ++j) {
+      long long N = 2LL * kCols[i].L * kRows[j].L;
+      if (N < full) continue;
+      if (nfft > 0 && N != nfft) continue;
+      // among equal N prefer the most balanced split
+      bool better = best < 0 || N < best ||
+                    (N == best && std::abs(kCols[i].L - kRows[j].L) <
+                                      std::abs(bc->L - br->L));
+      if (better) { best = N; bc = &kCols[i]; br = &kRows[j]; }
+    }
+  if (best < 0)
+    return set_err(XCX_EUNSUPPORTED,
+                   "no supported transform length for n=%d (nfft=%d); "
+                   "supported N = 2*N1*N2h up to %d", n, nfft,
+                   2 * kCols[kNCols - 1].L * kRows[kNRows - 1].L);
+  HIP_TRY(hipSetDevice(ctx->device));
+  xcx_plan* p = new (std::nothrow) xcx_plan();
+  if (!p) return set_err(XCX_ENOMEM, "host allocation failed");
+  p->ctx = ctx;
+  p->col = bc;
+  p->row = br;
+  Geom& g = p->g;
+  g.n = n;
+  g.N = (int)best;
+  g.N1 = bc->L;
+  g.N2h = br->L;
+  g.N2 = 2 * br->L;
+  g.idx_min = idx_min;
+  g.idx_max = idx_max;
+  g.shift = (int)(((long long)n - 1 - idx_min) % g.N1);
+  if (g.shift < 0) g.shift += g.N1;
+  g.flags = flags;
+  p->L = idx_max - idx_min;
+  size_t sp = (size_t)g.N1 * g.N2h + g.N1;
+  p->spec_pitch = (sp + 15) / 16 * 16;
+
+  std::vector<float2> t;
+  int rc;
+  fill_table(t, g.N1, g.N1);
+  if ((rc = upload(ctx, p->tw_N1, t.data(), t.size() * sizeof(float2)))) { delete p; return rc; }
+  fill_table(t, g.N2h, g.N2h);
+  if ((rc = upload(ctx, p->tw_N2h, t.data(), t.size() * sizeof(float2)))) { delete p; return rc; }
+  fill_table(t, g.N2h, g.N2);
+  if ((rc = upload(ctx, p->tw_unt, t.data(), t.size() * sizeof(float2)))) { delete p; return rc; }
+  {
+    const int nhi = (g.N / 2) / kTwQL + 2;
+    std::vector<float2> lo, hi;
+    fill_table(lo, kTwQL, g.N);
+    fill_table(hi, nhi, g.N, kTwQL);
+    lo.insert(lo.end(), hi.begin(), hi.end());
+    if ((rc = upload(ctx, p->tw_N, lo.data(), lo.size() * sizeof(float2)))) { delete p; return rc; }
+  }
+  *out = p;
+  return XCX_OK;
+}
+
+extern "C" int xcx_plan_destroy(xcx_plan* p) {
+  if (!p) return XCX_OK;
+  hipSetDevice(p->ctx->device);
+  hipStreamSynchronize(p->ctx->stream);
+  DevBuf* bufs[] = {&p->tw_N1, &p->tw_N2h, &p->tw_unt, &p->tw_N, &p->stats,
+                    &p->Tm_f, &p->Tn_f, &p->spectra, &p->T, &p->descs,
+                    &p->dtraces, &p->dout, &p->dpairs};
+  for (DevBuf* b : bufs) b->release();
+  delete p;
+  return XCX_OK;
+}
+
+extern "C" int xcx_plan_set_whiten(xcx_plan* p, double fs, double fmin,
+                                   double fmax, double ftaper) {
+  if (!p) return set_err(XCX_EINVAL, "null plan");
+  if (!(fs > 0) || !(fmin >= 0) || !(fmax > fmin) || ftaper < 0)
+    return set_err(XCX_EINVAL, "bad whitening band");
+  const double bin = (double)p->g.N / fs;   // bins per Hz
+  p->wb[0] = (float)((fmin - ftaper) * bin);
+  p->wb[1] = (float)(fmin * bin);
+  p->wb[2] = (float)(fmax * bin);
+  p->wb[3] = (float)((fmax + ftaper) * bin);
+  // Parseval norm of the ideal whitened spectrum |X[k]| = g[k]
+  const int N = p->g.N;
+  double acc = 0.0;
+  for (int k = 0; k <= N / 2; ++k) {
+    float f = (float)k;
+    double gk;
+    if (f >= p->wb[1] && f <= p->wb[2]) gk = 1.0;
+    else if (f >= p->wb[0] && f < p->wb[1])
+      gk = 0.5 * (1.0 - cos(M_PI * (f - p->wb[0]) / (p->wb[1] - p->wb[0])));
+    else if (f > p->wb[2] && f <= p->wb[3])
+      gk = 0.5 * (1.0 + cos(M_PI * (f - p->wb[2]) / (p->wb[3] - p->wb[2])));
+    else gk = 0.0;
+    acc += ((k == 0 || k == N / 2) ? 1.0 : 2.0) * gk * gk;
+  }
+  p->fixed_norm = (float)sqrt(acc / N);
+  p->whiten_set = true;
+  return XCX_OK;
+}
+
+extern "C" int xcx_plan_set_batch(xcx_plan* p, int b) {
+  if (!p || b < 1 || b > 65535) return set_err(XCX_EINVAL, "batch must be in [1,65535]");
+  p->batch = b;
+  p->desc_key = 0;
+  return XCX_OK;
+}
+
+extern "C" int xcx_plan_info(xcx_plan* p, int* out6) {
+  if (!p || !out6) return set_err(XCX_EINVAL, "null argument");
+  out6[0] = p->g.N; out6[1] = p->g.N1; out6[2] = p->g.N2; out6[3] = p->L;
+  out6[4] = p->batch; out6[5] = (int)(2 * p->spec_pitch);
+  return XCX_OK;
+}
+
+extern "C" int xcx_plan_counters(xcx_plan* p, long long* launches, long long* pw) {
+  if (!p) return set_err(XCX_EINVAL, "null plan");
+  if (launches) *launches = p->launches;
+  if (pw) *pw = p->pair_windows;
+  return XCX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// forward: station-windows sw in [sw_begin, sw_end) of an S x W grid
+// (sw = s*W + wl, window index w0 + wl) -> spectrum slots slot0 + sw
+// ---------------------------------------------------------------------------
+static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_w,
+                   int W, int w0, int sw_begin, int sw_end, int slot0) {
+  xcx_ctx* ctx = p->ctx;
+  const Geom& g = p->g;
+  const int kChunk = 64;
+  const size_t tm_per = (size_t)g.N1 * g.N2h;
+  int rc;
+  if ((g.flags & XCX_F_WHITEN) && !p->whiten_set)
+    return set_err(XCX_EINVAL, "XCX_WHITEN set but xcx_plan_set_whiten() not called");
+  if ((rc = p->stats.ensure(ctx, sizeof(SwStat) * kChunk))) return rc;
+  if ((rc = p->Tm_f.ensure(ctx, sizeof(cf) * tm_per * kChunk))) return rc;
+  if ((rc = p->Tn_f.ensure(ctx, sizeof(cf) * g.N1 * kChunk))) return rc;
+  for (int b = sw_begin; b < sw_end; b += kChunk) {
+    const int cnt = std::min(kChunk, sw_end - b);
+    hipLaunchKernelGGL(k_stats, dim3(cnt), dim3(kNT), 0, ctx->stream, traces,
+                       stride_s, stride_w, W, w0, b, g.n, g.N, g.flags,
+                       p->fixed_norm, (SwStat*)p->stats.ptr);
+    HIP_TRY(hipGetLastError());
+    F1Args f1{};
+    f1.traces = traces; f1.stride_s = stride_s; f1.stride_w = stride_w;
+    f1.W = W; f1.w0 = w0; f1.sw0 = b;
+    f1.stats = (const SwStat*)p->stats.ptr;
+    f1.Tm = (cf*)p->Tm_f.ptr; f1.Tn = (cf*)p->Tn_f.ptr;
+    f1.tw_sub = (const cf*)p->tw_N2h.ptr;
+    f1.tw_unt = (const cf*)p->tw_unt.ptr;
+    f1.tw_N = (const cf*)p->tw_N.ptr;
+    f1.g = g;
+    HIP_TRY(p->row->fwd(f1, dim3(g.N1 / kRB, cnt), ctx->stream));
+    F2Args f2{};
+    f2.Tm = (const cf*)p->Tm_f.ptr; f2.Tn = (const cf*)p->Tn_f.ptr;
+    f2.stats = (const SwStat*)p->stats.ptr;
+    f2.Xm = (cf*)p->spectra.ptr;
+    f2.Xn = (cf*)p->spectra.ptr + tm_per;
+    f2.spec_pitch = p->spec_pitch;
+    f2.slot0 = slot0 + b;
+    f2.tw_sub = (const cf*)p->tw_N1.ptr;
+    f2.wb0 = p->wb[0]; f2.wb1 = p->wb[1]; f2.wb2 = p->wb[2]; f2.wb3 = p->wb[3];
+    f2.g = g;
+    HIP_TRY(p->col->fwd(f2, dim3(g.N2h / kCB + 1, cnt), ctx->stream));
+    p->launches += 3;
+  }
+  return XCX_OK;
+}
+
+// pair-window batch: descriptors [d0, d0+B) of the device descriptor array
+static int pair_batch(xcx_plan* p, size_t d0, int B, float* out, int nstack) {
+  xcx_ctx* ctx = p->ctx;
+  const Geom& g = p->g;
+  const size_t tm_per = (size_t)g.N1 * g.N2h;
+  I1Args a{};
+  a.Xm = (const cf*)p->spectra.ptr;
+  a.Xn = (const cf*)p->spectra.ptr + tm_per;
+  a.spec_pitch = p->spec_pitch;
+  a.pw = (const PwDesc*)p->descs.ptr + d0;
+  a.B = B;
+  a.nstack = nstack;
+  a.stack_stride = 1;
+  a.T = (cf*)p->T.ptr;
+  a.tw_sub = (const cf*)p->tw_N1.ptr;
+  a.tw_N = (const cf*)p->tw_N.ptr;
+  a.g = g;
+  const int ncbt = g.N2h / kCB + 1;
+  const int per_xcd = (ncbt + 7) / 8;
+  HIP_TRY(p->col->pair(a, dim3(8u * per_xcd * B), ctx->stream));
+  I2Args r{};
+  r.T = (const cf*)p->T.ptr;
+  r.pw = a.pw;
+  r.out = out;
+  r.tw_sub = (const cf*)p->tw_N2h.ptr;
+  r.tw_unt = (const cf*)p->tw_unt.ptr;
+  r.g = g;
+  HIP_TRY(p->row->pair(r, dim3(g.N1 / kRB, B), ctx->stream));
+  p->launches += 2;
+  p->pair_windows += B;
+  return XCX_OK;
+}
+
+static unsigned long long fnv(const void* data, size_t bytes, unsigned long long h) {
+  const unsigned char* c = (const unsigned char*)data;
+  for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ULL; }
+  return h;
+}
+
+extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
+                              long stride_s, long stride_w, const int* pairs,
+                              int P, float* out, long ld_out, int on_device) {
+  if (!p || !traces || !pairs || !out) return set_err(XCX_EINVAL, "null argument");
+  if (S < 1 || W < 1 || P < 1) return set_err(XCX_EINVAL, "S, W, P must be >= 1");
+  xcx_ctx* ctx = p->ctx;
+  const Geom& g = p->g;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const bool stack = g.flags & XCX_F_STACK;
+  const long L = p->L;
+  if (ld_out == 0) ld_out = L;
+  if (ld_out < L) return set_err(XCX_EINVAL, "ld_out (%ld) < L (%ld)", ld_out, L);
+  if (stride_s < 0 || stride_w < 0) return set_err(XCX_EINVAL, "negative stride");
+  for (int i = 0; i < P; ++i)
+    if (pairs[2 * i] < 0 || pairs[2 * i] >= S || pairs[2 * i + 1] < 0 || pairs[2 * i + 1] >= S)
+      return set_err(XCX_EINVAL, "pair %d = (%d,%d) outside [0,%d)", i, pairs[2 * i], pairs[2 * i + 1], S);
+  if ((long long)S * W > 0x7fffffffLL / 2) return set_err(XCX_EINVAL, "S*W too large");
+  int rc;
+  const float* dtr = traces;
+  float* dout = out;
+  const size_t nrows = stack ? (size_t)P : (size_t)P * W;
+  if (!on_device) {
+    const size_t span = (size_t)(S - 1) * stride_s + (size_t)(W - 1) * stride_w + g.n;
+    if ((rc = p->dtraces.ensure(ctx, span * sizeof(float)))) return rc;
+    HIP_TRY(hipMemcpyAsync(p->dtraces.ptr, traces, span * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = p->dout.ensure(ctx, nrows * (size_t)ld_out * sizeof(float)))) return rc;
+    dtr = (const float*)p->dtraces.ptr;
+    dout = (float*)p->dout.ptr;
+  }
+  // processing order: pairs grouped by 8x8 station tiles so that one launch
+  // batch touches few distinct spectra (L2 / Infinity-Cache reuse)
+  unsigned long long key = fnv(pairs, sizeof(int) * 2 * (size_t)P, 1469598103934665603ULL);
+  int hdr[4] = {S, W, P, (int)stack};
+  key = fnv(hdr, sizeof hdr, key);
+  key = fnv(&ld_out, sizeof ld_out, key);
+  const size_t ndesc = stack ? (size_t)P : (size_t)P * W;
+  if (key != p->desc_key || p->hdescs.size() != ndesc) {
+    std::vector<int> perm(P);
+    for (int i = 0; i < P; ++i) perm[i] = i;
+    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
+      int ta = (pairs[2 * a] >> 3) * 8192 + (pairs[2 * a + 1] >> 3);
+      int tb = (pairs[2 * b] >> 3) * 8192 + (pairs[2 * b + 1] >> 3);
+      return ta < tb;
+    });
+    p->hdescs.resize(ndesc);
+    if (stack) {
+      for (int q = 0; q < P; ++q) {
+        int pi = perm[q];
+        p->hdescs[q] = PwDesc{pairs[2 * pi] * W, pairs[2 * pi + 1] * W, (long long)pi * ld_out};
+      }
+    } else {
+      for (int w = 0; w < W; ++w)
+        for (int q = 0; q < P; ++q) {
+          int pi = perm[q];
+          p->hdescs[(size_t)w * P + q] =
+              PwDesc{pairs[2 * pi], pairs[2 * pi + 1], ((long long)pi * W + w) * ld_out};
+        }
+    }
+    if ((rc = upload(ctx, p->descs, p->hdescs.data(), ndesc * sizeof(PwDesc)))) return rc;
+    p->desc_key = key;
+  }
+  const int B = p->batch;
+  const size_t tm_per = (size_t)g.N1 * g.N2h;
+  if ((rc = p->T.ensure(ctx, sizeof(cf) * tm_per * B))) return rc;
+  if (stack) {
+    if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)S * W))) return rc;
+    if ((rc = forward(p, dtr, stride_s, stride_w, W, 0, 0, S * W, 0))) return rc;
+    for (size_t d0 = 0; d0 < (size_t)P; d0 += B)
+      if ((rc = pair_batch(p, d0, (int)std::min((size_t)B, P - d0), dout, W))) return rc;
+  } else {
+    if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)S))) return rc;
+    for (int w = 0; w < W; ++w) {
+      // one window of every station: sw = s*1 + 0 with window index w
+      if ((rc = forward(p, dtr, stride_s, stride_w, 1, w, 0, S, 0))) return rc;
+      for (size_t q0 = 0; q0 < (size_t)P; q0 += B)
+        if ((rc = pair_batch(p, (size_t)w * P + q0, (int)std::min((size_t)B, P - q0), dout, 1))) return rc;
+    }
+  }
+  if (!on_device) {
+    HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld_out * sizeof(float), dout, (size_t)ld_out * sizeof(float),
+                             (size_t)L * sizeof(float), nrows, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  return XCX_OK;
+}
+
+extern "C" int xcx_cc1d(xcx_plan* p, const float* x, const float* y, int batch,
+                        float* out, int on_device) {
+  if (!p || !x || !y || !out) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1) return set_err(XCX_EINVAL, "batch must be >= 1");
+  xcx_ctx* ctx = p->ctx;
+  const Geom& g = p->g;
+  if (g.flags & XCX_F_STACK) return set_err(XCX_EINVAL, "xcx_cc1d does not stack");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const long L = p->L;
+  const int n = g.n;
+  int rc;
+  const int kRows = 256;   // rows per chunk
+  const size_t tm_per = (size_t)g.N1 * g.N2h;
+  if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * 2 * (size_t)std::min(batch, kRows)))) return rc;
+  if ((rc = p->T.ensure(ctx, sizeof(cf) * tm_per * p->batch))) return rc;
+  if ((rc = p->descs.ensure(ctx, sizeof(PwDesc) * kRows))) return rc;
+  p->desc_key = 0;
+  const float *dx = x, *dy = y;
+  float* dout = out;
+  if (!on_device) {
+    const size_t inb = (size_t)batch * n * sizeof(float);
+    if ((rc = p->dtraces.ensure(ctx, 2 * inb))) return rc;
+    HIP_TRY(hipMemcpyAsync(p->dtraces.ptr, x, inb, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync((char*)p->dtraces.ptr + inb, y, inb, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = p->dout.ensure(ctx, (size_t)batch * L * sizeof(float)))) return rc;
+    dx = (const float*)p->dtraces.ptr;
+    dy = dx + (size_t)batch * n;
+    dout = (float*)p->dout.ptr;
+  }
+  std::vector<PwDesc> d;
+  for (int r0 = 0; r0 < batch; r0 += kRows) {
+    const int cnt = std::min(kRows, batch - r0);
+    if ((rc = forward(p, dx + (size_t)r0 * n, n, 0, 1, 0, 0, cnt, 0))) return rc;
+    if ((rc = forward(p, dy + (size_t)r0 * n, n, 0, 1, 0, 0, cnt, cnt))) return rc;
+    d.resize(cnt);
+    for (int i = 0; i < cnt; ++i) d[i] = PwDesc{i, cnt + i, (long long)(r0 + i) * L};
+    HIP_TRY(hipMemcpyAsync(p->descs.ptr, d.data(), sizeof(PwDesc) * cnt, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int q0 = 0; q0 < cnt; q0 += p->batch)
+      if ((rc = pair_batch(p, q0, std::min(p->batch, cnt - q0), dout, 1))) return rc;
+  }
+  if (!on_device) {
+    HIP_TRY(hipMemcpyAsync(out, dout, (size_t)batch * L * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  return XCX_OK;
+}

@@ -1,0 +1,23 @@
+// xcx_internal.h -- shared between the translation units of libxcx.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+
+struct xcx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  void* comm = nullptr;      // ncclComm_t
+  int nranks = 1, rank = 0;
+};
+
+namespace xcx {
+int set_err(int code, const char* fmt, ...);
+
+struct DevBuf {
+  void* ptr = nullptr;
+  size_t bytes = 0;
+  int ensure(xcx_ctx* ctx, size_t need);   // grow-only
+  void release();
+};
+}  // namespace xcx

@@ -1,0 +1,232 @@
+"""
+Host-side handles over the C ABI: Context (one HIP device + stream),
+DeviceArray (caller-owned HBM buffer) and CCPlan (cross-correlation plan).
+
+This is plumbing only; all arithmetic happens in libxcx.so.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, ptr
+
+__all__ = ['Context', 'DeviceArray', 'CCPlan', 'default_context']
+
+
+class DeviceArray:
+    """A contiguous device buffer with numpy-like shape/dtype metadata."""
+
+    def __init__(self, ctx, shape, dtype=np.float32):
+        self.ctx = ctx
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape))
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        check(_ffi.lib().xcx_malloc(ctx.handle, self.nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            check(_ffi.lib().xcx_free(self.ctx.handle, C.c_void_p(self.ptr)))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def copy_from(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if a.nbytes != self.nbytes:
+            raise ValueError('size mismatch in copy_from')
+        check(_ffi.lib().xcx_memcpy_h2d(self.ctx.handle, C.c_void_p(self.ptr),
+                                        ptr(a), self.nbytes))
+        return self
+
+    def to_host(self):
+        out = np.empty(self.shape, dtype=self.dtype)
+        check(_ffi.lib().xcx_memcpy_d2h(self.ctx.handle, ptr(out),
+                                        C.c_void_p(self.ptr), self.nbytes))
+        return out
+
+    def rows_to_host(self, row0, nrows, width):
+        """Copy rows [row0, row0+nrows) of a 2-D buffer, first `width` cols."""
+        pitch = self.shape[-1] * self.dtype.itemsize
+        out = np.empty((nrows, width), dtype=self.dtype)
+        check(_ffi.lib().xcx_memcpy2d_d2h(
+            self.ctx.handle, ptr(out), width * self.dtype.itemsize,
+            C.c_void_p(self.ptr + row0 * pitch), pitch,
+            width * self.dtype.itemsize, nrows))
+        return out
+
+    def zero(self):
+        check(_ffi.lib().xcx_memset(self.ctx.handle, C.c_void_p(self.ptr), 0,
+                                    self.nbytes))
+        return self
+
+
+class Context:
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        check(_ffi.lib().xcx_init(int(device), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+
+    def close(self):
+        if self.handle:
+            _ffi.lib().xcx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def name(self):
+        buf = C.create_string_buffer(256)
+        check(_ffi.lib().xcx_device_name(self.handle, buf, 256))
+        return buf.value.decode()
+
+    def empty(self, shape, dtype=np.float32):
+        return DeviceArray(self, shape, dtype)
+
+    def array(self, a, dtype=None):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        return DeviceArray(self, a.shape, a.dtype).copy_from(a)
+
+    def sync(self):
+        check(_ffi.lib().xcx_sync(self.handle))
+
+    def timer_start(self):
+        check(_ffi.lib().xcx_timer_start(self.handle))
+
+    def timer_stop(self):
+        ms = C.c_float()
+        check(_ffi.lib().xcx_timer_stop(self.handle, C.byref(ms)))
+        return ms.value
+
+    # --- RCCL time-stack reduce -------------------------------------------
+    @staticmethod
+    def comm_unique_id():
+        buf = C.create_string_buffer(128)
+        check(_ffi.lib().xcx_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, uid, nranks, rank):
+        check(_ffi.lib().xcx_comm_init(self.handle, uid, nranks, rank))
+
+    def stack_reduce(self, stack, count=None, reduce_scatter=False):
+        n = int(count if count is not None else np.prod(stack.shape))
+        check(_ffi.lib().xcx_stack_reduce(self.handle, ptr(stack), n,
+                                          int(bool(reduce_scatter))))
+
+
+_default = {}
+
+
+def default_context(device=0):
+    """Process-wide context per device (created on first use)."""
+    if device not in _default:
+        _default[device] = Context(device)
+    return _default[device]
+
+
+class CCPlan:
+    """Plan for the batched cross-correlation (include/xcx.h: xcx_plan_cc1d).
+
+    n: window length; index_min/index_max: retained lag slice of the 2n-1 lags
+    (core/process.py:155-162); flags: normalize / unbias / stack / onebit /
+    whiten / demean.
+    """
+
+    def __init__(self, ctx, n, index_min=0, index_max=None, normalize=True,
+                 unbiased=False, stack=False, onebit=False, whiten=None,
+                 demean=False, nfft=0, batch=None):
+        self.ctx = ctx
+        self.n = int(n)
+        flags = 0
+        flags |= _ffi.NORMALIZE if normalize else 0
+        flags |= _ffi.UNBIAS if unbiased else 0
+        flags |= _ffi.STACK if stack else 0
+        flags |= _ffi.ONEBIT if onebit else 0
+        flags |= _ffi.WHITEN if whiten else 0
+        flags |= _ffi.DEMEAN if demean else 0
+        self.flags = flags
+        h = C.c_void_p()
+        check(_ffi.lib().xcx_plan_cc1d(ctx.handle, self.n, int(nfft),
+                                       int(index_min), int(index_max or 0),
+                                       flags, C.byref(h)))
+        self.handle = h
+        if whiten:
+            fs, fmin, fmax, ftaper = whiten
+            check(_ffi.lib().xcx_plan_set_whiten(h, fs, fmin, fmax, ftaper))
+        if batch:
+            check(_ffi.lib().xcx_plan_set_batch(h, int(batch)))
+        info = (C.c_int * 6)()
+        check(_ffi.lib().xcx_plan_info(h, info))
+        self.N, self.N1, self.N2, self.L, self.batch, self.spec_floats = info[:]
+        self.stack = bool(stack)
+
+    def close(self):
+        if self.handle:
+            _ffi.lib().xcx_plan_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def counters(self):
+        a, b = C.c_longlong(), C.c_longlong()
+        check(_ffi.lib().xcx_plan_counters(self.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def pairs(self, traces, pairs, W, stride_w, out=None, ld_out=0,
+              stride_s=None):
+        """All pairs x W windows.  `traces`: numpy [S, T] or DeviceArray [S, T];
+        window w of station s = traces[s, w*stride_w : w*stride_w + n].
+        Returns `out` (numpy [P, W, L] / [P, L] if stacking, or the DeviceArray
+        passed in)."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        P = pairs.shape[0]
+        S, T = traces.shape
+        stride_s = T if stride_s is None else stride_s
+        if (W - 1) * stride_w + self.n > T:
+            raise ValueError('windows exceed the trace length')
+        on_dev = isinstance(traces, DeviceArray)
+        if on_dev:
+            if not isinstance(out, DeviceArray):
+                raise ValueError('device traces need a DeviceArray `out`')
+        else:
+            traces = np.ascontiguousarray(traces, dtype=np.float32)
+            if out is None:
+                shape = (P, self.L) if self.stack else (P, W, self.L)
+                out = np.empty(shape, dtype=np.float32)
+        check(_ffi.lib().xcx_cc1d_pairs(
+            self.handle, ptr(traces), S, W, stride_s, stride_w, ptr(pairs), P,
+            ptr(out), int(ld_out), int(on_dev)))
+        return out
+
+    def cc(self, x, y, out=None):
+        """Batched two-input form: x, y [batch, n] -> [batch, L]."""
+        on_dev = isinstance(x, DeviceArray)
+        if not on_dev:
+            x = np.ascontiguousarray(x, dtype=np.float32)
+            y = np.ascontiguousarray(y, dtype=np.float32)
+        if x.shape != y.shape or x.shape[-1] != self.n:
+            raise ValueError('x and y must both be [batch, n]')
+        batch = int(np.prod(x.shape[:-1])) if len(x.shape) > 1 else 1
+        if out is None:
+            if on_dev:
+                out = self.ctx.empty((batch, self.L))
+            else:
+                out = np.empty(x.shape[:-1] + (self.L,), dtype=np.float32)
+        check(_ffi.lib().xcx_cc1d(self.handle, ptr(x), ptr(y), batch, ptr(out),
+                                  int(on_dev)))
+        return out
