@@ -62,6 +62,8 @@ int xcx_free(xcx_ctx* ctx, void* dptr);
 int xcx_memset(xcx_ctx* ctx, void* dptr, int value, size_t bytes);
 int xcx_memcpy_h2d(xcx_ctx* ctx, void* dst, const void* src, size_t bytes);
 int xcx_memcpy_d2h(xcx_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* asynchronous on the context's stream */
+int xcx_memcpy_d2d(xcx_ctx* ctx, void* dst, const void* src, size_t bytes);
 /* rows x width_bytes, with independent pitches (bytes) */
 int xcx_memcpy2d_d2h(xcx_ctx* ctx, void* dst, size_t dpitch, const void* src,
                      size_t spitch, size_t width_bytes, size_t rows);
@@ -114,6 +116,17 @@ int xcx_cc1d(xcx_plan* plan, const float* x, const float* y, int batch,
  * creation (bench bookkeeping) */
 int xcx_plan_counters(xcx_plan* plan, long long* launches,
                       long long* pair_windows);
+
+/* Per-kernel timing with HIP events recorded on the plan's stream around
+ * every launch (bench.py roofline leg).  enable != 0 clears and starts;
+ * xcx_plan_profile_read synchronises and returns, for kernel_id 0..4
+ * (k_stats, k_fwd_rows, k_fwd_cols, k_pair_cols, k_pair_rows), the summed
+ * duration, the launch count and the units (station-windows / pair-windows)
+ * those launches processed. */
+int xcx_plan_profile(xcx_plan* plan, int enable);
+int xcx_plan_profile_read(xcx_plan* plan, int kernel_id, char* name,
+                          size_t name_len, double* total_us,
+                          long long* launches, long long* units);
 
 /* ---- row-wise signal ops on [batch][n] float32, in place ----------------
  * norm1d  : x / ||x||_2                       (signal/normalize.py:73-80)

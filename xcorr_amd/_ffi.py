@@ -43,6 +43,7 @@ SIGNATURES = {
     'xcx_memset': [_vp, _vp, _i, _sz],
     'xcx_memcpy_h2d': [_vp, _vp, _vp, _sz],
     'xcx_memcpy_d2h': [_vp, _vp, _vp, _sz],
+    'xcx_memcpy_d2d': [_vp, _vp, _vp, _sz],
     'xcx_memcpy2d_d2h': [_vp, _vp, _sz, _vp, _sz, _sz, _sz],
     'xcx_sync': [_vp],
     'xcx_timer_start': [_vp],
@@ -57,6 +58,10 @@ SIGNATURES = {
     'xcx_cc1d': [_vp, _vp, _vp, _i, _vp, _i],
     'xcx_plan_counters': [_vp, C.POINTER(C.c_longlong),
                           C.POINTER(C.c_longlong)],
+    'xcx_plan_profile': [_vp, _i],
+    'xcx_plan_profile_read': [_vp, _i, C.c_char_p, _sz, _pd,
+                              C.POINTER(C.c_longlong),
+                              C.POINTER(C.c_longlong)],
     'xcx_norm1d': [_vp, _vp, _l, _l, _i],
     'xcx_demean': [_vp, _vp, _l, _l, _i],
     'xcx_detrend_linear': [_vp, _vp, _l, _l, _i],

@@ -136,12 +136,12 @@ extern "C" int xcx_init(int device, xcx_ctx** out) {
 
 extern "C" int xcx_destroy(xcx_ctx* ctx) {
   if (!ctx) return XCX_OK;
-  hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
   xcx_comm_destroy(ctx);
-  hipEventDestroy(ctx->ev0);
-  hipEventDestroy(ctx->ev1);
-  hipStreamDestroy(ctx->stream);
+  (void)hipEventDestroy(ctx->ev0);
+  (void)hipEventDestroy(ctx->ev1);
+  (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return XCX_OK;
 }
@@ -191,6 +191,11 @@ extern "C" int xcx_memcpy_d2h(xcx_ctx* ctx, void* dst, const void* src, size_t b
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return XCX_OK;
 }
+extern "C" int xcx_memcpy_d2d(xcx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || !dst || !src) return set_err(XCX_EINVAL, "null argument");
+  HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return XCX_OK;
+}
 extern "C" int xcx_memcpy2d_d2h(xcx_ctx* ctx, void* dst, size_t dpitch, const void* src,
                                 size_t spitch, size_t width_bytes, size_t rows) {
   if (!ctx || !dst || !src) return set_err(XCX_EINVAL, "null argument");
@@ -232,7 +237,7 @@ int DevBuf::ensure(xcx_ctx* ctx, size_t need) {
   return XCX_OK;
 }
 void DevBuf::release() {
-  if (ptr) hipFree(ptr);
+  if (ptr) (void)hipFree(ptr);
   ptr = nullptr;
   bytes = 0;
 }
@@ -260,6 +265,27 @@ struct xcx_plan {
   std::vector<PwDesc> hdescs;
   unsigned long long desc_key = 0;
   long long launches = 0, pair_windows = 0;
+  // optional per-kernel HIP-event timing (xcx_plan_profile)
+  bool profiling = false;
+  struct Ev { hipEvent_t a, b; int kid; int units; };
+  std::vector<Ev> evs;
+};
+
+enum { KID_STATS = 0, KID_FWD_ROWS, KID_FWD_COLS, KID_PAIR_COLS, KID_PAIR_ROWS, KID_COUNT };
+static const char* kKernelNames[KID_COUNT] = {"k_stats", "k_fwd_rows", "k_fwd_cols",
+                                              "k_pair_cols", "k_pair_rows"};
+
+struct ProfScope {
+  xcx_plan* p; size_t idx; bool on;
+  ProfScope(xcx_plan* p_, int kid, int units) : p(p_), idx(0), on(p_->profiling) {
+    if (!on) return;
+    xcx_plan::Ev e{nullptr, nullptr, kid, units};
+    if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) { on = false; return; }
+    (void)hipEventRecord(e.a, p->ctx->stream);
+    p->evs.push_back(e);
+    idx = p->evs.size() - 1;
+  }
+  ~ProfScope() { if (on) (void)hipEventRecord(p->evs[idx].b, p->ctx->stream); }
 };
 
 static void fill_table(std::vector<float2>& v, int count, int L, int mul = 1) {
@@ -352,8 +378,9 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
 
 extern "C" int xcx_plan_destroy(xcx_plan* p) {
   if (!p) return XCX_OK;
-  hipSetDevice(p->ctx->device);
-  hipStreamSynchronize(p->ctx->stream);
+  (void)hipSetDevice(p->ctx->device);
+  (void)hipStreamSynchronize(p->ctx->stream);
+  for (auto& e : p->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   DevBuf* bufs[] = {&p->tw_N1, &p->tw_N2h, &p->tw_unt, &p->tw_N, &p->stats,
                     &p->Tm_f, &p->Tn_f, &p->spectra, &p->T, &p->descs,
                     &p->dtraces, &p->dout, &p->dpairs};
@@ -412,6 +439,34 @@ extern "C" int xcx_plan_counters(xcx_plan* p, long long* launches, long long* pw
   return XCX_OK;
 }
 
+extern "C" int xcx_plan_profile(xcx_plan* p, int enable) {
+  if (!p) return set_err(XCX_EINVAL, "null plan");
+  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  for (auto& e : p->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  p->evs.clear();
+  p->profiling = enable != 0;
+  return XCX_OK;
+}
+
+extern "C" int xcx_plan_profile_read(xcx_plan* p, int kernel_id, char* name, size_t name_len,
+                                     double* total_us, long long* launches, long long* units) {
+  if (!p) return set_err(XCX_EINVAL, "null plan");
+  if (kernel_id < 0 || kernel_id >= KID_COUNT) return set_err(XCX_EINVAL, "kernel id out of range");
+  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  double tot = 0.0; long long nl = 0, nu = 0;
+  for (auto& e : p->evs) {
+    if (e.kid != kernel_id) continue;
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e.a, e.b));
+    tot += 1e3 * ms; nl += 1; nu += e.units;
+  }
+  if (name && name_len) snprintf(name, name_len, "%s", kKernelNames[kernel_id]);
+  if (total_us) *total_us = tot;
+  if (launches) *launches = nl;
+  if (units) *units = nu;
+  return XCX_OK;
+}
+
 // ---------------------------------------------------------------------------
 // forward: station-windows sw in [sw_begin, sw_end) of an S x W grid
 // (sw = s*W + wl, window index w0 + wl) -> spectrum slots slot0 + sw
@@ -430,9 +485,12 @@ static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_
   if ((rc = p->Tn_f.ensure(ctx, sizeof(cf) * g.N1 * kChunk))) return rc;
   for (int b = sw_begin; b < sw_end; b += kChunk) {
     const int cnt = std::min(kChunk, sw_end - b);
-    hipLaunchKernelGGL(k_stats, dim3(cnt), dim3(kNT), 0, ctx->stream, traces,
-                       stride_s, stride_w, W, w0, b, g.n, g.N, g.flags,
-                       p->fixed_norm, (SwStat*)p->stats.ptr);
+    {
+      ProfScope ps(p, KID_STATS, cnt);
+      hipLaunchKernelGGL(k_stats, dim3(cnt), dim3(kNT), 0, ctx->stream, traces,
+                         stride_s, stride_w, W, w0, b, g.n, g.N, g.flags,
+                         p->fixed_norm, (SwStat*)p->stats.ptr);
+    }
     HIP_TRY(hipGetLastError());
     F1Args f1{};
     f1.traces = traces; f1.stride_s = stride_s; f1.stride_w = stride_w;
@@ -443,7 +501,10 @@ static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_
     f1.tw_unt = (const cf*)p->tw_unt.ptr;
     f1.tw_N = (const cf*)p->tw_N.ptr;
     f1.g = g;
-    HIP_TRY(p->row->fwd(f1, dim3(g.N1 / kRB, cnt), ctx->stream));
+    {
+      ProfScope ps(p, KID_FWD_ROWS, cnt);
+      HIP_TRY(p->row->fwd(f1, dim3(g.N1 / kRB, cnt), ctx->stream));
+    }
     F2Args f2{};
     f2.Tm = (const cf*)p->Tm_f.ptr; f2.Tn = (const cf*)p->Tn_f.ptr;
     f2.stats = (const SwStat*)p->stats.ptr;
@@ -454,7 +515,10 @@ static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_
     f2.tw_sub = (const cf*)p->tw_N1.ptr;
     f2.wb0 = p->wb[0]; f2.wb1 = p->wb[1]; f2.wb2 = p->wb[2]; f2.wb3 = p->wb[3];
     f2.g = g;
-    HIP_TRY(p->col->fwd(f2, dim3(g.N2h / kCB + 1, cnt), ctx->stream));
+    {
+      ProfScope ps(p, KID_FWD_COLS, cnt);
+      HIP_TRY(p->col->fwd(f2, dim3(g.N2h / kCB + 1, cnt), ctx->stream));
+    }
     p->launches += 3;
   }
   return XCX_OK;
@@ -479,7 +543,10 @@ static int pair_batch(xcx_plan* p, size_t d0, int B, float* out, int nstack) {
   a.g = g;
   const int ncbt = g.N2h / kCB + 1;
   const int per_xcd = (ncbt + 7) / 8;
-  HIP_TRY(p->col->pair(a, dim3(8u * per_xcd * B), ctx->stream));
+  {
+    ProfScope ps(p, KID_PAIR_COLS, B);
+    HIP_TRY(p->col->pair(a, dim3(8u * per_xcd * B), ctx->stream));
+  }
   I2Args r{};
   r.T = (const cf*)p->T.ptr;
   r.pw = a.pw;
@@ -487,7 +554,10 @@ static int pair_batch(xcx_plan* p, size_t d0, int B, float* out, int nstack) {
   r.tw_sub = (const cf*)p->tw_N2h.ptr;
   r.tw_unt = (const cf*)p->tw_unt.ptr;
   r.g = g;
-  HIP_TRY(p->row->pair(r, dim3(g.N1 / kRB, B), ctx->stream));
+  {
+    ProfScope ps(p, KID_PAIR_ROWS, B);
+    HIP_TRY(p->row->pair(r, dim3(g.N1 / kRB, B), ctx->stream));
+  }
   p->launches += 2;
   p->pair_windows += B;
   return XCX_OK;

@@ -187,6 +187,27 @@ class CCPlan:
         check(_ffi.lib().xcx_plan_counters(self.handle, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def profile_step(self, fn):
+        """Run fn() once with per-kernel HIP-event timing enabled; returns
+        {kernel: {avg_us, total_us, launches, units_per_launch}}."""
+        L = _ffi.lib()
+        check(L.xcx_plan_profile(self.handle, 1))
+        fn()
+        out = {}
+        for kid in range(5):
+            name = C.create_string_buffer(64)
+            tot, nl, nu = C.c_double(), C.c_longlong(), C.c_longlong()
+            check(L.xcx_plan_profile_read(self.handle, kid, name, 64,
+                                          C.byref(tot), C.byref(nl),
+                                          C.byref(nu)))
+            if nl.value:
+                out[name.value.decode()] = {
+                    'total_us': tot.value, 'launches': nl.value,
+                    'avg_us': tot.value / nl.value,
+                    'units_per_launch': nu.value / nl.value}
+        check(L.xcx_plan_profile(self.handle, 0))
+        return out
+
     def pairs(self, traces, pairs, W, stride_w, out=None, ld_out=0,
               stride_s=None):
         """All pairs x W windows.  `traces`: numpy [S, T] or DeviceArray [S, T];

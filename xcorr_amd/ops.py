@@ -1,0 +1,122 @@
+"""
+Row-wise signal operations on plain arrays (core dimension last), executed by
+libxcx.so.  Inputs are float32 numpy arrays ``[..., n]`` (a processed copy is
+returned) or DeviceArrays ``[batch, n]`` (processed in place in HBM).
+
+These are the numpy-level kernels underneath the reference's
+``xr.apply_ufunc`` closures; ``xcorr_amd.signal`` wraps them with the
+reference's labelled-array interface.
+"""
+import numpy as np
+
+from . import _ffi
+from ._ffi import check, ptr
+from .engine import DeviceArray, default_context
+
+__all__ = ['copy', 'norm1d', 'demean', 'detrend_linear', 'taper', 'unbias',
+           'onebit', 'sosfiltfilt', 'sosfilt']
+
+
+def _prep(x):
+    """-> (buffer, batch, n, on_device, restore)"""
+    if isinstance(x, DeviceArray):
+        n = x.shape[-1]
+        batch = int(np.prod(x.shape[:-1])) if len(x.shape) > 1 else 1
+        return x, batch, n, 1, None
+    a = np.array(x, dtype=np.float32, order='C', copy=True)
+    if a.ndim == 0:
+        raise ValueError('array with at least one dimension required')
+    n = a.shape[-1]
+    batch = int(np.prod(a.shape[:-1])) if a.ndim > 1 else 1
+    return a, batch, n, 0, a
+
+
+def copy(ctx, dst, src):
+    check(_ffi.lib().xcx_memcpy_d2d(ctx.handle, ptr(dst), ptr(src), src.nbytes))
+    return dst
+
+
+def _ctx(ctx, x):
+    if ctx is not None:
+        return ctx
+    return x.ctx if isinstance(x, DeviceArray) else default_context()
+
+
+def norm1d(ctx, x):
+    """x / ||x||_2 (xcorr/signal/normalize.py:73-80)."""
+    ctx = _ctx(ctx, x)
+    buf, b, n, dev, _ = _prep(x)
+    check(_ffi.lib().xcx_norm1d(ctx.handle, ptr(buf), b, n, dev))
+    return buf
+
+
+def demean(ctx, x):
+    """x - mean(x) (xcorr/signal/detrend.py:110)."""
+    ctx = _ctx(ctx, x)
+    buf, b, n, dev, _ = _prep(x)
+    check(_ffi.lib().xcx_demean(ctx.handle, ptr(buf), b, n, dev))
+    return buf
+
+
+def detrend_linear(ctx, x):
+    """Remove the least-squares line (xcorr/signal/detrend.py:87-99)."""
+    ctx = _ctx(ctx, x)
+    buf, b, n, dev, _ = _prep(x)
+    check(_ffi.lib().xcx_detrend_linear(ctx.handle, ptr(buf), b, n, dev))
+    return buf
+
+
+def taper(ctx, x, nmax, wtype='hann'):
+    """Taper both flanks over nmax samples (xcorr/signal/window.py:92-106;
+    wtype 'cosine' = ObsPy Trace.taper flank)."""
+    ctx = _ctx(ctx, x)
+    buf, b, n, dev, _ = _prep(x)
+    wt = {'hann': 0, 'cosine': 1}[wtype]
+    check(_ffi.lib().xcx_taper(ctx.handle, ptr(buf), b, n, int(nmax), wt, dev))
+    return buf
+
+
+def unbias(ctx, x, npts, index_min=0, index_max=0):
+    """x * npts/(npts-|lag|) (xcorr/signal/unbias.py:73-85)."""
+    ctx = _ctx(ctx, x)
+    buf, b, n, dev, _ = _prep(x)
+    index_max = index_max or 2 * npts - 1
+    if n != index_max - index_min:
+        raise ValueError('last dimension does not match the lag slice')
+    check(_ffi.lib().xcx_unbias(ctx.handle, ptr(buf), b, int(npts),
+                                int(index_min), int(index_max), dev))
+    return buf
+
+
+def onebit(ctx, x):
+    ctx = _ctx(ctx, x)
+    buf, b, n, dev, _ = _prep(x)
+    check(_ffi.lib().xcx_onebit(ctx.handle, ptr(buf), b, n, dev))
+    return buf
+
+
+def _sos(sos):
+    sos = np.ascontiguousarray(sos, dtype=np.float64)
+    if sos.ndim != 2 or sos.shape[1] != 6:
+        raise ValueError('sos array must be shape (n_sections, 6)')
+    return sos
+
+
+def sosfiltfilt(ctx, x, sos):
+    """scipy.signal.sosfiltfilt(sos, x, axis=-1) (xcorr/signal/filter.py:95)."""
+    ctx = _ctx(ctx, x)
+    sos = _sos(sos)
+    buf, b, n, dev, _ = _prep(x)
+    check(_ffi.lib().xcx_sosfiltfilt(ctx.handle, ptr(buf), b, n, ptr(sos),
+                                     sos.shape[0], dev))
+    return buf
+
+
+def sosfilt(ctx, x, sos):
+    """scipy.signal.sosfilt(sos, x, axis=-1) from rest."""
+    ctx = _ctx(ctx, x)
+    sos = _sos(sos)
+    buf, b, n, dev, _ = _prep(x)
+    check(_ffi.lib().xcx_sosfilt(ctx.handle, ptr(buf), b, n, ptr(sos),
+                                 sos.shape[0], dev))
+    return buf
