@@ -1,0 +1,116 @@
+"""GPU: the host-side mirrors of the reference interface (util.cc.cc,
+signal.*, core.process) -- these read like the reference's own call sites."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_numpy as R          # noqa: E402
+import xcorr_amd.util.cc as ucc            # noqa: E402
+import xcorr_amd.signal as sig             # noqa: E402
+import xcorr_amd.core as core              # noqa: E402
+
+TOL = 1e-5
+
+
+def relerr(got, ref):
+    ref = np.asarray(ref, np.float64)
+    return float(np.abs(np.asarray(got, np.float64) - ref).max() / max(np.abs(ref).max(), 1e-300))
+
+
+def test_util_cc_signature_and_values(ctx, golden):
+    x, y = golden['x_1000'], golden['y_1000']
+    r = ucc.cc(x, y, normalize=True, pad=True, unbiased=False)
+    assert r.dtype == np.float32 and r.shape == (1999,)
+    assert relerr(r, golden['cc_1000_norm1']) < TOL
+    r64 = ucc.cc(x, y, normalize=False, pad=True, unbiased=False, dtype=np.float64)
+    assert r64.dtype == np.float64 and relerr(r64, golden['cc_1000_norm0']) < TOL
+    # pad=False: circular correlation with fftshift ordering (util/cc.py:72-78)
+    assert relerr(ucc.cc(x, y, normalize=False, pad=False, unbiased=False),
+                  R.cc(x, y, normalize=False, pad=False)) < TOL
+    xs = golden['kat_x'].astype(np.float32)
+    ys = golden['kat_y'].astype(np.float32)
+    np.testing.assert_allclose(ucc.cc(xs, ys, False, False, False), golden['kat_nopad'], atol=1e-5)
+    # unbiased=True (default): closed-form weights over all 2n-1 lags
+    ru = ucc.cc(x, y, normalize=True)
+    assert relerr(ru / R.weight_full(1000), golden['cc_1000_norm1']) < TOL
+    s, m = ucc.compute_shift_and_max(x, y, delta=0.02, unbiased=False)
+    sr, mr = ucc.extract_shift_and_max(golden['cc_1000_norm1'], 0.02)
+    assert s == sr and abs(m - mr) < TOL
+
+
+def test_signal_functions(ctx):
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((3, 4, 600)).astype(np.float32) + 2
+    b = rng.standard_normal((3, 4, 600)).astype(np.float32)
+    c = sig.correlate1d(a, b)
+    assert c.shape == (3, 4, 1199)
+    assert relerr(c, R.correlate1d(a, b, dtype=np.float64)) < TOL
+    assert relerr(sig.correlate1d(a, b, normalize=False), R.correlate1d(a, b, False, np.float64)) < TOL
+    with pytest.raises(ValueError, match='same shape'):
+        sig.correlate1d(a, b[:, :, :-1])
+    assert relerr(sig.norm1d(a), R.norm1d(a)) < TOL
+    assert relerr(sig.demean(a), R.demean(a)) < TOL
+    assert relerr(sig.detrend(a, type='linear'), R.detrend_linear(a)) < 2 * TOL
+    assert relerr(sig.taper(a, max_length=2., sampling_rate=50.), R.taper(a, 50., max_length=2.)) < TOL
+    assert relerr(sig.filter(a, 3., btype='highpass', order=2, sampling_rate=50.),
+                  R.sosfiltfilt(R.butter_sos(2, 3., 'highpass', 50.), a)) < TOL
+    assert relerr(sig.filter(a, (1., 5.), btype='bandpass', order=4, sampling_rate=50.),
+                  R.sosfiltfilt(R.butter_sos(4, (1., 5.), 'bandpass', 50.), a)) < TOL
+    cc = R.correlate1d(a, b)
+    assert relerr(sig.unbias(cc, npts=600), R.unbias(cc, 600)) < 1e-6
+
+
+def test_core_process_matches_reference_loop(ctx):
+    """init + process on an in-memory client == the reference's double loop
+    of util.cc.cc calls (core/process.py:82-165), incl. status bookkeeping."""
+    fs, wl = 50., 40.
+    n = int(wl * fs)
+    S, T = 3, 9000
+    tr = R.synthetic_traces(S, T)
+    names = ['A', 'B', 'C']
+    client = core.ArrayClient(dict(zip(names, tr)), fs, t0=0.)
+    pairs = ['A-B', 'A-C', 'B-C']
+    ds = core.init(pairs, 0., T / fs, fs, window_length=wl, window_overlap=.5, clip_lag=(-5., 5.))
+    imin, imax = ds.lag_attrs['index_min'], ds.lag_attrs['index_max']
+    core.process(ds, client)
+    nproc = 0
+    for ip, p in enumerate(pairs):
+        i, j = names.index(p[0]), names.index(p[2])
+        for it, t in enumerate(ds.time):
+            i0 = int(round((t - wl / 2) * fs))
+            if i0 < 0 or i0 + n > T:
+                assert ds.status[ip, it] == -1 and np.all(ds.cc[ip, it] == 0)
+                continue
+            assert ds.status[ip, it] == 1
+            ref = R.cc(tr[i, i0:i0 + n], tr[j, i0:i0 + n], normalize=True, dtype=np.float64)[imin:imax]
+            assert relerr(ds.cc[ip, it], ref) < TOL
+            assert ds.pair_offset[ip, it] == 0 and abs(ds.time_offset[ip, it]) < 1e-9
+            nproc += 1
+    assert nproc == 3 * 8
+    # resume: nothing left to do; retry_missing re-tries the -1 steps
+    before = ds.cc.copy()
+    core.process(ds, client)
+    np.testing.assert_array_equal(ds.cc, before)
+    core.process(ds, client, retry_missing=True)
+    assert (ds.status == -1).sum() == 3 * (len(ds.time) - 8)
+    # bias correction at the end (core/process.py:178-180)
+    ds2 = core.init(pairs, 0., T / fs, fs, wl, .5, unbiased_cc=True)
+    core.process(ds2, client)
+    ok = ds2.status[0] == 1
+    ref = R.cc(tr[0, 0:n], tr[1, 0:n], dtype=np.float64)
+    it = int(np.argmax(ok))
+    assert relerr(ds2.cc[0, it] / R.weight_full(n), ref) < TOL
+    assert ds2.cc_attrs['unbiased'] == 1
+
+
+def test_process_batched_equals_process(ctx):
+    fs, wl = 50., 60.
+    n = int(wl * fs)
+    tr = R.synthetic_traces(4, 5 * n // 2 + n)
+    out, lag = core.process_batched(tr, fs, wl, 0.5, clip_lag=(-10., 10.), demean=True)
+    assert out.shape == (6, 6, 1000) and lag.shape == (1000,)
+    imin = 179499 - (180000 - n)
+    ref = R.cc_pairs(tr, R.all_pairs(4), n, n // 2, demean_=True, dtype=np.float64,
+                     index_min=n - 1 - 500, index_max=n - 1 + 500)
+    assert relerr(out, ref) < TOL

@@ -1,0 +1,111 @@
+"""GPU: row-wise signal ops and SOS filters against the oracle
+(scipy/numpy restatements of xcorr/signal/*)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_numpy as R          # noqa: E402
+from xcorr_amd import ops                  # noqa: E402
+
+TOL = 1e-5
+
+
+def relerr(got, ref):
+    ref = np.asarray(ref, np.float64)
+    return float(np.abs(np.asarray(got, np.float64) - ref).max() / max(np.abs(ref).max(), 1e-300))
+
+
+@pytest.fixture(scope='module')
+def x():
+    rng = np.random.default_rng(1)
+    return (rng.standard_normal((7, 5001)) + 3.0 + 1e-3 * np.arange(5001)).astype(np.float32)
+
+
+def test_norm_demean_detrend(ctx, x):
+    assert relerr(ops.norm1d(ctx, x), R.norm1d(x)) < TOL
+    assert relerr(ops.demean(ctx, x), R.demean(x)) < TOL
+    assert relerr(ops.detrend_linear(ctx, x), R.detrend_linear(x)) < 2 * TOL
+    one = x[:1, :1]
+    assert ops.demean(ctx, one)[0, 0] == 0
+    assert np.all(np.isnan(ops.norm1d(ctx, np.zeros((2, 9), np.float32))))
+
+
+def test_taper_and_window_rules(ctx, x):
+    assert relerr(ops.taper(ctx, x, 250), R.taper(x, 50.0, max_length=5.0)) < 1e-6
+    assert relerr(ops.taper(ctx, x, 75), R.taper(x, 50.0, max_length=1.5)) < 1e-6
+    assert relerr(ops.taper(ctx, x, 500), R.taper(x, 50.0, max_percentage=0.1 - 1e-9)) < 1e-6
+    # half-length flanks (the reference default nmax = 0.5*len, odd length: overlap)
+    nm = int(round(0.5 * x.shape[-1]))
+    assert relerr(ops.taper(ctx, x, nm), x * R.window(x.shape[-1], 50.).astype(np.float32)) < 1e-6
+    cos = R.cosine_taper_obspy(5001, 50.0, 0.05)
+    assert relerr(ops.taper(ctx, x, 250, 'cosine'), x * cos.astype(np.float32)) < 1e-6
+    from xcorr_amd._ffi import XcxError
+    with pytest.raises(XcxError, match='nmax'):
+        ops.taper(ctx, x, 0)
+
+
+def test_unbias_and_onebit(ctx):
+    rng = np.random.default_rng(2)
+    n = 2501
+    c = rng.standard_normal((4, 2 * n - 1)).astype(np.float32)
+    assert relerr(ops.unbias(ctx, c, n), R.unbias(c, n)) < 1e-6
+    sl = c[:, 100:4000]
+    assert relerr(ops.unbias(ctx, sl, n, 100, 4000), R.unbias(sl, n, 100, 4000)) < 1e-6
+    with pytest.raises(ValueError):
+        ops.unbias(ctx, sl, n, 100, 3999)
+    v = np.array([[-2., 0., 3., -0., 1e-30]], np.float32)
+    np.testing.assert_array_equal(ops.onebit(ctx, v), [[-1, 0, 1, 0, 1]])
+
+
+FILTERS = [(2, 3.0, 'highpass'), (4, 1.5, 'highpass'), (4, (0.1, 10.0), 'bandpass'),
+           (4, 20.0, 'lowpass'), (8, (1.0, 5.0), 'bandpass'), (1, 2.0, 'lowpass')]
+
+
+@pytest.mark.parametrize('order,freq,btype', FILTERS)
+def test_sos_filters_rows(ctx, x, order, freq, btype):
+    sos = R.butter_sos(order, freq, btype, 50.0)
+    assert relerr(ops.sosfiltfilt(ctx, x, sos), R.sosfiltfilt(sos, x)) < TOL
+    assert relerr(ops.sosfilt(ctx, x, sos), R.sosfilt(sos, x)) < TOL
+
+
+def test_sos_long_rows_chunked_scan(ctx):
+    """Few long rows take the exact chunked-scan path (day-long traces)."""
+    rng = np.random.default_rng(3)
+    xl = (rng.standard_normal((3, 300001)) + 1.0).astype(np.float32)
+    for order, freq, btype in [(4, (0.1, 10.0), 'bandpass'), (2, 0.05, 'highpass')]:
+        sos = R.butter_sos(order, freq, btype, 50.0)
+        assert relerr(ops.sosfilt(ctx, xl, sos), R.sosfilt(sos, xl)) < TOL
+        assert relerr(ops.sosfiltfilt(ctx, xl, sos), R.sosfiltfilt(sos, xl)) < TOL
+
+
+def test_sos_many_short_rows_and_errors(ctx):
+    rng = np.random.default_rng(4)
+    xm = rng.standard_normal((300, 999)).astype(np.float32)
+    sos = R.butter_sos(2, 3.0, 'highpass', 50.0)
+    assert relerr(ops.sosfiltfilt(ctx, xm, sos), R.sosfiltfilt(sos, xm)) < TOL
+    from xcorr_amd._ffi import XcxError
+    with pytest.raises(XcxError, match='greater than padlen'):     # scipy's message
+        ops.sosfiltfilt(ctx, xm[:, :9], sos)
+    with pytest.raises(ValueError, match='sos array must be shape'):
+        ops.sosfilt(ctx, xm, np.zeros((2, 5)))
+
+
+def test_postprocess_chain_stages(ctx):
+    """core/postprocess.py:133-141 without the timeshift stage (not built):
+    unbias -> demean -> taper(5 s) -> highpass sosfiltfilt -> taper(1.5 s)."""
+    rng = np.random.default_rng(5)
+    n, fs = 3000, 50.
+    c = (rng.standard_normal((6, 2 * n - 1)) * 0.01).astype(np.float32)
+    y = ops.unbias(ctx, c, n)
+    y = ops.demean(ctx, y)
+    y = ops.taper(ctx, y, 250)
+    sos = R.butter_sos(2, 3., 'highpass', fs)
+    y = ops.sosfiltfilt(ctx, y, sos)
+    y = ops.taper(ctx, y, 75)
+    r = R.unbias(c, n)
+    r = R.demean(r)
+    r = R.taper(r, fs, max_length=5.)
+    r = R.sosfiltfilt(sos, r)
+    r = R.taper(r, fs, max_length=1.5)
+    assert relerr(y, r) < TOL

@@ -1,0 +1,270 @@
+"""GPU: the HIP cross-correlation path through the C ABI against (a) vectors
+frozen from the reference's own util/cc.py, (b) the oracle on seeded inputs,
+(c) size-independent properties at BASELINE.json's full size.
+
+Tolerance (north_star): 1e-5 relative float32, scaled by max|cc|."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_numpy as R          # noqa: E402  (checker only)
+import xcorr_amd as X                      # noqa: E402
+
+TOL = 1e-5
+
+
+def relerr(got, ref):
+    ref = np.asarray(ref, np.float64)
+    return float(np.abs(np.asarray(got, np.float64) - ref).max() / max(np.abs(ref).max(), 1e-300))
+
+
+def test_native_library_loaded():
+    from xcorr_amd import _ffi
+    assert _ffi.lib() is not None
+    import os
+    maps = open(f'/proc/{os.getpid()}/maps').read()
+    assert 'libxcx.so' in maps
+
+
+def test_reference_golden_vectors(ctx, golden):
+    """Outputs of the reference's cc() (float64 FFT path), all fixture sizes."""
+    for n in golden['sizes']:
+        n = int(n)
+        x, y = golden[f'x_{n}'], golden[f'y_{n}']
+        for nrm in (0, 1):
+            plan = X.CCPlan(ctx, n, normalize=bool(nrm))
+            got = plan.cc(x[None], y[None])[0]
+            plan.close()
+            assert got.shape == (2 * n - 1,) and got.dtype == np.float32
+            assert relerr(got, golden[f'cc_{n}_norm{nrm}']) < TOL, (n, nrm)
+
+
+def test_reference_kat(ctx, golden):
+    x = golden['kat_x'].astype(np.float32)
+    y = golden['kat_y'].astype(np.float32)
+    got = X.CCPlan(ctx, 4, normalize=False).cc(x[None], y[None])[0]
+    np.testing.assert_allclose(got, [0, .5, 2, 3.5, 5, 4, 0], atol=5e-6)
+    got = X.CCPlan(ctx, 4, normalize=True).cc(x[None], y[None])[0]
+    np.testing.assert_allclose(got, golden['kat_norm'], atol=1e-6)
+
+
+def test_reference_full_size_digest(ctx, golden):
+    """n = 180000 (1 h @ 50 Hz): digest of the reference run."""
+    n = int(golden['big_n'])
+    rng = np.random.default_rng(12345)
+    a = rng.standard_normal(n).astype(np.float32)
+    b = (np.roll(a, 250) + 0.5 * rng.standard_normal(n).astype(np.float32)).astype(np.float32)
+    plan = X.CCPlan(ctx, n)
+    assert plan.N == 368640
+    r = plan.cc(a[None], b[None])[0]
+    mx = float(golden['big_max'])
+    assert r.shape == (359999,)
+    assert int(np.argmax(r)) == int(golden['big_argmax'])
+    assert abs(float(r.max()) - mx) < TOL * mx
+    assert np.abs(r[golden['big_probe_idx']] - golden['big_probe_val']).max() < TOL * mx
+    assert abs(float(np.sqrt((r.astype(np.float64) ** 2).sum())) - float(golden['big_l2'])) < 1e-4
+    # full vector against the oracle
+    assert relerr(r, R.cc_fair(a, b, dtype=np.float64)) < TOL
+
+
+@pytest.mark.parametrize('n', [1, 2, 3, 7, 64, 255, 256, 257, 1000, 4097, 20000, 65536, 131072, 200000, 262144])
+def test_sizes_and_planner(ctx, n):
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((2, n)).astype(np.float32)
+    y = (0.5 * np.roll(x, max(1, n // 5), axis=-1) + rng.standard_normal((2, n))).astype(np.float32)
+    for nrm in (True, False):
+        plan = X.CCPlan(ctx, n, normalize=nrm)
+        assert plan.N >= 2 * n - 1 and plan.N == plan.N1 * plan.N2
+        got = plan.cc(x, y)
+        plan.close()
+        assert relerr(got, R.cc_fair(x, y, normalize=nrm, dtype=np.float64)) < TOL
+
+
+def test_unsupported_and_invalid_arguments(ctx):
+    from xcorr_amd._ffi import XcxError
+    with pytest.raises(XcxError, match='no supported transform length'):
+        X.CCPlan(ctx, 300000)
+    with pytest.raises(XcxError, match='lag slice'):
+        X.CCPlan(ctx, 100, index_min=150, index_max=100)
+    with pytest.raises(XcxError, match='n must be'):
+        X.CCPlan(ctx, 0)
+    plan = X.CCPlan(ctx, 100)
+    with pytest.raises(XcxError, match='outside'):
+        plan.pairs(np.zeros((2, 100), np.float32), [(0, 2)], 1, 100)
+    with pytest.raises(ValueError):
+        plan.cc(np.zeros((1, 100), np.float32), np.zeros((1, 99), np.float32))
+    with pytest.raises(XcxError, match='xcx_plan_set_whiten'):
+        p = X.CCPlan.__new__(X.CCPlan)
+        X.CCPlan.__init__(p, ctx, 100, whiten=None)
+        import ctypes as C
+        from xcorr_amd import _ffi
+        h = C.c_void_p()
+        _ffi.check(_ffi.lib().xcx_plan_cc1d(ctx.handle, 100, 0, 0, 0, _ffi.NORMALIZE | _ffi.WHITEN, C.byref(h)))
+        x = np.zeros((1, 100), np.float32)
+        o = np.zeros((1, 199), np.float32)
+        _ffi.check(_ffi.lib().xcx_cc1d(h, _ffi.ptr(x), _ffi.ptr(x), 1, _ffi.ptr(o), 0))
+
+
+def test_zero_and_constant_inputs(ctx):
+    n = 500
+    z = np.zeros((1, n), np.float32)
+    o = np.ones((1, n), np.float32)
+    plan = X.CCPlan(ctx, n, normalize=True)
+    r = plan.cc(z, o)[0]
+    assert np.all(np.isnan(r))                     # 0/0 like the reference
+    r = X.CCPlan(ctx, n, normalize=False).cc(z, o)[0]
+    assert np.all(r == 0)
+    r = plan.cc(o, o)[0]                           # triangle, peak 1 at zero lag
+    ref = (n - np.abs(np.arange(-(n - 1), n))) / n
+    np.testing.assert_allclose(r, ref, atol=TOL)
+
+
+CASES = [
+    dict(),
+    dict(demean=True),
+    dict(onebit=True, demean=True),
+    dict(index_min=1000, index_max=4500),
+    dict(index_min=2999, index_max=3000),
+    dict(normalize=False),
+    dict(whiten=(50., 1., 10., .5)),
+    dict(whiten=(50., 1., 10., .5), onebit=True, demean=True),
+]
+
+
+@pytest.mark.parametrize('kw', CASES, ids=[str(sorted(c)) for c in CASES])
+def test_pairs_engine(ctx, kw):
+    S, n, hop, W = 5, 3000, 1500, 4
+    T = hop * (W - 1) + n
+    tr = R.synthetic_traces(S, T)
+    pairs = R.all_pairs(S)
+    plan = X.CCPlan(ctx, n, **kw)
+    got = plan.pairs(tr, pairs, W, hop)
+    wh = kw.get('whiten')
+    g = R.whiten_weights(plan.N, *wh) if wh else None
+    ref = R.cc_pairs(tr, pairs, n, hop, normalize=kw.get('normalize', True), dtype=np.float64,
+                     demean_=kw.get('demean', False), onebit_=kw.get('onebit', False),
+                     index_min=kw.get('index_min', 0), index_max=kw.get('index_max'),
+                     whiten=g, nfft=plan.N)
+    assert got.shape == ref.shape
+    assert relerr(got, ref) < TOL
+    plan.close()
+
+
+def test_pairs_unbiased_and_order(ctx):
+    S, n, hop, W = 4, 2000, 1000, 3
+    tr = R.synthetic_traces(S, hop * (W - 1) + n)
+    pairs = np.array([(3, 0), (1, 1), (0, 2), (2, 1)], np.int32)   # arbitrary order, auto-pair, i>j
+    ref = R.cc_pairs(tr, pairs, n, hop, dtype=np.float64)
+    got = X.CCPlan(ctx, n).pairs(tr, pairs, W, hop)
+    assert relerr(got, ref) < TOL
+    # unbiased: errors scale with the weight n/(n-|lag|) (up to n at the ends),
+    # so compare after dividing the weight out again
+    gotu = X.CCPlan(ctx, n, unbiased=True).pairs(tr, pairs, W, hop)
+    assert relerr(gotu / R.weight_full(n), ref) < TOL
+    assert relerr(gotu[..., n - 1], ref[..., n - 1]) < TOL        # weight 1 at zero lag
+
+
+def test_stack_equals_sum_of_windows(ctx):
+    S, n, hop, W = 4, 3000, 1500, 5
+    tr = R.synthetic_traces(S, hop * (W - 1) + n)
+    pairs = R.all_pairs(S)
+    per = X.CCPlan(ctx, n).pairs(tr, pairs, W, hop)
+    st = X.CCPlan(ctx, n, stack=True).pairs(tr, pairs, W, hop)
+    assert st.shape == (len(pairs), 2 * n - 1)
+    assert relerr(st, per.astype(np.float64).sum(axis=1)) < TOL
+    assert relerr(st, R.cc_pairs(tr, pairs, n, hop, dtype=np.float64).sum(axis=1)) < TOL
+
+
+def test_device_resident_padded_rows_and_batches(ctx):
+    """Device pointers in/out, padded output pitch, batch sizes that do not
+    divide the pair count (ragged last batch)."""
+    S, n, hop, W = 6, 2500, 1250, 3
+    T = hop * (W - 1) + n
+    tr = R.synthetic_traces(S, T)
+    pairs = R.all_pairs(S)                      # 15 pairs
+    ref = R.cc_pairs(tr, pairs, n, hop, dtype=np.float64)
+    L = 2 * n - 1
+    ld = (L + 31) // 32 * 32
+    dtr = ctx.array(tr)
+    for batch in (1, 4, 7, 64):
+        plan = X.CCPlan(ctx, n, batch=batch)
+        out = ctx.empty((len(pairs) * W, ld)).zero()
+        plan.pairs(dtr, pairs, W, hop, out=out, ld_out=ld)
+        got = out.rows_to_host(0, len(pairs) * W, L).reshape(len(pairs), W, L)
+        assert relerr(got, ref) < TOL, batch
+        pad = out.to_host()[:, L:]
+        assert np.all(pad == 0)                 # padding is never written
+        launches, pw = plan.counters()
+        assert pw == len(pairs) * W
+        plan.close()
+
+
+def test_properties_full_size(ctx):
+    """BASELINE size (n = 180000, N = 368640): symmetry, autocorrelation peak,
+    shift theorem, linearity -- no oracle needed."""
+    n = 180000
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal(n).astype(np.float32)
+    y = rng.standard_normal(n).astype(np.float32)
+    raw = X.CCPlan(ctx, n, normalize=False)
+    nrm = X.CCPlan(ctx, n, normalize=True)
+    rxy = raw.cc(x[None], y[None])[0].astype(np.float64)
+    ryx = raw.cc(y[None], x[None])[0].astype(np.float64)
+    scale = np.abs(rxy).max()
+    assert np.abs(rxy - ryx[::-1]).max() < TOL * scale          # R_xy[k] = R_yx[-k]
+    rxx = nrm.cc(x[None], x[None])[0]
+    assert int(np.argmax(rxx)) == n - 1 and abs(float(rxx[n - 1]) - 1.0) < TOL
+    assert np.abs(rxx - rxx[::-1]).max() < TOL
+    # linearity in the first argument
+    z = rng.standard_normal(n).astype(np.float32)
+    rzy = raw.cc(z[None], y[None])[0].astype(np.float64)
+    rsum = raw.cc((x + z)[None], y[None])[0].astype(np.float64)
+    assert np.abs(rsum - (rxy + rzy)).max() < 2 * TOL * np.abs(rsum).max()
+    # shift: delaying x by d samples moves the peak of cc(x_d, x) to lag +d
+    d = 250
+    xd = np.concatenate([np.zeros(d, np.float32), x[:-d]])
+    r = nrm.cc(xd[None], x[None])[0]
+    assert int(np.argmax(r)) == n - 1 + d
+    # zero-lag value equals the plain dot product
+    dot = float(np.dot(x.astype(np.float64), y.astype(np.float64)))
+    assert abs(rxy[n - 1] - dot) < TOL * scale
+
+
+def test_baseline_config_checksum(ctx):
+    """configs[1] geometry on a reduced record: 16 stations, n = 180000,
+    50 % overlap, 3 windows; every pair-window's zero-lag sample and energy
+    against direct dot products (size-independent check of all 360 CCFs)."""
+    S, n, hop, W = 16, 180000, 90000, 3
+    T = hop * (W - 1) + n
+    tr = R.synthetic_traces(S, T)
+    pairs = R.all_pairs(S)
+    L = 2 * n - 1
+    ld = 360000
+    plan = X.CCPlan(ctx, n)
+    dtr = ctx.array(tr)
+    out = ctx.empty((len(pairs) * W, ld))
+    plan.pairs(dtr, pairs, W, hop, out=out, ld_out=ld)
+    got = out.rows_to_host(0, len(pairs) * W, L).reshape(len(pairs), W, L)
+    t64 = tr.astype(np.float64)
+    for w in range(W):
+        seg = t64[:, w * hop:w * hop + n]
+        nrm = np.linalg.norm(seg, axis=1)
+        gram = (seg @ seg.T) / np.outer(nrm, nrm)
+        zero_lag = np.array([gram[i, j] for i, j in pairs])
+        assert np.abs(got[:, w, n - 1] - zero_lag).max() < TOL
+    # common signal with 25-sample moveout per station: peak at lag 25*(i-j)
+    # (raw traces carry a DC offset, so use the demeaned plan for the peak)
+    plan_d = X.CCPlan(ctx, n, demean=True)
+    plan_d.pairs(dtr, pairs, W, hop, out=out, ld_out=ld)
+    got = out.rows_to_host(0, len(pairs) * W, L).reshape(len(pairs), W, L)
+    for p in (0, 17, 60, 119):
+        i, j = pairs[p]
+        assert int(np.argmax(got[p, 1])) == n - 1 + 25 * (i - j)
+    # three full rows against the oracle
+    for p, w in ((0, 0), (59, 1), (119, 2)):
+        i, j = pairs[p]
+        a = t64[i, w * hop:w * hop + n]
+        b = t64[j, w * hop:w * hop + n]
+        ref = R.cc_fair(a - a.mean(), b - b.mean(), dtype=np.float64)
+        assert relerr(got[p, w], ref) < TOL

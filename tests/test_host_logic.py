@@ -1,0 +1,94 @@
+"""CPU: host-side mirrors of the reference interface (no GPU work)."""
+import numpy as np
+import pytest
+
+from oracle import ref_numpy as R
+import xcorr_amd.util.cc as ucc
+import xcorr_amd.core as core
+from xcorr_amd import shard
+import xcorr_amd.signal as sig
+
+
+def test_lag_weight_match_reference(golden):
+    for n in golden['sizes']:
+        n = int(n)
+        np.testing.assert_allclose(ucc.lag(n, 0.02), golden[f'lag_{n}'], atol=1e-12)
+        if n >= 3:
+            # reference weight() is defined on the first 2n-3 lags only
+            np.testing.assert_allclose(ucc.weight(n)[:2 * n - 3], golden[f'weight_{n}'], rtol=1e-15)
+            np.testing.assert_allclose(ucc.weight(n, clip=3.0)[:2 * n - 3],
+                                       golden[f'weight_{n}_clip'], rtol=1e-15)
+    np.testing.assert_allclose(ucc.lag(4, .02, pad=False), golden['kat_lag_nopad'])
+
+
+def test_extract_shift(golden):
+    r = np.zeros(11)
+    r[2] = 1.0
+    assert ucc.extract_shift(r) == -3
+    assert ucc.extract_shift(r, 0.5) == -1.5
+    assert ucc.extract_shift_and_max(r) == (-3, 1.0)
+
+
+def test_cc_argument_errors_match_reference():
+    with pytest.raises(AssertionError, match='same length'):
+        ucc.cc(np.zeros(4, np.float32), np.zeros(5, np.float32))
+    with pytest.raises(AssertionError, match='same dtype'):
+        ucc.cc(np.zeros(4, np.float32), np.zeros(4, np.float64))
+
+
+def test_init_layout_matches_reference_rules():
+    ds = core.init('A-B', 0., 86400., 50., window_length=3600., window_overlap=.5)
+    assert ds.cc.shape == (1, 48, 359999) and ds.cc.dtype == np.float32
+    assert ds.lag_attrs['npts'] == 180000
+    assert (ds.lag_attrs['index_min'], ds.lag_attrs['index_max']) == (0, 359999)
+    np.testing.assert_allclose(ds.time[:3], [0., 1800., 3600.])
+    assert np.all(ds.status == 0)
+    ds = core.init('A-B', 0., 7200., 50., 3600., .5, clip_lag=(-10., 10.))
+    assert (ds.lag_attrs['index_min'], ds.lag_attrs['index_max']) == R.clip_lag_indices(180000, .02, (-10., 10.))
+    assert ds.lag.shape == (1000,) and ds.lag[0] == -10.0
+    # update_lag_indices (util/time.py:104-108) is consistent with the slice
+    assert R.lag_indices(180000, .02, ds.lag[0], ds.lag[-1]) == (179499, 180499)
+    ds = core.init('A-B', 0., 7200., 50., 3600., .5, clip_lag=5.)
+    assert ds.lag[0] == -5.0
+    with pytest.raises(TypeError):
+        core.init('A-B', 0., 7200., 50., 3600., .5, clip_lag=[1, 2])
+
+
+def test_array_client_windows():
+    fs = 50.
+    tr = {'A': np.arange(1000, dtype=np.float32), 'B': np.arange(1000, dtype=np.float32) * 2}
+    cl = core.ArrayClient(tr, fs, t0=100.)
+    w = cl.get_pair_processed_waveforms('A-B', time=105., duration=4.)
+    (xa, ta), (xb, tb) = w
+    assert len(xa) == 200 and xa[0] == 150 and ta == 103. and xb[0] == 300
+    assert cl.get_pair_processed_waveforms('A-B', time=100., duration=4.) is None
+    assert cl.get_pair_processed_waveforms('A-C', time=105., duration=4.) is None
+
+
+def test_shard_helpers():
+    pairs = shard.all_pairs(64)
+    assert pairs.shape == (2016, 2) and tuple(pairs[0]) == (0, 1) and tuple(pairs[-1]) == (62, 63)
+    seen = np.zeros(2016, int)
+    sizes = []
+    for r in range(8):
+        p, idx = shard.shard_pairs(pairs, r, 8)
+        seen[idx] += 1
+        sizes.append(len(p))
+        np.testing.assert_array_equal(p, pairs[idx])
+    assert np.all(seen == 1) and max(sizes) - min(sizes) <= 1
+    days = [shard.shard_days(30, r, 8) for r in range(8)]
+    assert [len(d) for d in days] == [4, 4, 4, 4, 4, 4, 3, 3]
+    assert sum(days, []) == list(range(30))
+    assert len(shard.window_starts(4320000, 180000, 90000)) == 47
+
+
+def test_signal_host_helpers():
+    np.testing.assert_allclose(sig.window(1000, 50., max_length=5.), R.window(1000, 50., max_length=5.))
+    np.testing.assert_allclose(sig.window(999, 50., max_percentage=.1), R.window(999, 50., max_percentage=.1))
+    np.testing.assert_allclose(sig.unbias_weights(100, 10, 150), R.weight_full(100)[10:150])
+    with pytest.raises(TypeError):
+        sig.window(100, 50., max_length=5)
+    with pytest.raises(ValueError):
+        sig.filter(np.zeros((2, 100), np.float32), 3, sampling_rate=50.)
+    with pytest.raises(KeyError):
+        sig.detrend(np.zeros((2, 10), np.float32), type='cubic')

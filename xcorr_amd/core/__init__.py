@@ -1,0 +1,6 @@
+"""xcorr_amd.core -- the pair x window driver of xcorr/core (init, process)."""
+from .init import init, CCDataset  # noqa: F401
+from .process import process, process_batched  # noqa: F401
+from .client import ArrayClient  # noqa: F401
+
+__all__ = ['init', 'process', 'process_batched', 'CCDataset', 'ArrayClient']

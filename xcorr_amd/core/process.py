@@ -1,0 +1,101 @@
+"""
+Pair x window driver (xcorr/core/process.py:23-185).
+
+``process`` keeps the reference's control flow -- skip processed steps,
+``retry_missing``, status -1 on missing data, pair/time offsets, the lag slice
+``[index_min:index_max]``, optional bias correction at the end -- but instead
+of one ``util.cc.cc`` call per (pair, time) it collects every available window
+first and hands the whole batch to the GPU engine in one call
+(``CCPlan.cc``): the hot loop of core/process.py:82-165 becomes one batched
+launch sequence.
+"""
+import numpy as np
+
+from ..engine import CCPlan, default_context
+
+__all__ = ['process', 'process_batched']
+
+
+def process(dataset, client, inventory=None, retry_missing=False,
+            test_run=False, hash_waveforms=False, metadata_hash=None, verb=0,
+            ctx=None, **kwargs):
+    """Process the container in place and return it.
+
+    dataset : :class:`xcorr_amd.core.CCDataset` (see ``init``)
+    client  : object with ``get_pair_processed_waveforms(pair, time, duration,
+        ...)`` returning two (data, starttime_seconds) items or None
+        (stream/client.py:1116-1149; :class:`ArrayClient` here).
+    Waveform hashing (core/process.py:146-149) is storage-integrity plumbing
+    and not part of this build (`hash_waveforms` is accepted and ignored).
+    """
+    la = dataset.lag_attrs
+    npts, imin, imax = la['npts'], la['index_min'], la['index_max']
+    wl = dataset.time_attrs['window_length']
+    todo, xs, ys = [], [], []
+    for ip, p in enumerate(dataset.pair):
+        for it, t in enumerate(dataset.time):
+            st = dataset.status[ip, it]
+            if st != 0 and not (retry_missing and st == -1):
+                continue                      # core/process.py:93-104
+            w = client.get_pair_processed_waveforms(
+                pair=p, time=t, duration=wl,
+                sampling_rate=la['sampling_rate'], **kwargs)
+            if w is None or len(w) != 2:
+                dataset.status[ip, it] = -1   # core/process.py:122-132
+                if test_run:
+                    break
+                continue
+            (xa, ta), (xb, tb) = w
+            dataset.pair_offset[ip, it] = ta - tb            # :135-138
+            dataset.time_offset[ip, it] = ta + wl / 2 - t    # :139-143
+            xs.append(np.asarray(xa[:npts], dtype=np.float32))
+            ys.append(np.asarray(xb[:npts], dtype=np.float32))
+            todo.append((ip, it))
+            if test_run:
+                break
+        if test_run and todo:
+            break
+    if todo:
+        ctx = ctx or default_context()
+        plan = CCPlan(ctx, npts, index_min=imin, index_max=imax,
+                      normalize=dataset.cc_attrs['normalize'] == 1,
+                      unbiased=False)
+        out = plan.cc(np.stack(xs), np.stack(ys))            # :155-162
+        plan.close()
+        for k, (ip, it) in enumerate(todo):
+            dataset.cc[ip, it] = out[k].astype(dataset.cc.dtype)
+            dataset.status[ip, it] = 1                       # :165
+    if dataset.cc_attrs['bias_correct'] == 1 and dataset.cc_attrs['unbiased'] == 0:
+        from .. import ops
+        flat = dataset.cc.reshape(-1, dataset.cc.shape[-1])
+        dataset.cc[...] = ops.unbias(ctx or default_context(), flat, npts,
+                                     imin, imax).reshape(dataset.cc.shape)
+        dataset.cc_attrs['unbiased'] = np.byte(1)            # :178-180
+    return dataset
+
+
+def process_batched(traces, sampling_rate, window_length, window_overlap=0.5,
+                    pairs=None, clip_lag=None, normalize=True, onebit=False,
+                    whiten=None, demean=False, stack=False, ctx=None):
+    """Device-resident fast path for regularly sampled, gap-free records:
+    traces [S, T] (numpy) -> cc [P, W, L] (or [P, L] with stack=True).
+    Windows start at k*hop (all whole windows inside the record); equivalent
+    to ``init`` + ``process`` on an :class:`ArrayClient` over the same
+    windows, without the per-window host copies."""
+    from .init import init
+    traces = np.ascontiguousarray(traces, dtype=np.float32)
+    S, T = traces.shape
+    n = int(window_length * sampling_rate)
+    hop = int(round(n * (1 - window_overlap)))
+    W = (T - n) // hop + 1
+    if pairs is None:
+        pairs = [(i, j) for i in range(S) for j in range(i + 1, S)]
+    lay = init('x', 0., 1., sampling_rate, window_length, window_overlap,
+               clip_lag=clip_lag)
+    imin, imax = lay.lag_attrs['index_min'], lay.lag_attrs['index_max']
+    ctx = ctx or default_context()
+    plan = CCPlan(ctx, n, index_min=imin, index_max=imax, normalize=normalize,
+                  onebit=onebit, whiten=whiten, demean=demean, stack=stack)
+    out = plan.pairs(traces, np.asarray(pairs, np.int32), W, hop)
+    plan.close()
+    return out, lay.lag

@@ -1,0 +1,22 @@
+"""
+xcorr_amd.signal -- the starred functions of ``xcorr/signal`` on the GPU.
+
+Every function takes either a float32 numpy array with the core dimension
+last (what the reference's ``xr.apply_ufunc`` closures receive) plus the
+metadata the reference reads from coordinate attrs (``sampling_rate``,
+``npts``, ``index_min`` ...) as keyword arguments, or -- when xarray is
+importable -- an ``xarray.DataArray`` carrying that metadata, in which case
+the reference's signature ``f(x, ..., dim=None)`` applies and a DataArray is
+returned.  (xarray is not installed in the build container: the DataArray
+branch is exercised only where xarray exists.)
+"""
+from .ops1d import (correlate1d, norm1d, norm, demean, detrend, window, taper,
+                    filter, unbias, unbias_weights)  # noqa: F401
+
+__all__ = ['correlate1d', 'norm1d', 'norm', 'demean', 'detrend', 'window',
+           'taper', 'filter', 'unbias', 'unbias_weights']
+
+try:                                    # B4 seam: DataArray.signal accessor
+    from . import accessor  # noqa: F401
+except ModuleNotFoundError:             # xarray absent
+    accessor = None

@@ -1,0 +1,43 @@
+"""``DataArray.signal`` accessor for the GPU-backed functions (B4 seam,
+xcorr/signal/accessor.py:52-327).  Imported only when xarray is available."""
+from functools import wraps
+
+import xarray as xr
+
+from . import ops1d as _f
+
+
+@xr.register_dataarray_accessor('signal')
+class SignalAccessor():
+    def __init__(self, dataarray: xr.DataArray):
+        self._da = dataarray
+
+    @wraps(_f.correlate1d)
+    def correlate1d(self, in2, **kwargs):
+        return _f.correlate1d(self._da, in2, **kwargs)
+
+    @wraps(_f.norm1d)
+    def norm1d(self, **kwargs):
+        return _f.norm1d(self._da, **kwargs)
+
+    norm = norm1d
+
+    @wraps(_f.detrend)
+    def detrend(self, **kwargs):
+        return _f.detrend(self._da, **kwargs)
+
+    @wraps(_f.demean)
+    def demean(self, **kwargs):
+        return _f.demean(self._da, **kwargs)
+
+    @wraps(_f.taper)
+    def taper(self, **kwargs):
+        return _f.taper(self._da, **kwargs)
+
+    @wraps(_f.filter)
+    def filter(self, *args, **kwargs):
+        return _f.filter(self._da, *args, **kwargs)
+
+    @wraps(_f.unbias)
+    def unbias(self, **kwargs):
+        return _f.unbias(self._da, **kwargs)

@@ -1,0 +1,242 @@
+"""numpy-level + DataArray-level implementations (see package docstring)."""
+import numpy as np
+
+from .. import ops as _ops
+from ..engine import CCPlan, default_context
+
+try:
+    import xarray as xr
+except ModuleNotFoundError:
+    xr = None
+
+_types = ('constant', 'linear')
+_plans = {}
+
+
+def _is_da(x):
+    return xr is not None and isinstance(x, xr.DataArray)
+
+
+def _check_dim(x, dim):
+    dim = dim or x.dims[-1]
+    if not isinstance(dim, str):
+        raise TypeError('dim should be a string')
+    if dim not in x.dims:
+        raise ValueError(f'x has no dimensions "{dim}"')
+    return dim
+
+
+def _apply_da(x, dim, fn):
+    """Move `dim` last, run fn on the float32 values, rebuild the DataArray."""
+    xt = x.transpose(..., dim)
+    vals = np.ascontiguousarray(xt.values, dtype=np.float32)
+    out = fn(vals).astype(x.dtype)
+    y = xt.copy(data=out).transpose(*x.dims)
+    y.attrs = x.attrs
+    y.name = x.name
+    return y
+
+
+def _cc_plan(n, normalize):
+    key = (n, bool(normalize))
+    if key not in _plans:
+        if len(_plans) > 16:
+            _plans.pop(next(iter(_plans))).close()
+        _plans[key] = CCPlan(default_context(), n, normalize=normalize)
+    return _plans[key]
+
+
+# -- a4: signal/correlate.py:32-159 -----------------------------------------
+def correlate1d(in1, in2, normalize=True, dtype=None, dim=None, **kwargs):
+    """One-dimensional cross-correlation along the last axis (or `dim`).
+    Output length 2N-1, lags -(N-1)..(N-1) (signal/correlate.py:97-113)."""
+    if _is_da(in1):
+        dim = _check_dim(in1, dim)
+        if dim not in in2.dims:
+            raise ValueError(f'in2 has no dimensions "{dim}"')
+        if in1.shape != in2.shape:
+            raise ValueError('in1 and in2 should have the same shape!')
+        dtype = dtype or in1.dtype
+        if not isinstance(dtype, np.dtype):
+            raise TypeError('dtype should be a numpy.dtype')
+        a = in1.transpose(..., dim)
+        b = in2.transpose(..., dim)
+        out = correlate1d(a.values, b.values, normalize=normalize,
+                          dtype=dtype)
+        coord = in1[dim]
+        N = coord.size
+        delta = float((coord[1] - coord[0]).item()) if N > 1 else 1.0
+        new_dim = f'delta_{dim}'
+        cc = xr.DataArray(
+            out, dims=a.dims[:-1] + (new_dim,),
+            coords={**{d: a[d] for d in a.dims[:-1] if d in a.coords},
+                    new_dim: np.arange(-(N - 1), N) * delta},
+            name='cc')
+        cc.attrs = {
+            'long_name': 'Cross-correlation Estimate',
+            'standard_name': 'cross_correlation_estimate',
+            'units': '-',
+            'normalize': np.byte(normalize),
+            'bias_correct': np.byte(0),
+            'unbiased': np.byte(0),
+        }
+        return cc
+    in1 = np.asarray(in1)
+    in2 = np.asarray(in2)
+    if in1.shape != in2.shape:
+        raise ValueError('in1 and in2 should have the same shape!')
+    dtype = np.dtype(dtype or in1.dtype)
+    n = in1.shape[-1]
+    lead = in1.shape[:-1]
+    plan = _cc_plan(n, normalize)
+    out = plan.cc(np.ascontiguousarray(in1, np.float32).reshape(-1, n),
+                  np.ascontiguousarray(in2, np.float32).reshape(-1, n))
+    return out.reshape(lead + (2 * n - 1,)).astype(dtype)
+
+
+# -- a5: signal/normalize.py:33-92 -------------------------------------------
+def norm1d(x, dim=None, **kwargs):
+    """x / ||x||_2 along the last axis (signal/normalize.py:73-80)."""
+    if _is_da(x):
+        dim = _check_dim(x, dim)
+        return _apply_da(x, dim, lambda v: _ops.norm1d(None, v))
+    return _ops.norm1d(None, x)
+
+
+norm = norm1d
+
+
+# -- a7: signal/detrend.py:31-145 ----------------------------------------------
+def detrend(x, dim=None, type=None, skipna=True):
+    """Remove the mean ('constant') or the least-squares line ('linear')
+    (signal/detrend.py:87-110).  NaN handling (`skipna`) is not supported on
+    the GPU path: rows must be finite."""
+    type = type or _types[0]
+    if not isinstance(type, str):
+        raise TypeError('type should be a string')
+    if type not in _types:
+        raise KeyError(f'type should be any of "{"|".join(_types)}"')
+    fn = _ops.detrend_linear if type == 'linear' else _ops.demean
+    if _is_da(x):
+        dim = _check_dim(x, dim)
+        return _apply_da(x, dim, lambda v: fn(None, v))
+    return fn(None, x)
+
+
+def demean(x, dim=None, **kwargs):
+    """signal/detrend.py:127-145."""
+    return detrend(x, dim=dim, type='constant', **kwargs)
+
+
+# -- a8: signal/window.py:27-116, signal/taper.py:23-85 -------------------------
+def _nmax(npts, sampling_rate, max_percentage, max_length, xmax=None):
+    nmax = 0.5 * npts
+    if max_percentage:
+        if not isinstance(max_percentage, float):
+            raise TypeError('max_percentage should be of type `float`.')
+        if max_percentage < 0. or max_percentage > .5:
+            raise ValueError('max_percentage should be within [0, .5].')
+        nmax = max_percentage * npts
+    if max_length:
+        if not isinstance(max_length, float):
+            raise TypeError('max_length should be of type `float`.')
+        if max_length < 0. or (xmax is not None and max_length > xmax):
+            raise ValueError('max_length should be within [0, x].')
+        nmax = max_length * sampling_rate
+    return int(round(nmax))
+
+
+def window(npts, sampling_rate, wtype='hann', max_percentage=None,
+           max_length=None, side=None):
+    """Taper window of `npts` samples (signal/window.py:74-106): ones with the
+    first/last ``nmax`` samples of a periodic Hann window of length 2*nmax.
+    Host-side coordinate helper (float64), like the reference."""
+    wtype = wtype or 'hann'
+    if wtype != 'hann':
+        raise ValueError('only wtype="hann" is built on the GPU path')
+    side = side or 'both'
+    if side not in ('left', 'right', 'both'):
+        raise ValueError('side should be either "left", "right" or "both"!')
+    nmax = _nmax(npts, sampling_rate, max_percentage, max_length)
+    i = np.arange(nmax, dtype=np.float64)
+    w = np.ones(npts, dtype=np.float64)
+    w[0:nmax] = 0.5 * (1.0 - np.cos(np.pi * i / nmax))
+    w[npts - nmax:] = 0.5 * (1.0 + np.cos(np.pi * i / nmax))
+    return w
+
+
+def taper(x, wtype=None, max_percentage=None, max_length=None, side=None,
+          dim=None, sampling_rate=None):
+    """x * window (signal/taper.py:67-69)."""
+    wtype = wtype or 'hann'
+    if wtype != 'hann':
+        raise ValueError('only wtype="hann" is built on the GPU path')
+    if _is_da(x):
+        dim = _check_dim(x, dim)
+        if 'sampling_rate' not in x[dim].attrs:
+            raise ValueError('x has no attribute "sampling_rate"!')
+        fs = x[dim].attrs['sampling_rate']
+        nmax = _nmax(x[dim].size, fs, max_percentage, max_length,
+                     float(np.max(x[dim].values)))
+        return _apply_da(x, dim, lambda v: _ops.taper(None, v, nmax))
+    if sampling_rate is None:
+        raise ValueError('x has no attribute "sampling_rate"!')
+    x = np.asarray(x)
+    nmax = _nmax(x.shape[-1], sampling_rate, max_percentage, max_length)
+    return _ops.taper(None, x, nmax)
+
+
+# -- a9: signal/filter.py:27-120 -------------------------------------------------
+def filter(x, frequency, btype=None, order=2, dim=None, sampling_rate=None):
+    """Zero-phase Butterworth: ``butter(order, frequency, btype, 'sos', fs)``
+    designed on the host (scipy, microseconds), ``sosfiltfilt`` on the GPU
+    (signal/filter.py:86-96)."""
+    import scipy.signal
+    if not (isinstance(frequency, float) or
+            (isinstance(frequency, tuple) and len(frequency) == 2)):
+        raise ValueError('Corner frequency should be a `float` or tuple-pair '
+                         'with (min, max)!')
+    btype = btype or 'highpass'
+    if _is_da(x):
+        dim = _check_dim(x, dim)
+        if 'sampling_rate' not in x[dim].attrs:
+            raise ValueError(f'Dimension "{dim}" has no attribute '
+                             '"sampling_rate"!')
+        sampling_rate = x[dim].attrs['sampling_rate']
+    elif sampling_rate is None:
+        raise ValueError('sampling_rate is required for array input')
+    sos = scipy.signal.butter(N=order, Wn=frequency, btype=btype,
+                              output='sos', fs=sampling_rate)
+    if _is_da(x):
+        return _apply_da(x, dim, lambda v: _ops.sosfiltfilt(None, v, sos))
+    return _ops.sosfiltfilt(None, x, sos)
+
+
+# -- a3: signal/unbias.py:30-145 -------------------------------------------------
+def unbias_weights(npts, index_min=0, index_max=None):
+    """``weight(npts)[index_min:index_max]`` (signal/unbias.py:133-135)."""
+    from ..util.cc import weight
+    index_max = 2 * npts - 1 if index_max is None else index_max
+    return weight(npts, pad=True)[index_min:index_max]
+
+
+def unbias(x, npts=None, index_min=0, index_max=None, dim=None):
+    """Bias-correct a cross-correlation estimate (signal/unbias.py:73-85)."""
+    if _is_da(x):
+        dim = _check_dim(x, dim)
+        if 'unbiased' not in x.attrs:
+            raise ValueError('x has no unbiased attribute flag!')
+        if x.attrs['unbiased'] != 0:
+            return x
+        la = x[dim].attrs
+        for attr in ('sampling_rate', 'delta', 'npts', 'index_min',
+                     'index_max'):
+            if attr not in la:
+                raise ValueError(f'Lag has no attribute "{attr}"!')
+        y = _apply_da(x, dim, lambda v: _ops.unbias(
+            None, v, la['npts'], la['index_min'], la['index_max']))
+        y.attrs['unbiased'] = np.byte(True)
+        return y
+    if npts is None:
+        raise ValueError('npts is required for array input')
+    return _ops.unbias(None, x, npts, index_min, index_max or 0)
