@@ -94,16 +94,16 @@ def test_unsupported_and_invalid_arguments(ctx):
         plan.pairs(np.zeros((2, 100), np.float32), [(0, 2)], 1, 100)
     with pytest.raises(ValueError):
         plan.cc(np.zeros((1, 100), np.float32), np.zeros((1, 99), np.float32))
+    # XCX_WHITEN without a band is an error, not a silent no-op
+    import ctypes as C
+    from xcorr_amd import _ffi
+    h = C.c_void_p()
+    _ffi.check(_ffi.lib().xcx_plan_cc1d(ctx.handle, 100, 0, 0, 0, _ffi.NORMALIZE | _ffi.WHITEN, C.byref(h)))
+    x = np.zeros((1, 100), np.float32)
+    o = np.zeros((1, 199), np.float32)
     with pytest.raises(XcxError, match='xcx_plan_set_whiten'):
-        p = X.CCPlan.__new__(X.CCPlan)
-        X.CCPlan.__init__(p, ctx, 100, whiten=None)
-        import ctypes as C
-        from xcorr_amd import _ffi
-        h = C.c_void_p()
-        _ffi.check(_ffi.lib().xcx_plan_cc1d(ctx.handle, 100, 0, 0, 0, _ffi.NORMALIZE | _ffi.WHITEN, C.byref(h)))
-        x = np.zeros((1, 100), np.float32)
-        o = np.zeros((1, 199), np.float32)
         _ffi.check(_ffi.lib().xcx_cc1d(h, _ffi.ptr(x), _ffi.ptr(x), 1, _ffi.ptr(o), 0))
+    _ffi.lib().xcx_plan_destroy(h)
 
 
 def test_zero_and_constant_inputs(ctx):

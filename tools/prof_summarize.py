@@ -1,0 +1,58 @@
+"""Condense rocprofv3 CSV output (kernel-trace stats + PMC passes) into a small
+JSON + text summary that is committed under profiles/."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+out = sys.argv[1]
+summ = {}
+
+def short(name):
+    for k in ('k_pair_rows', 'k_pair_cols', 'k_fwd_rows', 'k_fwd_cols', 'k_stats', 'k_sos_tiles',
+              'k_sos_scan', 'k_row_reduce_apply', 'k_taper', 'k_sos_edges'):
+        if k in name:
+            return k
+    return name[:60]
+
+# kernel stats
+for f in glob.glob(os.path.join(out, 'kt', '**', '*kernel_stats.csv'), recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    ks = {}
+    for r in rows:
+        ks[short(r['Name'])] = {
+            'calls': int(r['Calls']), 'total_ns': int(float(r['TotalDurationNs'])),
+            'avg_ns': float(r['AverageNs']), 'pct': float(r['Percentage']),
+            'min_ns': float(r['MinNs']), 'max_ns': float(r['MaxNs'])}
+    summ['kernel_stats'] = ks
+    summ['kernel_stats_file'] = os.path.relpath(f, out)
+
+def pmc(dirname, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    for f in glob.glob(os.path.join(out, dirname, '**', '*counter_collection.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r.get('Counter_Name') != counter:
+                continue
+            k = short(r['Kernel_Name'])
+            acc[k][0] += float(r['Counter_Value'])
+            acc[k][1] += 1
+    return {k: {'sum': v[0], 'dispatches': v[1], 'avg': v[0] / max(v[1], 1)} for k, v in acc.items()}
+
+fetch = pmc('pmc_fetch', 'FETCH_SIZE')
+write = pmc('pmc_write', 'WRITE_SIZE')
+# MI355X_MICROARCH.md (HBM): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950
+# FETCH_SIZE reports exactly half of the bytes of wide coalesced reads.
+hbm = {}
+for k in set(fetch) | set(write):
+    fb = 2.0 * 1024.0 * fetch.get(k, {}).get('avg', 0.0)
+    wb = 1024.0 * write.get(k, {}).get('avg', 0.0)
+    hbm[k] = {'fetch_bytes_per_launch_corrected_x2': fb, 'write_bytes_per_launch': wb,
+              'hbm_bytes_per_launch': fb + wb,
+              'fetch_kib_raw_avg': fetch.get(k, {}).get('avg'), 'write_kib_raw_avg': write.get(k, {}).get('avg')}
+summ['pmc'] = hbm
+json.dump(summ, open(os.path.join(out, 'summary.json'), 'w'), indent=1)
+with open(os.path.join(out, 'summary.txt'), 'w') as fh:
+    fh.write('kernel                 calls   avg_us     pct   fetch_MB(x2)  write_MB  (per launch)\n')
+    for k, v in sorted(summ.get('kernel_stats', {}).items(), key=lambda kv: -kv[1]['total_ns']):
+        h = hbm.get(k, {})
+        fh.write(f"{k:22s} {v['calls']:6d} {v['avg_ns']/1e3:8.1f} {v['pct']:7.2f} "
+                 f"{h.get('fetch_bytes_per_launch_corrected_x2', 0)/1e6:12.2f} {h.get('write_bytes_per_launch', 0)/1e6:9.2f}\n")
+print(open(os.path.join(out, 'summary.txt')).read())
