@@ -223,6 +223,7 @@ template <bool INV> struct Bfly<10, INV> : BflyCT<2, 5, INV> {};
 template <bool INV> struct Bfly<12, INV> : BflyCT<3, 4, INV> {};
 template <bool INV> struct Bfly<15, INV> : BflyCT<3, 5, INV> {};
 template <bool INV> struct Bfly<16, INV> : BflyCT<4, 4, INV> {};
+template <bool INV> struct Bfly<24, INV> : BflyCT<3, 8, INV> {};
 
 // ---------------------------------------------------------------------------
 // sub-FFT configuration: length and up to four radices (1 = unused)

@@ -1,0 +1,38 @@
+// wave_inst.hip -- one instantiation of the wave column or row kernels.
+// Compile with -DXCX_INST_COL=1|0 -DXCX_INST_L=<len> -DXCX_INST_R=<r0,r1,..>
+#include "wave_launch.h"
+
+namespace xcx {
+
+using RX = Radices<XCX_INST_R>;
+static_assert(RX::L == XCX_INST_L, "radices do not multiply to the length");
+
+#define XCX_CAT2(a, b) a##b
+#define XCX_CAT(a, b) XCX_CAT2(a, b)
+
+#if XCX_INST_COL
+constexpr size_t kLds = sizeof(cf) * cpad_size(RX::L);
+hipError_t XCX_CAT(launch_wfwd_cols_, XCX_INST_L)(const WF2Args& a, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_wfwd_cols<RX>, grid, dim3(kWNT), kLds, s, a);
+  return hipGetLastError();
+}
+hipError_t XCX_CAT(launch_wpair_cols_, XCX_INST_L)(const WI1Args& a, dim3 grid, hipStream_t s) {
+  if (a.nstack > 1)
+    hipLaunchKernelGGL((k_wpair_cols<RX, true>), grid, dim3(kWNT), kLds, s, a);
+  else
+    hipLaunchKernelGGL((k_wpair_cols<RX, false>), grid, dim3(kWNT), kLds, s, a);
+  return hipGetLastError();
+}
+#else
+constexpr size_t kLds = sizeof(cf) * RX::L * kWRB;
+hipError_t XCX_CAT(launch_wfwd_rows_, XCX_INST_L)(const WF1Args& a, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_wfwd_rows<RX>, grid, dim3(kWNT), kLds, s, a);
+  return hipGetLastError();
+}
+hipError_t XCX_CAT(launch_wpair_rows_, XCX_INST_L)(const WI2Args& a, dim3 grid, hipStream_t s) {
+  hipLaunchKernelGGL(k_wpair_rows<RX>, grid, dim3(kWNT), kLds, s, a);
+  return hipGetLastError();
+}
+#endif
+
+}  // namespace xcx

@@ -1,0 +1,31 @@
+// wave_launch.h -- launch table of the one-wave-per-workgroup kernels
+#pragma once
+#include <hip/hip_runtime.h>
+#include "wave_kernels.h"
+
+namespace xcx {
+
+#define XCX_WCOL_LIST(X) X(64) X(128) X(256) X(512) X(768) X(1024) X(1536) X(2048)
+#define XCX_WROW_LIST(X) X(16) X(32) X(64) X(120) X(128)
+
+#define XCX_DECL_WCOL(L)                                                       \
+  hipError_t launch_wfwd_cols_##L(const WF2Args& a, dim3 grid, hipStream_t s); \
+  hipError_t launch_wpair_cols_##L(const WI1Args& a, dim3 grid, hipStream_t s);
+#define XCX_DECL_WROW(L)                                                       \
+  hipError_t launch_wfwd_rows_##L(const WF1Args& a, dim3 grid, hipStream_t s); \
+  hipError_t launch_wpair_rows_##L(const WI2Args& a, dim3 grid, hipStream_t s);
+XCX_WCOL_LIST(XCX_DECL_WCOL)
+XCX_WROW_LIST(XCX_DECL_WROW)
+
+struct WColEntry {
+  int L;
+  hipError_t (*fwd)(const WF2Args&, dim3, hipStream_t);
+  hipError_t (*pair)(const WI1Args&, dim3, hipStream_t);
+};
+struct WRowEntry {
+  int L;
+  hipError_t (*fwd)(const WF1Args&, dim3, hipStream_t);
+  hipError_t (*pair)(const WI2Args&, dim3, hipStream_t);
+};
+
+}  // namespace xcx

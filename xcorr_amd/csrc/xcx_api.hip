@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -12,6 +13,7 @@
 
 #include "../../include/xcx.h"
 #include "cc_launch.h"
+#include "wave_launch.h"
 #include "xcx_internal.h"
 
 using namespace xcx;
@@ -50,6 +52,52 @@ static const ColEntry kCols[] = {XCX_COL_LIST(XCX_COL_ROW)};
 static const RowEntry kRows[] = {XCX_ROW_LIST(XCX_ROW_ROW)};
 static const int kNCols = sizeof(kCols) / sizeof(kCols[0]);
 static const int kNRows = sizeof(kRows) / sizeof(kRows[0]);
+#define XCX_WCOL_ROW(L) {L, launch_wfwd_cols_##L, launch_wpair_cols_##L},
+#define XCX_WROW_ROW(L) {L, launch_wfwd_rows_##L, launch_wpair_rows_##L},
+static const WColEntry kWCols[] = {XCX_WCOL_LIST(XCX_WCOL_ROW)};
+static const WRowEntry kWRows[] = {XCX_WROW_LIST(XCX_WROW_ROW)};
+static const int kNWCols = sizeof(kWCols) / sizeof(kWCols[0]);
+static const int kNWRows = sizeof(kWRows) / sizeof(kWRows[0]);
+
+// ---------------------------------------------------------------------------
+// k_wstats: partial sums of a station-window, grid = (kStatParts, cnt).
+// PHASE 0: sum(x) -> psum (only with DEMEAN); PHASE 1: sum(x'^2) -> psq with
+// x' the demeaned / one-bit sample.  Consumers add the kStatParts partials in
+// fixed order (wave_kernels.h sw_mean / sw_scale): deterministic.
+// ---------------------------------------------------------------------------
+template <int PHASE>
+__global__ __launch_bounds__(kNT) void k_wstats(
+    const float* __restrict__ traces, long stride_s, long stride_w, int W,
+    int w0, int sw0, int n, int flags, const double* __restrict__ psum,
+    double* __restrict__ dst) {
+  __shared__ double red[kNT];
+  const int swl = blockIdx.y;
+  const int sw = sw0 + swl;
+  const int s = sw / W, wl = sw % W;
+  const float* x = traces + (long)s * stride_s + (long)(w0 + wl) * stride_w;
+  const int tid = threadIdx.x;
+  const int part = blockIdx.x;
+  const int per = (n + kStatParts - 1) / kStatParts;
+  const int lo = part * per, hi = min(n, lo + per);
+  double acc = 0.0;
+  if (PHASE == 0) {
+    for (int i = lo + tid; i < hi; i += kNT) acc += (double)x[i];
+  } else {
+    const float mean = sw_mean(psum, swl, n, flags & XCX_F_DEMEAN);
+    for (int i = lo + tid; i < hi; i += kNT) {
+      float v = x[i] - mean;
+      if (flags & XCX_F_ONEBIT) v = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
+      acc += (double)v * (double)v;
+    }
+  }
+  red[tid] = acc;
+  __syncthreads();
+  for (int o = kNT / 2; o > 0; o >>= 1) {
+    if (tid < o) red[tid] += red[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) dst[swl * kStatParts + part] = red[0];
+}
 
 // ---------------------------------------------------------------------------
 // k_stats: one workgroup per station-window; mean (optional) and the scale
@@ -251,6 +299,10 @@ struct xcx_plan {
   Geom g{};
   const ColEntry* col = nullptr;
   const RowEntry* row = nullptr;
+  const WColEntry* wcol = nullptr;
+  const WRowEntry* wrow = nullptr;
+  bool wave = true;          // one-wave-per-workgroup engine (default)
+  DevBuf psum, psq;          // partial statistics of a forward chunk
   int L = 0;                 // retained lags
   int batch = 64;            // pair-windows per launch batch
   size_t spec_pitch = 0;     // float2 per spectrum slot
@@ -316,37 +368,47 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
     return set_err(XCX_EINVAL, "lag slice [%d,%d) outside [0,%lld)", idx_min,
                    idx_max, full);
   // choose N = 2*N1*N2h: smallest supported >= 2n-1 (or == nfft)
+  const char* eng = getenv("XCX_ENGINE");
+  const bool wave = !(eng && strcmp(eng, "wg") == 0);
   long long best = -1;
-  const ColEntry* bc = nullptr;
-  const RowEntry* br = nullptr;
-  for (int i = 0; i < kNCols; ++i)
-    for (int j = 0; j < kNRows; ++j) {
-      long long N = 2LL * kCols[i].L * kRows[j].L;
+  int bi = -1, bj = -1;
+  const int nc = wave ? kNWCols : kNCols, nr = wave ? kNWRows : kNRows;
+  for (int i = 0; i < nc; ++i)
+    for (int j = 0; j < nr; ++j) {
+      const int L1 = wave ? kWCols[i].L : kCols[i].L;
+      const int L2 = wave ? kWRows[j].L : kRows[j].L;
+      long long N = 2LL * L1 * L2;
       if (N < full) continue;
       if (nfft > 0 && N != nfft) continue;
-      // among equal N prefer the most balanced split
-      bool better = best < 0 || N < best ||
-                    (N == best && std::abs(kCols[i].L - kRows[j].L) <
-                                      std::abs(bc->L - br->L));
-      if (better) { best = N; bc = &kCols[i]; br = &kRows[j]; }
+      // among equal N: wave engine prefers long columns (one column per
+      // wave), the workgroup engine the most balanced split
+      bool better = best < 0 || N < best;
+      if (!better && N == best) {
+        const int b1 = wave ? kWCols[bi].L : kCols[bi].L;
+        const int b2 = wave ? kWRows[bj].L : kRows[bj].L;
+        better = wave ? (L1 > b1) : (std::abs(L1 - L2) < std::abs(b1 - b2));
+      }
+      if (better) { best = N; bi = i; bj = j; }
     }
   if (best < 0)
     return set_err(XCX_EUNSUPPORTED,
                    "no supported transform length for n=%d (nfft=%d); "
                    "supported N = 2*N1*N2h up to %d", n, nfft,
-                   2 * kCols[kNCols - 1].L * kRows[kNRows - 1].L);
+                   wave ? 2 * kWCols[kNWCols - 1].L * kWRows[kNWRows - 1].L
+                        : 2 * kCols[kNCols - 1].L * kRows[kNRows - 1].L);
   HIP_TRY(hipSetDevice(ctx->device));
   xcx_plan* p = new (std::nothrow) xcx_plan();
   if (!p) return set_err(XCX_ENOMEM, "host allocation failed");
   p->ctx = ctx;
-  p->col = bc;
-  p->row = br;
+  p->wave = wave;
+  if (wave) { p->wcol = &kWCols[bi]; p->wrow = &kWRows[bj]; }
+  else { p->col = &kCols[bi]; p->row = &kRows[bj]; }
   Geom& g = p->g;
   g.n = n;
   g.N = (int)best;
-  g.N1 = bc->L;
-  g.N2h = br->L;
-  g.N2 = 2 * br->L;
+  g.N1 = wave ? kWCols[bi].L : kCols[bi].L;
+  g.N2h = wave ? kWRows[bj].L : kRows[bj].L;
+  g.N2 = 2 * g.N2h;
   g.idx_min = idx_min;
   g.idx_max = idx_max;
   g.shift = (int)(((long long)n - 1 - idx_min) % g.N1);
@@ -383,7 +445,7 @@ extern "C" int xcx_plan_destroy(xcx_plan* p) {
   for (auto& e : p->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   DevBuf* bufs[] = {&p->tw_N1, &p->tw_N2h, &p->tw_unt, &p->tw_N, &p->stats,
                     &p->Tm_f, &p->Tn_f, &p->spectra, &p->T, &p->descs,
-                    &p->dtraces, &p->dout, &p->dpairs};
+                    &p->dtraces, &p->dout, &p->dpairs, &p->psum, &p->psq};
   for (DevBuf* b : bufs) b->release();
   delete p;
   return XCX_OK;
@@ -480,6 +542,54 @@ static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_
   int rc;
   if ((g.flags & XCX_F_WHITEN) && !p->whiten_set)
     return set_err(XCX_EINVAL, "XCX_WHITEN set but xcx_plan_set_whiten() not called");
+  if (p->wave) {
+    const size_t tf_per = (size_t)(g.N2h + 1) * g.N1;
+    if ((rc = p->psum.ensure(ctx, sizeof(double) * kStatParts * kChunk))) return rc;
+    if ((rc = p->psq.ensure(ctx, sizeof(double) * kStatParts * kChunk))) return rc;
+    if ((rc = p->Tm_f.ensure(ctx, sizeof(cf) * tf_per * kChunk))) return rc;
+    for (int b = sw_begin; b < sw_end; b += kChunk) {
+      const int cnt = std::min(kChunk, sw_end - b);
+      {
+        ProfScope ps(p, KID_STATS, cnt);
+        if (g.flags & XCX_F_DEMEAN)
+          hipLaunchKernelGGL(k_wstats<0>, dim3(kStatParts, cnt), dim3(kNT), 0, ctx->stream, traces, stride_s,
+                             stride_w, W, w0, b, g.n, g.flags, (const double*)nullptr, (double*)p->psum.ptr);
+        if ((g.flags & XCX_F_NORMALIZE) && !(g.flags & XCX_F_WHITEN))
+          hipLaunchKernelGGL(k_wstats<1>, dim3(kStatParts, cnt), dim3(kNT), 0, ctx->stream, traces, stride_s,
+                             stride_w, W, w0, b, g.n, g.flags, (const double*)p->psum.ptr, (double*)p->psq.ptr);
+      }
+      HIP_TRY(hipGetLastError());
+      WF1Args f1{};
+      f1.traces = traces; f1.stride_s = stride_s; f1.stride_w = stride_w;
+      f1.W = W; f1.w0 = w0; f1.sw0 = b;
+      f1.psum = (const double*)p->psum.ptr;
+      f1.Tf = (cf*)p->Tm_f.ptr;
+      f1.tw_sub = (const cf*)p->tw_N2h.ptr;
+      f1.tw_unt = (const cf*)p->tw_unt.ptr;
+      f1.tw_N = (const cf*)p->tw_N.ptr;
+      f1.g = g;
+      {
+        ProfScope ps(p, KID_FWD_ROWS, cnt);
+        HIP_TRY(p->wrow->fwd(f1, dim3(g.N1 / kWRB, cnt), ctx->stream));
+      }
+      WF2Args f2{};
+      f2.Tf = (const cf*)p->Tm_f.ptr;
+      f2.psq = (const double*)p->psq.ptr;
+      f2.X = (cf*)p->spectra.ptr;
+      f2.spec_pitch = p->spec_pitch;
+      f2.slot0 = slot0 + b;
+      f2.tw_sub = (const cf*)p->tw_N1.ptr;
+      f2.wb0 = p->wb[0]; f2.wb1 = p->wb[1]; f2.wb2 = p->wb[2]; f2.wb3 = p->wb[3];
+      f2.fixed_norm = p->fixed_norm;
+      f2.g = g;
+      {
+        ProfScope ps(p, KID_FWD_COLS, cnt);
+        HIP_TRY(p->wcol->fwd(f2, dim3(g.N2h + 1, cnt), ctx->stream));
+      }
+      p->launches += 4;
+    }
+    return XCX_OK;
+  }
   if ((rc = p->stats.ensure(ctx, sizeof(SwStat) * kChunk))) return rc;
   if ((rc = p->Tm_f.ensure(ctx, sizeof(cf) * tm_per * kChunk))) return rc;
   if ((rc = p->Tn_f.ensure(ctx, sizeof(cf) * g.N1 * kChunk))) return rc;
@@ -529,6 +639,37 @@ static int pair_batch(xcx_plan* p, size_t d0, int B, float* out, int nstack) {
   xcx_ctx* ctx = p->ctx;
   const Geom& g = p->g;
   const size_t tm_per = (size_t)g.N1 * g.N2h;
+  if (p->wave) {
+    WI1Args a{};
+    a.X = (const cf*)p->spectra.ptr;
+    a.spec_pitch = p->spec_pitch;
+    a.pw = (const PwDesc*)p->descs.ptr + d0;
+    a.B = B;
+    a.nstack = nstack;
+    a.T = (cf*)p->T.ptr;
+    a.tw_sub = (const cf*)p->tw_N1.ptr;
+    a.tw_N = (const cf*)p->tw_N.ptr;
+    a.g = g;
+    const int per_xcd = (g.N2h + 1 + 7) / 8;
+    {
+      ProfScope ps(p, KID_PAIR_COLS, B);
+      HIP_TRY(p->wcol->pair(a, dim3(8u * per_xcd * B), ctx->stream));
+    }
+    WI2Args r{};
+    r.T = (const cf*)p->T.ptr;
+    r.pw = a.pw;
+    r.out = out;
+    r.tw_sub = (const cf*)p->tw_N2h.ptr;
+    r.tw_unt = (const cf*)p->tw_unt.ptr;
+    r.g = g;
+    {
+      ProfScope ps(p, KID_PAIR_ROWS, B);
+      HIP_TRY(p->wrow->pair(r, dim3(g.N1 / kWRB, B), ctx->stream));
+    }
+    p->launches += 2;
+    p->pair_windows += B;
+    return XCX_OK;
+  }
   I1Args a{};
   a.Xm = (const cf*)p->spectra.ptr;
   a.Xn = (const cf*)p->spectra.ptr + tm_per;
