@@ -290,6 +290,89 @@ XCX_DEV void fft_stage(const cf* __restrict__ tw, LoadF ld, StoreF st) {
 }
 
 // ---------------------------------------------------------------------------
+// Chain-twiddle variant used by the one-wave kernels: instead of R-1 table
+// loads per butterfly, ONE base factor w = W_{NS*R}^{k} per (lane, iteration)
+// is loaded up front (stage_tw_base, issued at kernel start in the shadow of
+// the data loads) and its powers are formed by multiplication, re-seeded at
+// w^8 and w^16 from repeated squaring so that no factor is more than ~10
+// roundings away from the table value.
+// VEC_ST: `st(j0, c, v)` receives the whole butterfly output (positions
+// j0 + t*NS) so that the caller can run its own recurrences over t.
+// ---------------------------------------------------------------------------
+template <int L, int R, int NS, int NB, int NT> struct StageGeom {
+  static constexpr int NBF = NB * (L / R);
+  static constexpr int IT = (NBF + NT - 1) / NT;
+  static constexpr bool GUARD = (NBF % NT) != 0;
+  static constexpr int STEP = (NS > 1) ? L / (NS * R) : 0;
+};
+
+template <int L, int R, int NS, int NB, int NT>
+XCX_DEV void stage_tw_base(const cf* __restrict__ tw,
+                           cf (&base)[StageGeom<L, R, NS, NB, NT>::IT]) {
+  using G = StageGeom<L, R, NS, NB, NT>;
+#pragma unroll
+  for (int it = 0; it < G::IT; ++it) {
+    const int b = threadIdx.x + it * NT;
+    const int j = (G::GUARD && b >= G::NBF) ? 0 : b / NB;
+    base[it] = tw[(j % NS) * G::STEP];
+  }
+}
+
+XCX_DEV cf csq(cf a) { return make_float2(a.x * a.x - a.y * a.y, 2.f * a.x * a.y); }
+
+// v[t] *= w^t  (conjugated when INV), t = 1..R-1
+template <int R, bool INV> XCX_DEV void apply_tw_chain(cf (&v)[R], cf w1) {
+  cf w8 = w1, wt = w1;
+  if constexpr (R > 8) w8 = csq(csq(csq(w1)));
+  static_for<R - 1>([&](auto tc) {
+    constexpr int t = decltype(tc)::value + 1;
+    if constexpr (t == 1) wt = w1;
+    else if constexpr (t == 8) wt = w8;
+    else if constexpr (t == 16) wt = csq(w8);
+    else if constexpr (t == 24) wt = cmul(csq(w8), w8);
+    else wt = cmul(wt, w1);
+    v[t] = ctw<INV>(v[t], wt);
+  });
+}
+
+template <int L, int R, int NS, int NB, int NT, bool INV, bool SYNC, bool VEC_ST,
+          class LoadF, class StoreF>
+XCX_DEV void fft_stage_c(const cf (&base)[StageGeom<L, R, NS, NB, NT>::IT], LoadF ld, StoreF st) {
+  using G = StageGeom<L, R, NS, NB, NT>;
+  const int tid = threadIdx.x;
+  cf v[G::IT][R];
+#pragma unroll
+  for (int it = 0; it < G::IT; ++it) {
+    const int b = tid + it * NT;
+    if (!G::GUARD || b < G::NBF) {
+      const int c = b % NB;
+      const int j = b / NB;
+#pragma unroll
+      for (int t = 0; t < R; ++t) v[it][t] = ld(j + t * (L / R), c);
+      if constexpr (NS > 1) apply_tw_chain<R, INV>(v[it], base[it]);
+      Bfly<R, INV>::run(v[it]);
+    }
+  }
+  if constexpr (SYNC) __syncthreads();
+#pragma unroll
+  for (int it = 0; it < G::IT; ++it) {
+    const int b = tid + it * NT;
+    if (!G::GUARD || b < G::NBF) {
+      const int c = b % NB;
+      const int j = b / NB;
+      const int k = (NS > 1) ? (j % NS) : 0;
+      const int j0 = (j - k) * R + k;
+      if constexpr (VEC_ST) {
+        st(it, j0, c, v[it]);
+      } else {
+#pragma unroll
+        for (int t = 0; t < R; ++t) st(j0 + t * NS, c, v[it][t]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // whole sub-FFT: first stage reads through `in`, last stage writes through
 // `out`, intermediate stages exchange through `lds` ([L][NBP] float2).
 // IN_LDS: `in` itself reads `lds` (barrier needed before stage 0 overwrites).

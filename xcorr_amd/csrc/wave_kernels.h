@@ -16,9 +16,9 @@
 // Layouts (all chosen so that every global access of a wave instruction is a
 // run of full 128-byte lines):
 //   Tf / X : [k2 in 0..N2h][N1]        column-major, Nyquist = column N2h
-//   T      : [res >> 4][k2 in 0..N2h-1][res & 15]   16-row tiles, where
-//            res = (m1 + shift) mod N1 is the OUTPUT residue of row m1; the
-//            real Nyquist value is packed into the imaginary slot of k2 = 0
+//   T      : [res >> 4][k2 in 0..N2h][res & 15]   16-row tiles, where
+//            res = (m1 + shift) mod N1 is the OUTPUT residue of row m1
+//            (slots k2 = 0 and N2h are real: only .x is consumed)
 //
 // The C2R row kernel reads each T element exactly once: butterflies j and
 // S-j of its first stage are computed by the same lane, which therefore holds
@@ -36,28 +36,40 @@ constexpr int kWNT = 64;     // one wave
 XCX_DEV int cpad(int p) { return p + (p >> 3); }
 constexpr int cpad_size(int L) { return L + (L >> 3) + 1; }
 
-// generic NB-sequence sub-FFT through LDS with caller-provided index maps
-template <class RX, int NB, bool INV, class Idx, class In, class Out>
-XCX_DEV void wave_subfft(cf* __restrict__ lds, const cf* __restrict__ tw, Idx idx, In in, Out out) {
+// One-column complex FFT of length RX::L by one wave.  All twiddle base
+// factors are loaded before the first butterfly; after the input loads the
+// wave touches only registers and LDS.  `epi(it, j0, v)` receives each last
+// stage butterfly (outputs at positions j0 + t*NSlast, t = 0..Rlast-1).
+template <class RX> struct ColGeom {
+  static constexpr int L = RX::L;
+  static constexpr int S = RX::S;
+  static constexpr int RL = (S == 2) ? RX::R1 : ((S == 3) ? RX::R2 : RX::R3);   // last radix
+  static constexpr int NSL = L / RL;                                            // its NS
+  using Last = StageGeom<L, RL, NSL, 1, kWNT>;
+};
+
+template <class RX, bool INV, class In, class Epi>
+XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in, Epi epi) {
   constexpr int L = RX::L;
-  constexpr int R0 = RX::R0, R1 = RX::R1, R2 = RX::R2, R3 = RX::R3;
-  auto lds_ld = [=](int p, int c) -> cf { return lds[idx(p, c)]; };
-  auto lds_st = [=](int p, int c, cf v) { lds[idx(p, c)] = v; };
-  static_assert(RX::S >= 2, "wave kernels need at least two stages");
-  fft_stage<L, R0, 1, NB, kWNT, INV, false>(tw, in, lds_st);
-  __syncthreads();
+  constexpr int R0 = RX::R0, R1 = RX::R1, R2 = RX::R2;
+  static_assert(RX::S == 2 || RX::S == 3, "column configs have two or three stages");
+  auto lds_ld = [=](int p, int) -> cf { return lds[cpad(p)]; };
+  auto lds_st = [=](int p, int, cf v) { lds[cpad(p)] = v; };
+  cf b0[StageGeom<L, R0, 1, 1, kWNT>::IT];
+  cf b1[StageGeom<L, R1, R0, 1, kWNT>::IT];
+  stage_tw_base<L, R1, R0, 1, kWNT>(tw, b1);
   if constexpr (RX::S == 2) {
-    fft_stage<L, R1, R0, NB, kWNT, INV, false>(tw, lds_ld, out);
-  } else {
-    fft_stage<L, R1, R0, NB, kWNT, INV, true>(tw, lds_ld, lds_st);
+    fft_stage_c<L, R0, 1, 1, kWNT, INV, false, false>(b0, in, lds_st);
     __syncthreads();
-    if constexpr (RX::S == 3) {
-      fft_stage<L, R2, R0 * R1, NB, kWNT, INV, false>(tw, lds_ld, out);
-    } else {
-      fft_stage<L, R2, R0 * R1, NB, kWNT, INV, true>(tw, lds_ld, lds_st);
-      __syncthreads();
-      fft_stage<L, R3, R0 * R1 * R2, NB, kWNT, INV, false>(tw, lds_ld, out);
-    }
+    fft_stage_c<L, R1, R0, 1, kWNT, INV, false, true>(b1, lds_ld, epi);
+  } else {
+    cf b2[StageGeom<L, R2, R0 * R1, 1, kWNT>::IT];
+    stage_tw_base<L, R2, R0 * R1, 1, kWNT>(tw, b2);
+    fft_stage_c<L, R0, 1, 1, kWNT, INV, false, false>(b0, in, lds_st);
+    __syncthreads();
+    fft_stage_c<L, R1, R0, 1, kWNT, INV, true, false>(b1, lds_ld, lds_st);
+    __syncthreads();
+    fft_stage_c<L, R2, R0 * R1, 1, kWNT, INV, false, true>(b2, lds_ld, epi);
   }
 }
 
@@ -126,17 +138,15 @@ __global__ __launch_bounds__(kWNT) void k_wfwd_rows(WF1Args a) {
     }
     return make_float2(v0, v1);
   };
-  auto idx = [](int p, int r) { return p * kWRB + r; };
   auto to_lds = [=](int p, int r, cf v) { lds[p * kWRB + r] = v; };
   auto lds_ld = [=](int p, int r) -> cf { return lds[p * kWRB + r]; };
-  (void)idx;
-  fft_stage<N2h, RX::R0, 1, kWRB, kWNT, false, false>(a.tw_sub, in, to_lds);
+  static_assert(RX::S == 2, "row configs have two stages");
+  cf b0[StageGeom<N2h, RX::R0, 1, kWRB, kWNT>::IT];
+  cf b1[StageGeom<N2h, RX::R1, RX::R0, kWRB, kWNT>::IT];
+  stage_tw_base<N2h, RX::R1, RX::R0, kWRB, kWNT>(a.tw_sub, b1);
+  fft_stage_c<N2h, RX::R0, 1, kWRB, kWNT, false, false, false>(b0, in, to_lds);
   __syncthreads();
-  fft_stage<N2h, RX::R1, RX::R0, kWRB, kWNT, false, true>(a.tw_sub, lds_ld, to_lds);
-  if constexpr (RX::S >= 3) {
-    __syncthreads();
-    fft_stage<N2h, RX::R2, RX::R0 * RX::R1, kWRB, kWNT, false, true>(a.tw_sub, lds_ld, to_lds);
-  }
+  fft_stage_c<N2h, RX::R1, RX::R0, kWRB, kWNT, false, true, false>(b1, lds_ld, to_lds);
   __syncthreads();
   cf* __restrict__ Tf = a.Tf + (size_t)sw * (size_t)(N2h + 1) * N1;
   for (int i = threadIdx.x; i < kWRB * N2h; i += kWNT) {
@@ -185,18 +195,23 @@ __global__ __launch_bounds__(kWNT) void k_wfwd_cols(WF2Args a) {
   cf* __restrict__ dst = a.X + (size_t)(a.slot0 + sw) * a.spec_pitch + (size_t)k2 * N1;
   const float wb0 = a.wb0, wb1 = a.wb1, wb2 = a.wb2, wb3 = a.wb3;
   auto in = [=](int m1, int) -> cf { return src[m1]; };
-  auto out = [=](int k1, int, cf v) {
-    if (whiten) {
-      int k = k1 * N2 + k2;
-      if (k > N - k) k = N - k;
-      const float gain = whiten_gain((float)k, wb0, wb1, wb2, wb3);
-      const float mag = sqrtf(v.x * v.x + v.y * v.y);
-      v = cscale(v, (mag > 0.f) ? gain / mag : 0.f);
+  using CG = ColGeom<RX>;
+  auto epi = [=](int, int j0, int, cf (&v)[CG::RL]) {
+#pragma unroll
+    for (int t = 0; t < CG::RL; ++t) {
+      const int k1 = j0 + t * CG::NSL;
+      cf o = v[t];
+      if (whiten) {
+        int k = k1 * N2 + k2;
+        if (k > N - k) k = N - k;
+        const float gain = whiten_gain((float)k, wb0, wb1, wb2, wb3);
+        const float mag = sqrtf(o.x * o.x + o.y * o.y);
+        o = cscale(o, (mag > 0.f) ? gain / mag : 0.f);
+      }
+      dst[k1] = cscale(o, scale);
     }
-    dst[k1] = cscale(v, scale);
   };
-  auto idx = [](int p, int) { return cpad(p); };
-  wave_subfft<RX, 1, false>(lds, a.tw_sub, idx, in, out);
+  wave_col_fft<RX, false>(lds, a.tw_sub, in, epi);
 }
 
 // ---------------------------------------------------------------------------
@@ -208,7 +223,7 @@ __global__ __launch_bounds__(kWNT) void k_wfwd_cols(WF2Args a) {
 struct WI1Args {
   const cf* X; size_t spec_pitch;
   const PwDesc* pw; int B; int nstack;
-  cf* T;                     // [B][N1/16][N2h][16]
+  cf* T;                     // [B][N1/16][N2h+1][16]
   const cf* tw_sub; const cf* tw_N;
   Geom g;
 };
@@ -229,11 +244,22 @@ __global__ __launch_bounds__(kWNT) void k_wpair_cols(WI1Args a) {
   const cf* __restrict__ Bp = a.X + (size_t)d.slot_b * a.spec_pitch + (size_t)k2 * N1;
   const int nstack = a.nstack;
   const unsigned sstride = (unsigned)a.spec_pitch;   // consecutive slots = consecutive windows
-  cf* __restrict__ T = a.T + (size_t)pwl * N1 * N2h;
+  cf* __restrict__ T = a.T + (size_t)pwl * N1 * (N2h + 1);
   const cf* __restrict__ twN = a.tw_N;
-  const bool nyq = k2 == N2h;
   const unsigned kk = (unsigned)k2;
   const int shift = g.shift;
+  using CG = ColGeom<RX>;
+  // four-step factors w_N^{-(j0 + t*NSL) k2}: base per (lane, iteration) and
+  // the wave-uniform step g = w_N^{-NSL k2}; powers by multiplication
+  cf f0[CG::Last::IT];
+#pragma unroll
+  for (int it = 0; it < CG::Last::IT; ++it) {
+    const int b = threadIdx.x + it * kWNT;
+    const int j = (CG::Last::GUARD && b >= CG::Last::NBF) ? 0 : b;
+    const int k = j % CG::NSL;
+    f0[it] = twN_lookup(twN, (unsigned)((j - k) * CG::RL + k) * kk);
+  }
+  const cf gstep = twN_lookup(twN, (unsigned)CG::NSL * kk);
   auto in = [=](int k1, int) -> cf {
     cf acc = cmulc(A[k1], Bp[k1]);
     if constexpr (STACK) {
@@ -242,18 +268,23 @@ __global__ __launch_bounds__(kWNT) void k_wpair_cols(WI1Args a) {
     }
     return acc;
   };
-  auto out = [=](int m1, int, cf v) {
-    const cf w = twN_lookup(twN, (unsigned)m1 * kk);
-    const cf r = cmulc(v, w);
-    int res = m1 + shift;
-    if (res >= N1) res -= N1;
-    float* t = reinterpret_cast<float*>(T + ((res >> 4) * N2h + (nyq ? 0 : k2)) * kWRB + (res & 15));
-    if (nyq) t[1] = r.x;
-    else if (k2 == 0) t[0] = r.x;
-    else *reinterpret_cast<cf*>(t) = r;
+  cf* __restrict__ Tc = T + k2 * kWRB;
+  const int trow = (N2h + 1) * kWRB;          // float2 per 16-row tile
+  auto epi = [=](int it, int j0, int, cf (&v)[CG::RL]) {
+    cf g8 = gstep, f = f0[it];
+    if constexpr (CG::RL > 8) g8 = csq(csq(csq(gstep)));
+    static_for<CG::RL>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      if constexpr (t > 0) {
+        if constexpr (t % 8 == 0) { f = f0[it]; static_for<t / 8>([&](auto) { f = cmul(f, g8); }); }
+        else f = cmul(f, gstep);
+      }
+      int res = j0 + t * CG::NSL + shift;
+      if (res >= N1) res -= N1;
+      Tc[(res >> 4) * trow + (res & 15)] = cmulc(v[t], f);
+    });
   };
-  auto idx = [](int p, int) { return cpad(p); };
-  wave_subfft<RX, 1, true>(lds, a.tw_sub, idx, in, out);
+  wave_col_fft<RX, true>(lds, a.tw_sub, in, epi);
 }
 
 // ---------------------------------------------------------------------------
@@ -280,10 +311,13 @@ __global__ __launch_bounds__(kWNT) void k_wpair_rows(WI2Args a) {
   const int N1 = g.N1, N = g.N, n = g.n;
   const int pwl = blockIdx.y;
   const int blk = blockIdx.x;
-  const cf* __restrict__ Tt = a.T + ((size_t)pwl * (N1 / kWRB) + blk) * (size_t)N2h * kWRB;
+  const cf* __restrict__ Tt = a.T + ((size_t)pwl * (N1 / kWRB) + blk) * (size_t)(N2h + 1) * kWRB;
   float* __restrict__ out = a.out + a.pw[pwl].out_off;
   const cf* __restrict__ twu = a.tw_unt;
   const int lane = threadIdx.x;
+  static_assert(RX::S == 2, "row configs have two stages");
+  cf b1[StageGeom<N2h, RX::R1, RX::R0, kWRB, kWNT>::IT];
+  stage_tw_base<N2h, RX::R1, RX::R0, kWRB, kWNT>(a.tw_sub, b1);
 
   // ---- stage 0: paired butterflies (j, S-j) with the Hermitian untangle ----
 #pragma unroll
@@ -326,7 +360,10 @@ __global__ __launch_bounds__(kWNT) void k_wpair_rows(WI2Args a) {
         ujp[t] = make_float2(sm.x - e.y, sm.y + e.x);
       }
     });
-    if (j == 0) uj[0] = make_float2(av[0].x + av[0].y, av[0].x - av[0].y);   // DC / Nyquist
+    if (j == 0) {                                  // DC and Nyquist of the row are real
+      const float dc = av[0].x, ny = Tt[N2h * kWRB + r].x;
+      uj[0] = make_float2(dc + ny, dc - ny);
+    }
     Bfly<R, true>::run(uj);
 #pragma unroll
     for (int t = 0; t < R; ++t) lds[(j * R + t) * kWRB + r] = uj[t];
@@ -360,14 +397,7 @@ __global__ __launch_bounds__(kWNT) void k_wpair_rows(WI2Args a) {
     }
   };
   auto lds_ld = [=](int p, int r) -> cf { return lds[p * kWRB + r]; };
-  auto lds_st = [=](int p, int r, cf v) { lds[p * kWRB + r] = v; };
-  if constexpr (RX::S == 2) {
-    fft_stage<N2h, RX::R1, RX::R0, kWRB, kWNT, true, false>(a.tw_sub, lds_ld, out_f);
-  } else {
-    fft_stage<N2h, RX::R1, RX::R0, kWRB, kWNT, true, true>(a.tw_sub, lds_ld, lds_st);
-    __syncthreads();
-    fft_stage<N2h, RX::R2, RX::R0 * RX::R1, kWRB, kWNT, true, false>(a.tw_sub, lds_ld, out_f);
-  }
+  fft_stage_c<N2h, RX::R1, RX::R0, kWRB, kWNT, true, false, false>(b1, lds_ld, out_f);
 }
 
 }  // namespace xcx

@@ -772,7 +772,7 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
     p->desc_key = key;
   }
   const int B = p->batch;
-  const size_t tm_per = (size_t)g.N1 * g.N2h;
+  const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
   if ((rc = p->T.ensure(ctx, sizeof(cf) * tm_per * B))) return rc;
   if (stack) {
     if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)S * W))) return rc;
@@ -808,7 +808,7 @@ extern "C" int xcx_cc1d(xcx_plan* p, const float* x, const float* y, int batch,
   const int n = g.n;
   int rc;
   const int kRows = 256;   // rows per chunk
-  const size_t tm_per = (size_t)g.N1 * g.N2h;
+  const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
   if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * 2 * (size_t)std::min(batch, kRows)))) return rc;
   if ((rc = p->T.ensure(ctx, sizeof(cf) * tm_per * p->batch))) return rc;
   if ((rc = p->descs.ensure(ctx, sizeof(PwDesc) * kRows))) return rc;
