@@ -76,6 +76,59 @@ __global__ __launch_bounds__(NT) void k_row_reduce_apply(float* __restrict__ x, 
   }
 }
 
+// few long rows (day-long station traces): split every row over kParts
+// workgroups -- partial sums first, then each workgroup re-derives the row
+// totals from the partials in fixed order and applies them to its slice.
+constexpr int kParts = 64;
+
+template <int OP>
+__global__ __launch_bounds__(NT) void k_row_partial(const float* __restrict__ x, long n, double* __restrict__ part) {
+  __shared__ double red[NT];
+  const float* __restrict__ row = x + (size_t)blockIdx.y * n;
+  const int tid = threadIdx.x;
+  const long per = (n + kParts - 1) / kParts;
+  const long lo = blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+  const double tbar = 0.5 * (double)(n - 1);
+  double a0 = 0.0, a1 = 0.0;
+  for (long i = lo + tid; i < hi; i += NT) {
+    const double v = row[i];
+    if (OP == OP_NORM) a0 += v * v;
+    else { a0 += v; if (OP == OP_DETREND) a1 += ((double)i - tbar) * v; }
+  }
+  a0 = block_sum(a0, red);
+  if (OP == OP_DETREND) a1 = block_sum(a1, red);
+  if (tid == 0) {
+    part[((size_t)blockIdx.y * kParts + blockIdx.x) * 2] = a0;
+    part[((size_t)blockIdx.y * kParts + blockIdx.x) * 2 + 1] = a1;
+  }
+}
+
+template <int OP>
+__global__ __launch_bounds__(NT) void k_row_apply(float* __restrict__ x, long n, const double* __restrict__ part) {
+  float* __restrict__ row = x + (size_t)blockIdx.y * n;
+  const int tid = threadIdx.x;
+  const long per = (n + kParts - 1) / kParts;
+  const long lo = blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+  double s0 = 0.0, s1 = 0.0;
+  for (int p = 0; p < kParts; ++p) {
+    s0 += part[((size_t)blockIdx.y * kParts + p) * 2];
+    s1 += part[((size_t)blockIdx.y * kParts + p) * 2 + 1];
+  }
+  if (OP == OP_NORM) {
+    const float fn = (float)sqrt(s0);
+    for (long i = lo + tid; i < hi; i += NT) row[i] = row[i] / fn;
+  } else if (OP == OP_DEMEAN) {
+    const float mean = (float)(s0 / (double)n);
+    for (long i = lo + tid; i < hi; i += NT) row[i] = row[i] - mean;
+  } else {
+    const double tbar = 0.5 * (double)(n - 1);
+    const double stt = (double)n * ((double)n * (double)n - 1.0) / 12.0;
+    const double m = (n > 1) ? s1 / stt : 0.0;
+    const double b = s0 / (double)n - m * tbar;
+    for (long i = lo + tid; i < hi; i += NT) row[i] = (float)((double)row[i] - (m * (double)i + b));
+  }
+}
+
 // taper: both flanks of nmax samples.  wtype 0: periodic Hann of length
 // 2*nmax (scipy.signal.windows.hann(2*nmax, False)); 1: ObsPy cosine flank
 __global__ void k_taper(float* __restrict__ x, long batch, long n, long nmax, int wtype) {
@@ -156,6 +209,14 @@ template <int OP> int row_op(xcx_ctx* ctx, float* x, long batch, long n, int on_
   Staged st;
   int rc = st.begin(ctx, x, (size_t)batch * n * sizeof(float), on_device);
   if (rc) return rc;
+  if (batch < 1024 && n >= 65536) {
+    if ((rc = ctx->scratch[0].ensure(ctx, sizeof(double) * 2 * kParts * (size_t)batch))) return rc;
+    double* part = (double*)ctx->scratch[0].ptr;
+    hipLaunchKernelGGL(k_row_partial<OP>, dim3(kParts, (unsigned)batch), dim3(NT), 0, ctx->stream, st.dev, n, part);
+    hipLaunchKernelGGL(k_row_apply<OP>, dim3(kParts, (unsigned)batch), dim3(NT), 0, ctx->stream, st.dev, n, part);
+    HIP_TRY(hipGetLastError());
+    return st.end();
+  }
   hipLaunchKernelGGL(k_row_reduce_apply<OP>, dim3((unsigned)batch), dim3(NT), 0, ctx->stream, st.dev, n);
   HIP_TRY(hipGetLastError());
   return st.end();

@@ -133,28 +133,45 @@ __global__ __launch_bounds__(64) void k_sos_tiles(
   }
 }
 
-// sequential propagation of chunk start states, one thread per row.
+// sequential propagation of chunk start states.  One row per 16-lane group:
+// lane d holds state component s[d] and row d of the transition matrix; the
+// matrix-vector product gathers s[e] with wave shuffles.
 //   forward : S0[c] = s; s = Z[c] + M_c s,   c = 0..nchunks-1
 //   reverse : c = nchunks-1..0
 // M_full = A^Lc, M_last = A^(len of the last chunk); init: [rows][D] or null.
 // Z (zero-state end states) is overwritten by the start states S0.
-__global__ void k_sos_scan(double* __restrict__ Z, const double* __restrict__ init,
+__global__ __launch_bounds__(64) void k_sos_scan(double* __restrict__ Z, const double* __restrict__ init,
                            const double* __restrict__ Mfull, const double* __restrict__ Mlast,
                            int D, int nchunks, long rows, int reverse) {
-  const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (row >= rows) return;
-  double s[2 * kMaxK], t[2 * kMaxK];
-  for (int d = 0; d < D; ++d) s[d] = init ? init[row * D + d] : 0.0;
+  const int lane = threadIdx.x;
+  const int d = lane & 15;
+  const long row = (long)blockIdx.x * 4 + (lane >> 4);
+  const bool live = row < rows && d < D;
+  const long rrow = row < rows ? row : rows - 1;       // keep every lane in the shuffles
+  double mf[2 * kMaxK], ml[2 * kMaxK];
+#pragma unroll
+  for (int e = 0; e < 2 * kMaxK; ++e) {
+    mf[e] = (d < D && e < D) ? Mfull[d * D + e] : 0.0;
+    ml[e] = (d < D && e < D) ? Mlast[d * D + e] : 0.0;
+  }
+  double s = (live && init) ? init[rrow * D + d] : 0.0;
+  double* zr = Z + (size_t)rrow * nchunks * D;
+  int c = reverse ? nchunks - 1 : 0;
+  double znext = live ? zr[(size_t)c * D + d] : 0.0;
   for (int i = 0; i < nchunks; ++i) {
-    const int c = reverse ? (nchunks - 1 - i) : i;
-    double* zc = Z + ((size_t)row * nchunks + c) * D;
-    const double* M = (c == nchunks - 1) ? Mlast : Mfull;
-    for (int d = 0; d < D; ++d) {
-      double acc = zc[d];
-      for (int e = 0; e < D; ++e) acc += M[d * D + e] * s[e];
-      t[d] = acc;
+    const int cn = reverse ? c - 1 : c + 1;
+    const double zc = znext;
+    if (i + 1 < nchunks) znext = live ? zr[(size_t)cn * D + d] : 0.0;
+    double acc = zc;
+    const bool last = c == nchunks - 1;
+#pragma unroll
+    for (int e = 0; e < 2 * kMaxK; ++e) {
+      const double se = __shfl(s, (lane & 48) | e, 64);
+      acc += (last ? ml[e] : mf[e]) * se;
     }
-    for (int d = 0; d < D; ++d) { zc[d] = s[d]; s[d] = t[d]; }
+    if (live) zr[(size_t)c * D + d] = s;
+    s = acc;
+    c = cn;
   }
 }
 
@@ -312,7 +329,7 @@ int run_pass(xcx_ctx* ctx, float* x, long rows, long n, const SosParams& P,
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   double* Z = (double*)zbuf.ptr;
   HIP_TRY((launch_tiles<K, REV, false>(ctx, x, n, n, Lc, nchunks, nseq, P, nullptr, Z)));
-  hipLaunchKernelGGL(k_sos_scan, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, ctx->stream, Z, init,
+  hipLaunchKernelGGL(k_sos_scan, dim3((unsigned)((rows + 3) / 4)), dim3(64), 0, ctx->stream, Z, init,
                      (const double*)mbuf.ptr, (const double*)mbuf.ptr + D * D, D, nchunks, rows, (int)REV);
   HIP_TRY(hipGetLastError());
   // re-run from the true start states; end states land back in Z
@@ -328,12 +345,11 @@ int run_pass(xcx_ctx* ctx, float* x, long rows, long n, const SosParams& P,
 
 template <int K>
 int filt_impl(xcx_ctx* ctx, float* dx, long rows, long n, const SosParams& P, bool filtfilt) {
-  DevBuf zbuf, mbuf, zi_d, tail, init, fend;
+  // grow-only per-context workspaces (no allocation in the steady state)
+  DevBuf &zbuf = ctx->scratch[1], &mbuf = ctx->scratch[2], &zi_d = ctx->scratch[3],
+         &tail = ctx->scratch[4], &init = ctx->scratch[5], &fend = ctx->scratch[6];
   int rc = XCX_OK;
-  auto cleanup = [&]() {
-    (void)hipStreamSynchronize(ctx->stream);
-    zbuf.release(); mbuf.release(); zi_d.release(); tail.release(); init.release(); fend.release();
-  };
+  auto cleanup = [&]() {};
   if (!filtfilt) {
     rc = run_pass<K, false>(ctx, dx, rows, n, P, nullptr, nullptr, zbuf, mbuf);
     cleanup();

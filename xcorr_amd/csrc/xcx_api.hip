@@ -187,6 +187,7 @@ extern "C" int xcx_destroy(xcx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   xcx_comm_destroy(ctx);
+  for (auto& b : ctx->scratch) b.release();
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
   (void)hipStreamDestroy(ctx->stream);

@@ -3,13 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstddef>
 
-struct xcx_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  void* comm = nullptr;      // ncclComm_t
-  int nranks = 1, rank = 0;
-};
+struct xcx_ctx;
 
 namespace xcx {
 int set_err(int code, const char* fmt, ...);
@@ -21,3 +15,12 @@ struct DevBuf {
   void release();
 };
 }  // namespace xcx
+
+struct xcx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  void* comm = nullptr;      // ncclComm_t
+  int nranks = 1, rank = 0;
+  xcx::DevBuf scratch[8];    // grow-only workspaces of the row ops / filters
+};
