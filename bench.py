@@ -237,7 +237,8 @@ def main():
         res['pipeline_GBps'] = (P * W / (1e-3 * ev_ms / a.steps)) * b_pw / 1e9
         res['pipeline_frac_of_hbm_peak'] = res['pipeline_GBps'] / HBM_PEAK_GBS
         if kern:
-            dom = max(('k_pair_rows', 'k_pair_cols'), key=lambda k: kern[k]['avg_us'])
+            dom = max([k for k in ('k_pair_rows', 'k_pair_cols', 'k_pair_fused') if k in kern],
+                      key=lambda k: kern[k]['total_us'])
             B = kern[dom]['units_per_launch']
             ach = B * b_pw / (kern[dom]['avg_us'] * 1e-6) / 1e9
             traffic = None

@@ -1,0 +1,24 @@
+// wave_fused_inst.hip -- one instantiation of the fused XCD-local pair kernel.
+// Compile with -DXCX_FC_L=<N1> -DXCX_FC_R=<radices> -DXCX_FR_L=<N2h> -DXCX_FR_R=<radices>
+#include "wave_launch.h"
+
+namespace xcx {
+
+using RXC = Radices<XCX_FC_R>;
+using RXR = Radices<XCX_FR_R>;
+static_assert(RXC::L == XCX_FC_L && RXR::L == XCX_FR_L, "radices do not multiply to the length");
+
+#define XCX_CAT3_(a, b, c, d) a##b##c##d
+#define XCX_CAT3(a, b, c, d) XCX_CAT3_(a, b, c, d)
+
+hipError_t XCX_CAT3(launch_wfused_, XCX_FC_L, _, XCX_FR_L)(const WFusedArgs& a, int nblocks, hipStream_t s) {
+  constexpr size_t lc = sizeof(cf) * cpad_size(RXC::L), lr = sizeof(cf) * RXR::L * kWRB;
+  constexpr size_t lds = lc > lr ? lc : lr;
+  if (a.nstack > 1)
+    hipLaunchKernelGGL((k_wpair_fused<RXC, RXR, true>), dim3(nblocks), dim3(kWNT), lds, s, a);
+  else
+    hipLaunchKernelGGL((k_wpair_fused<RXC, RXR, false>), dim3(nblocks), dim3(kWNT), lds, s, a);
+  return hipGetLastError();
+}
+
+}  // namespace xcx

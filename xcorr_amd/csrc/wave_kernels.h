@@ -228,24 +228,17 @@ struct WI1Args {
   Geom g;
 };
 
+// column body shared by k_wpair_cols and the fused kernel: pair-window
+// descriptor d, column k2, T slot base `T`
 template <class RX, bool STACK>
-__global__ __launch_bounds__(kWNT) void k_wpair_cols(WI1Args a) {
-  extern __shared__ __attribute__((aligned(16))) cf lds[];
+XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_t spec_pitch,
+                           const PwDesc d, int nstack, int k2, cf* __restrict__ T,
+                           const cf* __restrict__ tw_sub, const cf* __restrict__ twN, const Geom& g) {
   constexpr int N1 = RX::L;
-  const Geom g = a.g;
   const int N2h = g.N2h;
-  const int x = blockIdx.x & 7;
-  const int q = blockIdx.x >> 3;
-  const int k2 = (q / a.B) * 8 + x;
-  const int pwl = q % a.B;
-  if (k2 > N2h) return;
-  const PwDesc d = a.pw[pwl];
-  const cf* __restrict__ A = a.X + (size_t)d.slot_a * a.spec_pitch + (size_t)k2 * N1;
-  const cf* __restrict__ Bp = a.X + (size_t)d.slot_b * a.spec_pitch + (size_t)k2 * N1;
-  const int nstack = a.nstack;
-  const unsigned sstride = (unsigned)a.spec_pitch;   // consecutive slots = consecutive windows
-  cf* __restrict__ T = a.T + (size_t)pwl * N1 * (N2h + 1);
-  const cf* __restrict__ twN = a.tw_N;
+  const cf* __restrict__ A = X + (size_t)d.slot_a * spec_pitch + (size_t)k2 * N1;
+  const cf* __restrict__ Bp = X + (size_t)d.slot_b * spec_pitch + (size_t)k2 * N1;
+  const unsigned sstride = (unsigned)spec_pitch;   // consecutive slots = consecutive windows
   const unsigned kk = (unsigned)k2;
   const int shift = g.shift;
   using CG = ColGeom<RX>;
@@ -284,7 +277,21 @@ __global__ __launch_bounds__(kWNT) void k_wpair_cols(WI1Args a) {
       Tc[(res >> 4) * trow + (res & 15)] = cmulc(v[t], f);
     });
   };
-  wave_col_fft<RX, true>(lds, a.tw_sub, in, epi);
+  wave_col_fft<RX, true>(lds, tw_sub, in, epi);
+}
+
+template <class RX, bool STACK>
+__global__ __launch_bounds__(kWNT) void k_wpair_cols(WI1Args a) {
+  extern __shared__ __attribute__((aligned(16))) cf lds[];
+  const Geom g = a.g;
+  const int N2h = g.N2h;
+  const int x = blockIdx.x & 7;
+  const int q = blockIdx.x >> 3;
+  const int k2 = (q / a.B) * 8 + x;
+  const int pwl = q % a.B;
+  if (k2 > N2h) return;
+  pair_col_body<RX, STACK>(lds, a.X, a.spec_pitch, a.pw[pwl], a.nstack, k2,
+                           a.T + (size_t)pwl * RX::L * (N2h + 1), a.tw_sub, a.tw_N, g);
 }
 
 // ---------------------------------------------------------------------------
@@ -298,26 +305,34 @@ struct WI2Args {
   Geom g;
 };
 
-template <class RX>
-__global__ __launch_bounds__(kWNT) void k_wpair_rows(WI2Args a) {
-  extern __shared__ __attribute__((aligned(16))) cf lds[];
+// T loads of the row body: plain, or sc1 (L1 bypass, served by the XCD's L2)
+// when the producer ran in the same launch on the same XCD (fused kernel)
+template <bool SC1> XCX_DEV cf load_t(const cf* p) {
+  if constexpr (SC1) {
+    const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
+  } else {
+    return *p;
+  }
+}
+
+// row body shared by k_wpair_rows and the fused kernel: tile `Tt` (16 rows,
+// N2h+1 slots), output row `out`, block index blk
+template <class RX, bool SC1>
+XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, float* __restrict__ out, int blk,
+                           const cf* __restrict__ tw_sub, const cf* __restrict__ twu, const Geom& g) {
   constexpr int N2h = RX::L;
   constexpr int R = RX::R0;
   constexpr int S = N2h / R;
   constexpr int NITEM = S / 2 + 1;
   constexpr int TOTAL = NITEM * kWRB;
   constexpr int IT = (TOTAL + kWNT - 1) / kWNT;
-  const Geom g = a.g;
   const int N1 = g.N1, N = g.N, n = g.n;
-  const int pwl = blockIdx.y;
-  const int blk = blockIdx.x;
-  const cf* __restrict__ Tt = a.T + ((size_t)pwl * (N1 / kWRB) + blk) * (size_t)(N2h + 1) * kWRB;
-  float* __restrict__ out = a.out + a.pw[pwl].out_off;
-  const cf* __restrict__ twu = a.tw_unt;
   const int lane = threadIdx.x;
   static_assert(RX::S == 2, "row configs have two stages");
   cf b1[StageGeom<N2h, RX::R1, RX::R0, kWRB, kWNT>::IT];
-  stage_tw_base<N2h, RX::R1, RX::R0, kWRB, kWNT>(a.tw_sub, b1);
+  stage_tw_base<N2h, RX::R1, RX::R0, kWRB, kWNT>(tw_sub, b1);
 
   // ---- stage 0: paired butterflies (j, S-j) with the Hermitian untangle ----
 #pragma unroll
@@ -330,13 +345,13 @@ __global__ __launch_bounds__(kWNT) void k_wpair_rows(WI2Args a) {
     const bool single = jp == j;
     cf av[R], bv[R];
 #pragma unroll
-    for (int t = 0; t < R; ++t) av[t] = Tt[(j + S * t) * kWRB + r];
+    for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(Tt + (j + S * t) * kWRB + r);
     if (!single) {
 #pragma unroll
-      for (int t = 0; t < R; ++t) bv[t] = Tt[(jp + S * t) * kWRB + r];
+      for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(Tt + (jp + S * t) * kWRB + r);
     } else if (j == 0) {
 #pragma unroll
-      for (int t = 0; t < R; ++t) bv[t] = av[(t + 1) % R];   // mirror of 15t' is 15(R-t')
+      for (int t = 0; t < R; ++t) bv[t] = av[(t + 1) % R];   // mirror of S*t' is S*(R-t')
     } else {
 #pragma unroll
       for (int t = 0; t < R; ++t) bv[t] = av[t];             // j = S/2 mirrors inside itself
@@ -361,7 +376,7 @@ __global__ __launch_bounds__(kWNT) void k_wpair_rows(WI2Args a) {
       }
     });
     if (j == 0) {                                  // DC and Nyquist of the row are real
-      const float dc = av[0].x, ny = Tt[N2h * kWRB + r].x;
+      const float dc = av[0].x, ny = load_t<SC1>(Tt + N2h * kWRB + r).x;
       uj[0] = make_float2(dc + ny, dc - ny);
     }
     Bfly<R, true>::run(uj);
@@ -374,7 +389,7 @@ __global__ __launch_bounds__(kWNT) void k_wpair_rows(WI2Args a) {
     }
   }
   __syncthreads();
-  // ---- remaining stages + output ---------------------------------------
+  // ---- second stage + output ---------------------------------------------
   const int idx_min = g.idx_min, idx_max = g.idx_max;
   const bool unbias = g.flags & XCX_F_UNBIAS;
   const int shift = g.shift;
@@ -392,12 +407,119 @@ __global__ __launch_bounds__(kWNT) void k_wpair_rows(WI2Args a) {
           const int lag = jj - (n - 1);
           v *= (float)n / (float)(n - (lag < 0 ? -lag : lag));
         }
-        out[jj - idx_min] = v;
+        if constexpr (SC1) __builtin_nontemporal_store(v, out + (jj - idx_min));
+        else out[jj - idx_min] = v;
       }
     }
   };
   auto lds_ld = [=](int p, int r) -> cf { return lds[p * kWRB + r]; };
   fft_stage_c<N2h, RX::R1, RX::R0, kWRB, kWNT, true, false, false>(b1, lds_ld, out_f);
+}
+
+template <class RX>
+__global__ __launch_bounds__(kWNT) void k_wpair_rows(WI2Args a) {
+  extern __shared__ __attribute__((aligned(16))) cf lds[];
+  const Geom g = a.g;
+  const int pwl = blockIdx.y, blk = blockIdx.x;
+  const cf* __restrict__ Tt = a.T + ((size_t)pwl * (g.N1 / kWRB) + blk) * (size_t)(RX::L + 1) * kWRB;
+  pair_row_body<RX, false>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, g);
+}
+
+// ---------------------------------------------------------------------------
+// Fused pair kernel: both passes of a pair-window run on ONE XCD so that the
+// intermediate T (1.5 MB) lives in that XCD's 4 MiB L2 and never makes the
+// round trip through HBM.  Persistent single-wave workgroups read their XCD
+// id (HW_REG_XCC_ID) and pull tickets from that XCD's queue.  XCD x owns the
+// pair-windows pw with (pw >> 3) & 7 == x (the 8 pairs of a station-tile row:
+// they share a station, so its columns are re-read from the same L2); its
+// k-th pair-window is pw(k) = ((k >> 3) << 6) | (x << 3) | (k & 7).
+// Ticket order per XCD:   C(0) C(1) R(0) C(2) R(1) C(3) R(2) ...
+// (C = N2h+1 column waves, R = N1/16 row waves).  A wave only ever waits for
+// tickets drawn before its own (R(k) for C(k); C(k) for R(k-3), whose T ring
+// slot it overwrites), and every drawn ticket is held by a running wave, so
+// progress never depends on residency or placement.  Same-XCD visibility:
+// producers' plain stores land in the shared L2 (s_waitcnt vmcnt(0) before
+// the completion count), consumers read T with sc1 loads that bypass the
+// CU-private L1.  Every spin is bounded; a timeout raises *err.
+// ---------------------------------------------------------------------------
+struct WFusedArgs {
+  const cf* X; size_t spec_pitch;
+  const PwDesc* pw; int B; int nstack;
+  cf* Tring;                 // [8][3][N1*(N2h+1)]
+  float* out;
+  const cf* tw_N1; const cf* tw_N2h; const cf* tw_unt; const cf* tw_N;
+  int* ticket;               // [8][32]: one counter per 128-byte line
+  int* cdone; int* rdone;    // [B]
+  int* err;
+  Geom g;
+};
+
+XCX_DEV void spin_until(const int* p, int target, int* err) {
+  for (int i = 0; i < 400000; ++i) {
+    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      return;
+    }
+    __builtin_amdgcn_s_sleep(16);
+  }
+  if (threadIdx.x == 0) *err = 1;
+}
+
+template <class RXC, class RXR, bool STACK>
+__global__ __launch_bounds__(kWNT) void k_wpair_fused(WFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) cf lds[];
+  const Geom g = a.g;
+  constexpr int N1 = RXC::L;
+  constexpr int N2h = RXR::L;
+  constexpr int NC = N2h + 1;            // column tickets per pair-window
+  constexpr int NR = N1 / kWRB;          // row tickets per pair-window
+  unsigned xcc;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  const int x = (int)(xcc & 7u);
+  // pair-windows of this XCD
+  const int B = a.B;
+  int rem = (B & 63) - 8 * x;
+  rem = rem < 0 ? 0 : (rem > 8 ? 8 : rem);
+  const int M = (B >> 6) * 8 + rem;
+  if (M == 0) return;
+  const int total = M * (NC + NR);
+  const size_t tslot = (size_t)N1 * NC;
+  cf* __restrict__ Tx = a.Tring + (size_t)x * 3 * tslot;
+  int* tick = a.ticket + x * 32;
+  for (;;) {
+    int t = 0;
+    if (threadIdx.x == 0) t = __hip_atomic_fetch_add(tick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t >= total) break;
+    // decode: C(0) | [C(g+1) R(g)] for g = 0..M-2 | R(M-1)
+    bool is_col; int k, sub;
+    if (t < NC) { is_col = true; k = 0; sub = t; }
+    else {
+      const int tt = t - NC;
+      const int grp = tt / (NC + NR), r = tt % (NC + NR);
+      if (grp >= M - 1) { is_col = false; k = M - 1; sub = tt - (M - 1) * (NC + NR); }
+      else if (r < NC) { is_col = true; k = grp + 1; sub = r; }
+      else { is_col = false; k = grp; sub = r - NC; }
+    }
+    const int pw = ((k >> 3) << 6) | (x << 3) | (k & 7);
+    cf* __restrict__ T = Tx + (size_t)(k % 3) * tslot;
+    if (is_col) {
+      if (k >= 3) {
+        const int kp = k - 3;
+        spin_until(a.rdone + (((kp >> 3) << 6) | (x << 3) | (kp & 7)), NR, a.err);
+      }
+      pair_col_body<RXC, STACK>(lds, a.X, a.spec_pitch, a.pw[pw], a.nstack, sub, T, a.tw_N1, a.tw_N, g);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // T stores are in L2
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(a.cdone + pw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      spin_until(a.cdone + pw, NC, a.err);
+      pair_row_body<RXR, true>(lds, T + (size_t)sub * NC * kWRB, a.out + a.pw[pw].out_off, sub,
+                               a.tw_N2h, a.tw_unt, g);
+      // all T loads of this wave have returned (their values were consumed)
+      if (threadIdx.x == 0) __hip_atomic_fetch_add(a.rdone + pw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+  }
 }
 
 }  // namespace xcx

@@ -58,6 +58,9 @@ static const WColEntry kWCols[] = {XCX_WCOL_LIST(XCX_WCOL_ROW)};
 static const WRowEntry kWRows[] = {XCX_WROW_LIST(XCX_WROW_ROW)};
 static const int kNWCols = sizeof(kWCols) / sizeof(kWCols[0]);
 static const int kNWRows = sizeof(kWRows) / sizeof(kWRows[0]);
+#define XCX_WFUSED_ROW(C, R) {C, R, launch_wfused_##C##_##R},
+static const WFusedEntry kWFused[] = {XCX_WFUSED_LIST(XCX_WFUSED_ROW)};
+static const int kNWFused = sizeof(kWFused) / sizeof(kWFused[0]);
 
 // ---------------------------------------------------------------------------
 // k_wstats: partial sums of a station-window, grid = (kStatParts, cnt).
@@ -303,6 +306,10 @@ struct xcx_plan {
   const WColEntry* wcol = nullptr;
   const WRowEntry* wrow = nullptr;
   bool wave = true;          // one-wave-per-workgroup engine (default)
+  const WFusedEntry* fused = nullptr;   // XCD-local fused pair kernel, if built for (N1, N2h)
+  DevBuf Tring, fsync;       // T ring [8][3][slot], ticket / completion counters
+  int fused_blocks = 0;
+  size_t fused_err_off = 0;  // index of the error flag inside fsync
   DevBuf psum, psq;          // partial statistics of a forward chunk
   int L = 0;                 // retained lags
   int batch = 64;            // pair-windows per launch batch
@@ -324,9 +331,9 @@ struct xcx_plan {
   std::vector<Ev> evs;
 };
 
-enum { KID_STATS = 0, KID_FWD_ROWS, KID_FWD_COLS, KID_PAIR_COLS, KID_PAIR_ROWS, KID_COUNT };
+enum { KID_STATS = 0, KID_FWD_ROWS, KID_FWD_COLS, KID_PAIR_COLS, KID_PAIR_ROWS, KID_PAIR_FUSED, KID_COUNT };
 static const char* kKernelNames[KID_COUNT] = {"k_stats", "k_fwd_rows", "k_fwd_cols",
-                                              "k_pair_cols", "k_pair_rows"};
+                                              "k_pair_cols", "k_pair_rows", "k_pair_fused"};
 
 struct ProfScope {
   xcx_plan* p; size_t idx; bool on;
@@ -410,6 +417,18 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
   g.N1 = wave ? kWCols[bi].L : kCols[bi].L;
   g.N2h = wave ? kWRows[bj].L : kRows[bj].L;
   g.N2 = 2 * g.N2h;
+  if (wave) {
+    // opt-in (XCX_FUSED=1): parity-green but not yet faster than the two-launch
+    // path -- waves that hold a row ticket spin while their columns finish
+    const char* fe = getenv("XCX_FUSED");
+    if (fe && strcmp(fe, "1") == 0)
+      for (int i = 0; i < kNWFused; ++i)
+        if (kWFused[i].N1 == g.N1 && kWFused[i].N2h == g.N2h) p->fused = &kWFused[i];
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
+      p->fused_blocks = prop.multiProcessorCount * 12;
+    else p->fused_blocks = 256 * 12;
+  }
   g.idx_min = idx_min;
   g.idx_max = idx_max;
   g.shift = (int)(((long long)n - 1 - idx_min) % g.N1);
@@ -446,7 +465,7 @@ extern "C" int xcx_plan_destroy(xcx_plan* p) {
   for (auto& e : p->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   DevBuf* bufs[] = {&p->tw_N1, &p->tw_N2h, &p->tw_unt, &p->tw_N, &p->stats,
                     &p->Tm_f, &p->Tn_f, &p->spectra, &p->T, &p->descs,
-                    &p->dtraces, &p->dout, &p->dpairs, &p->psum, &p->psq};
+                    &p->dtraces, &p->dout, &p->dpairs, &p->psum, &p->psq, &p->Tring, &p->fsync};
   for (DevBuf* b : bufs) b->release();
   delete p;
   return XCX_OK;
@@ -705,6 +724,52 @@ static int pair_batch(xcx_plan* p, size_t d0, int B, float* out, int nstack) {
   return XCX_OK;
 }
 
+// fused XCD-local pass over descriptors [d0, d0+B): one persistent launch
+static int pair_fused(xcx_plan* p, size_t d0, int B, float* out, int nstack) {
+  xcx_ctx* ctx = p->ctx;
+  const Geom& g = p->g;
+  const size_t tslot = (size_t)g.N1 * (g.N2h + 1);
+  int rc;
+  if ((rc = p->Tring.ensure(ctx, sizeof(cf) * tslot * 24))) return rc;
+  const size_t nsync = 8 * 32 + 2 * (size_t)B + 32;
+  if ((rc = p->fsync.ensure(ctx, sizeof(int) * nsync))) return rc;
+  HIP_TRY(hipMemsetAsync(p->fsync.ptr, 0, sizeof(int) * nsync, ctx->stream));
+  WFusedArgs a{};
+  a.X = (const cf*)p->spectra.ptr;
+  a.spec_pitch = p->spec_pitch;
+  a.pw = (const PwDesc*)p->descs.ptr + d0;
+  a.B = B;
+  a.nstack = nstack;
+  a.Tring = (cf*)p->Tring.ptr;
+  a.out = out;
+  a.tw_N1 = (const cf*)p->tw_N1.ptr;
+  a.tw_N2h = (const cf*)p->tw_N2h.ptr;
+  a.tw_unt = (const cf*)p->tw_unt.ptr;
+  a.tw_N = (const cf*)p->tw_N.ptr;
+  a.ticket = (int*)p->fsync.ptr;
+  a.cdone = a.ticket + 8 * 32;
+  a.rdone = a.cdone + B;
+  a.err = a.rdone + B;
+  p->fused_err_off = 8 * 32 + 2 * (size_t)B;
+  a.g = g;
+  {
+    ProfScope ps(p, KID_PAIR_FUSED, B);
+    HIP_TRY(p->fused->run(a, p->fused_blocks, ctx->stream));
+  }
+  p->launches += 1;
+  p->pair_windows += B;
+  return XCX_OK;
+}
+
+static int fused_check(xcx_plan* p) {
+  int err = 0;
+  HIP_TRY(hipMemcpyAsync(&err, (int*)p->fsync.ptr + p->fused_err_off, sizeof(int), hipMemcpyDeviceToHost,
+                         p->ctx->stream));
+  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
+  if (err) return set_err(XCX_EHIP, "fused pair kernel: a producer/consumer wait timed out");
+  return XCX_OK;
+}
+
 static unsigned long long fnv(const void* data, size_t bytes, unsigned long long h) {
   const unsigned char* c = (const unsigned char*)data;
   for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ULL; }
@@ -778,16 +843,27 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
   if (stack) {
     if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)S * W))) return rc;
     if ((rc = forward(p, dtr, stride_s, stride_w, W, 0, 0, S * W, 0))) return rc;
-    for (size_t d0 = 0; d0 < (size_t)P; d0 += B)
-      if ((rc = pair_batch(p, d0, (int)std::min((size_t)B, P - d0), dout, W))) return rc;
+    if (p->fused) {
+      if ((rc = pair_fused(p, 0, P, dout, W))) return rc;
+    } else {
+      for (size_t d0 = 0; d0 < (size_t)P; d0 += B)
+        if ((rc = pair_batch(p, d0, (int)std::min((size_t)B, P - d0), dout, W))) return rc;
+    }
   } else {
     if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)S))) return rc;
     for (int w = 0; w < W; ++w) {
       // one window of every station: sw = s*1 + 0 with window index w
       if ((rc = forward(p, dtr, stride_s, stride_w, 1, w, 0, S, 0))) return rc;
-      for (size_t q0 = 0; q0 < (size_t)P; q0 += B)
-        if ((rc = pair_batch(p, (size_t)w * P + q0, (int)std::min((size_t)B, P - q0), dout, 1))) return rc;
+      if (p->fused) {
+        if ((rc = pair_fused(p, (size_t)w * P, P, dout, 1))) return rc;
+      } else {
+        for (size_t q0 = 0; q0 < (size_t)P; q0 += B)
+          if ((rc = pair_batch(p, (size_t)w * P + q0, (int)std::min((size_t)B, P - q0), dout, 1))) return rc;
+      }
     }
+  }
+  if (p->fused && (!on_device || getenv("XCX_CHECK"))) {
+    if ((rc = fused_check(p))) return rc;
   }
   if (!on_device) {
     HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld_out * sizeof(float), dout, (size_t)ld_out * sizeof(float),
