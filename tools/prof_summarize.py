@@ -6,11 +6,15 @@ from collections import defaultdict
 out = sys.argv[1]
 summ = {}
 
+import re
 def short(name):
-    for k in ('k_pair_rows', 'k_pair_cols', 'k_fwd_rows', 'k_fwd_cols', 'k_stats', 'k_sos_tiles',
-              'k_sos_scan', 'k_row_reduce_apply', 'k_taper', 'k_sos_edges'):
-        if k in name:
-            return k
+    m = re.search(r'(k_[a-z0-9_]+)', name)
+    if m:
+        k = m.group(1)
+        # template variants that are distinct kernels in the trace
+        if 'k_sos_tiles' in k:
+            k += '_write' if ', true>' in name.replace('true, ', '', 0)[-12:] or name.rstrip().endswith('true>') else ''
+        return k
     return name[:60]
 
 # kernel stats
@@ -49,6 +53,11 @@ for k in set(fetch) | set(write):
               'fetch_kib_raw_avg': fetch.get(k, {}).get('avg'), 'write_kib_raw_avg': write.get(k, {}).get('avg')}
 summ['pmc'] = hbm
 json.dump(summ, open(os.path.join(out, 'summary.json'), 'w'), indent=1)
+# bench.py reads this (kernel ids as reported by xcx_plan_profile_read)
+alias = {'k_wpair_rows': 'k_pair_rows', 'k_wpair_cols': 'k_pair_cols', 'k_wpair_fused': 'k_pair_fused',
+         'k_wfwd_rows': 'k_fwd_rows', 'k_wfwd_cols': 'k_fwd_cols'}
+latest = {alias.get(k, k): v for k, v in hbm.items()}
+json.dump(latest, open(os.path.join(out, 'pmc_latest.json'), 'w'), indent=1)
 with open(os.path.join(out, 'summary.txt'), 'w') as fh:
     fh.write('kernel                 calls   avg_us     pct   fetch_MB(x2)  write_MB  (per launch)\n')
     for k, v in sorted(summ.get('kernel_stats', {}).items(), key=lambda kv: -kv[1]['total_ns']):
