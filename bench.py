@@ -89,6 +89,9 @@ def cpu_baseline(n, seconds):
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
+    # a one-GPU box owns a 16-core share of its host (more workers only
+    # oversubscribe it); override with XCX_CPU_CORES
+    cores = int(os.environ.get('XCX_CPU_CORES', min(cores, 16)))
     for v in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS'):
         os.environ[v] = '1'
     ctx = mp.get_context('spawn')
@@ -237,22 +240,36 @@ def main():
         res['pipeline_GBps'] = (P * W / (1e-3 * ev_ms / a.steps)) * b_pw / 1e9
         res['pipeline_frac_of_hbm_peak'] = res['pipeline_GBps'] / HBM_PEAK_GBS
         if kern:
-            dom = max([k for k in ('k_pair_rows', 'k_pair_cols', 'k_pair_fused') if k in kern],
-                      key=lambda k: kern[k]['total_us'])
+            # The inverse pass of a pair-window is two launches: k_pair_cols (I1)
+            # and k_pair_rows (I2).  I2 writes every algorithmic output byte and
+            # is the kernel the roofline is quoted for; `pass` prices the whole
+            # two-launch pass against the full algorithmic bytes per pair-window.
+            dom = 'k_pair_fused' if 'k_pair_fused' in kern else 'k_pair_rows'
+            names = [k for k in ('k_pair_cols', 'k_pair_rows', 'k_pair_fused') if k in kern]
             B = kern[dom]['units_per_launch']
-            ach = B * b_pw / (kern[dom]['avg_us'] * 1e-6) / 1e9
-            traffic = None
-            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_latest.json')
-            if os.path.exists(pmc):
+            pmc = {}
+            pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_latest.json')
+            if os.path.exists(pmc_path):
                 try:
-                    traffic = json.load(open(pmc)).get(dom, {}).get('hbm_bytes_per_launch')
+                    pmc = json.load(open(pmc_path))
                 except Exception:
-                    traffic = None
+                    pmc = {}
+            alg_dom = B * (b_pw if dom == 'k_pair_fused' else 4.0 * L)
+            ach = alg_dom / (kern[dom]['avg_us'] * 1e-6) / 1e9
+            pass_us = sum(kern[k]['avg_us'] * kern[k]['launches'] for k in names) / kern[dom]['launches']
+            pass_ach = B * b_pw / (pass_us * 1e-6) / 1e9
+            tr = [pmc.get(k, {}).get('hbm_bytes_per_launch') for k in names]
             res['roofline'] = {
                 'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS,
-                'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS, 'traffic': traffic,
+                'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
+                'traffic': pmc.get(dom, {}).get('hbm_bytes_per_launch'),
                 'avg_launch_us': kern[dom]['avg_us'], 'launches': kern[dom]['launches'],
-                'algorithmic_bytes_per_launch': B * b_pw,
+                'algorithmic_bytes_per_launch': alg_dom,
+                'pair_windows_per_launch': B,
+                'pass': {'kernels': names, 'us_per_launch_set': pass_us,
+                         'algorithmic_bytes': B * b_pw, 'achieved': pass_ach,
+                         'frac': pass_ach / HBM_PEAK_GBS,
+                         'traffic': (sum(tr) if all(t is not None for t in tr) else None)},
                 'kernels_us': {k: v['avg_us'] for k, v in kern.items()},
             }
         if not a.no_cpu_baseline:
