@@ -21,4 +21,17 @@ hipError_t XCX_CAT3(launch_wfused_, XCX_FC_L, _, XCX_FR_L)(const WFusedArgs& a, 
   return hipGetLastError();
 }
 
+hipError_t XCX_CAT3(launch_wdual_, XCX_FC_L, _, XCX_FR_L)(const WDualArgs& a, hipStream_t s) {
+  constexpr size_t lc = sizeof(cf) * cpad_size(RXC::L), lr = sizeof(cf) * RXR::L * kWRB;
+  constexpr size_t lds = lc > lr ? lc : lr;
+  constexpr int CPX = (RXR::L + 1 + 7) / 8, RPX = (RXC::L / kWRB + 7) / 8;
+  const int Bm = a.Bc > a.Br ? a.Bc : a.Br;
+  const dim3 grid(8u * (CPX + RPX) * Bm);
+  if (a.nstack > 1)
+    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, true>), grid, dim3(kWNT), lds, s, a);
+  else
+    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, false>), grid, dim3(kWNT), lds, s, a);
+  return hipGetLastError();
+}
+
 }  // namespace xcx

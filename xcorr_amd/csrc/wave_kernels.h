@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kWNT) void k_wpair_cols(WI1Args a) {
 // residues [16b, 16b+16): the T tile b, read exactly once.
 // ---------------------------------------------------------------------------
 struct WI2Args {
-  const cf* T; const PwDesc* pw; float* out;
+  const cf* T; const PwDesc* pw; float* out; float* trash;
   const cf* tw_sub;          // W_{N2h}
   const cf* tw_unt;          // W_{N2}[k]
   Geom g;
@@ -319,9 +319,10 @@ template <bool SC1> XCX_DEV cf load_t(const cf* p) {
 
 // row body shared by k_wpair_rows and the fused kernel: tile `Tt` (16 rows,
 // N2h+1 slots), output row `out`, block index blk
-template <class RX, bool SC1>
+template <class RX, bool SC1, bool UNBIAS>
 XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, float* __restrict__ out, int blk,
-                           const cf* __restrict__ tw_sub, const cf* __restrict__ twu, const Geom& g) {
+                           const cf* __restrict__ tw_sub, const cf* __restrict__ twu, float* __restrict__ trash,
+                           const Geom& g) {
   constexpr int N2h = RX::L;
   constexpr int R = RX::R0;
   constexpr int S = N2h / R;
@@ -390,26 +391,30 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
   }
   __syncthreads();
   // ---- second stage + output ---------------------------------------------
-  const int idx_min = g.idx_min, idx_max = g.idx_max;
-  const bool unbias = g.flags & XCX_F_UNBIAS;
+  // Branch-free stores: a lag outside [idx_min, idx_max) (the N-(2n-1) padding
+  // lags, or a clipped slice) is redirected to a per-lane trash word instead
+  // of masking the store, so the whole epilogue is one basic block.
+  const int idx_min = g.idx_min;
+  const unsigned Lout = (unsigned)(g.idx_max - g.idx_min);
   const int shift = g.shift;
-  auto out_f = [=](int m, int r, cf u) {
-    int m1 = blk * kWRB + r - shift;
-    if (m1 < 0) m1 += N1;
-    const int c0 = m1 + N1 * (2 * m);
+  int m1 = blk * kWRB + (lane & 15) - shift;
+  if (m1 < 0) m1 += N1;
+  const int base = m1 + (n - 1) - idx_min;        // output index of (m = 0, h = 0) before the wrap
+  float* __restrict__ trash_l = trash + lane;
+  auto out_f = [=](int m, int, cf u) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      int jj = c0 + h * N1 + (n - 1);
-      if (jj >= N) jj -= N;
-      if (jj >= idx_min && jj < idx_max) {
-        float v = h ? u.y : u.x;
-        if (unbias) {
-          const int lag = jj - (n - 1);
-          v *= (float)n / (float)(n - (lag < 0 ? -lag : lag));
-        }
-        if constexpr (SC1) __builtin_nontemporal_store(v, out + (jj - idx_min));
-        else out[jj - idx_min] = v;
+      int o = base + N1 * (2 * m + h);
+      if (o >= N - idx_min) o -= N;               // circular lag index
+      float v = h ? u.y : u.x;
+      if constexpr (UNBIAS) {
+        int lag = o + idx_min - (n - 1);
+        lag = lag < 0 ? -lag : lag;
+        v *= (float)n / (float)(n - lag);
       }
+      float* dst = ((unsigned)o < Lout) ? out + o : trash_l;
+      if constexpr (SC1) __builtin_nontemporal_store(v, dst);
+      else *dst = v;
     }
   };
   auto lds_ld = [=](int p, int r) -> cf { return lds[p * kWRB + r]; };
@@ -422,7 +427,10 @@ __global__ __launch_bounds__(kWNT) void k_wpair_rows(WI2Args a) {
   const Geom g = a.g;
   const int pwl = blockIdx.y, blk = blockIdx.x;
   const cf* __restrict__ Tt = a.T + ((size_t)pwl * (g.N1 / kWRB) + blk) * (size_t)(RX::L + 1) * kWRB;
-  pair_row_body<RX, false>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, g);
+  if (g.flags & XCX_F_UNBIAS)
+    pair_row_body<RX, false, true>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, a.trash, g);
+  else
+    pair_row_body<RX, false, false>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, a.trash, g);
 }
 
 // ---------------------------------------------------------------------------
@@ -450,7 +458,7 @@ struct WFusedArgs {
   const cf* tw_N1; const cf* tw_N2h; const cf* tw_unt; const cf* tw_N;
   int* ticket;               // [8][32]: one counter per 128-byte line
   int* cdone; int* rdone;    // [B]
-  int* err;
+  int* err; float* trash;
   Geom g;
 };
 
@@ -513,13 +521,65 @@ __global__ __launch_bounds__(kWNT) void k_wpair_fused(WFusedArgs a) {
       if (threadIdx.x == 0) __hip_atomic_fetch_add(a.cdone + pw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       spin_until(a.cdone + pw, NC, a.err);
-      pair_row_body<RXR, true>(lds, T + (size_t)sub * NC * kWRB, a.out + a.pw[pw].out_off, sub,
-                               a.tw_N2h, a.tw_unt, g);
+      if (g.flags & XCX_F_UNBIAS)
+        pair_row_body<RXR, true, true>(lds, T + (size_t)sub * NC * kWRB, a.out + a.pw[pw].out_off, sub,
+                                       a.tw_N2h, a.tw_unt, a.trash, g);
+      else
+        pair_row_body<RXR, true, false>(lds, T + (size_t)sub * NC * kWRB, a.out + a.pw[pw].out_off, sub,
+                                        a.tw_N2h, a.tw_unt, a.trash, g);
       // all T loads of this wave have returned (their values were consumed)
       if (threadIdx.x == 0) __hip_atomic_fetch_add(a.rdone + pw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
   }
+}
+
+// ---------------------------------------------------------------------------
+// Dual pair kernel: ONE launch runs the row pass (I2) of batch b-1 and the
+// column pass (I1) of batch b, interleaved per XCD in a 16:12 pattern, so the
+// VALU-bound column waves and the HBM-bound row waves share every CU.  No
+// dependency exists inside the launch (the rows read the T buffer the previous
+// launch wrote; the columns write the other one): no inter-wave wait anywhere.
+// ---------------------------------------------------------------------------
+struct WDualArgs {
+  const cf* X; size_t spec_pitch;
+  const PwDesc* pw_c; int Bc; int nstack; cf* Tc;       // column pass: batch b
+  const PwDesc* pw_r; int Br; const cf* Tr; float* out; float* trash; // row pass: batch b-1
+  const cf* tw_N1; const cf* tw_N2h; const cf* tw_unt; const cf* tw_N;
+  Geom g;
+};
+
+template <class RXC, class RXR, bool STACK>
+__global__ __launch_bounds__(kWNT) void k_wpair_dual(WDualArgs a) {
+  extern __shared__ __attribute__((aligned(16))) cf lds[];
+  const Geom g = a.g;
+  constexpr int N1 = RXC::L;
+  constexpr int N2h = RXR::L;
+  constexpr int NR = N1 / kWRB;            // row waves per pair-window
+  constexpr int CPX = (N2h + 1 + 7) / 8;   // column slots per XCD
+  constexpr int RPX = (NR + 7) / 8;        // row slots per XCD and pair-window
+  const int x = blockIdx.x & 7;
+  const int q = blockIdx.x >> 3;
+  const int Bm = a.Bc > a.Br ? a.Bc : a.Br;
+  const int c = q / (CPX + RPX), r = q % (CPX + RPX);
+  if (r < CPX) {
+    // column item ci = r*Bm + c: pair-window fastest for a fixed column
+    const int k2 = r * 8 + x;
+    const int pwl = c;
+    if (k2 > N2h || pwl >= a.Bc) return;
+    pair_col_body<RXC, STACK>(lds, a.X, a.spec_pitch, a.pw_c[pwl], a.nstack, k2,
+                              a.Tc + (size_t)pwl * N1 * (N2h + 1), a.tw_N1, a.tw_N, g);
+  } else {
+    const int blk = (r - CPX) * 8 + x;
+    const int pwl = c;
+    if (blk >= NR || pwl >= a.Br) return;
+    const cf* __restrict__ Tt = a.Tr + ((size_t)pwl * NR + blk) * (size_t)(N2h + 1) * kWRB;
+    if (g.flags & XCX_F_UNBIAS)
+      pair_row_body<RXR, false, true>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, a.trash, g);
+    else
+      pair_row_body<RXR, false, false>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, a.trash, g);
+  }
+  (void)Bm;
 }
 
 }  // namespace xcx

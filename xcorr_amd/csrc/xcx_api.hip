@@ -58,7 +58,7 @@ static const WColEntry kWCols[] = {XCX_WCOL_LIST(XCX_WCOL_ROW)};
 static const WRowEntry kWRows[] = {XCX_WROW_LIST(XCX_WROW_ROW)};
 static const int kNWCols = sizeof(kWCols) / sizeof(kWCols[0]);
 static const int kNWRows = sizeof(kWRows) / sizeof(kWRows[0]);
-#define XCX_WFUSED_ROW(C, R) {C, R, launch_wfused_##C##_##R},
+#define XCX_WFUSED_ROW(C, R) {C, R, launch_wfused_##C##_##R, launch_wdual_##C##_##R},
 static const WFusedEntry kWFused[] = {XCX_WFUSED_LIST(XCX_WFUSED_ROW)};
 static const int kNWFused = sizeof(kWFused) / sizeof(kWFused[0]);
 
@@ -308,7 +308,11 @@ struct xcx_plan {
   bool wave = true;          // one-wave-per-workgroup engine (default)
   const WFusedEntry* fused = nullptr;   // XCD-local fused pair kernel, if built for (N1, N2h)
   DevBuf Tring, fsync;       // T ring [8][3][slot], ticket / completion counters
+  DevBuf trash;              // 64 floats: sink of out-of-range lags (branch-free stores)
   int fused_blocks = 0;
+  const WFusedEntry* dual = nullptr;    // one-launch I2(b-1) + I1(b) kernel, if built for (N1, N2h)
+  // pending row pass of the dual pipeline
+  size_t dual_d0 = 0; int dual_B = 0; int dual_slot = 0; float* dual_out = nullptr;
   size_t fused_err_off = 0;  // index of the error flag inside fsync
   DevBuf psum, psq;          // partial statistics of a forward chunk
   int L = 0;                 // retained lags
@@ -418,12 +422,17 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
   g.N2h = wave ? kWRows[bj].L : kRows[bj].L;
   g.N2 = 2 * g.N2h;
   if (wave) {
+    if (p->trash.ensure(ctx, sizeof(float) * 64)) { delete p; return XCX_ENOMEM; }
     // opt-in (XCX_FUSED=1): parity-green but not yet faster than the two-launch
     // path -- waves that hold a row ticket spin while their columns finish
     const char* fe = getenv("XCX_FUSED");
     if (fe && strcmp(fe, "1") == 0)
       for (int i = 0; i < kNWFused; ++i)
         if (kWFused[i].N1 == g.N1 && kWFused[i].N2h == g.N2h) p->fused = &kWFused[i];
+    const char* de = getenv("XCX_DUAL");
+    if (!(de && strcmp(de, "0") == 0))
+      for (int i = 0; i < kNWFused; ++i)
+        if (kWFused[i].N1 == g.N1 && kWFused[i].N2h == g.N2h) p->dual = &kWFused[i];
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
       p->fused_blocks = prop.multiProcessorCount * 12;
@@ -465,7 +474,7 @@ extern "C" int xcx_plan_destroy(xcx_plan* p) {
   for (auto& e : p->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   DevBuf* bufs[] = {&p->tw_N1, &p->tw_N2h, &p->tw_unt, &p->tw_N, &p->stats,
                     &p->Tm_f, &p->Tn_f, &p->spectra, &p->T, &p->descs,
-                    &p->dtraces, &p->dout, &p->dpairs, &p->psum, &p->psq, &p->Tring, &p->fsync};
+                    &p->dtraces, &p->dout, &p->dpairs, &p->psum, &p->psq, &p->Tring, &p->fsync, &p->trash};
   for (DevBuf* b : bufs) b->release();
   delete p;
   return XCX_OK;
@@ -679,6 +688,7 @@ static int pair_batch(xcx_plan* p, size_t d0, int B, float* out, int nstack) {
     r.T = (const cf*)p->T.ptr;
     r.pw = a.pw;
     r.out = out;
+    r.trash = (float*)p->trash.ptr;
     r.tw_sub = (const cf*)p->tw_N2h.ptr;
     r.tw_unt = (const cf*)p->tw_unt.ptr;
     r.g = g;
@@ -724,6 +734,42 @@ static int pair_batch(xcx_plan* p, size_t d0, int B, float* out, int nstack) {
   return XCX_OK;
 }
 
+// Dual pipeline: dual_push(batch) launches [rows of the pending batch +
+// columns of this batch]; dual_flush() launches the rows of the last batch.
+// T holds two batch-sized buffers used alternately.
+static int dual_launch(xcx_plan* p, size_t d0, int Bc, int nstack, float* out) {
+  xcx_ctx* ctx = p->ctx;
+  const Geom& g = p->g;
+  const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
+  WDualArgs a{};
+  a.X = (const cf*)p->spectra.ptr;
+  a.spec_pitch = p->spec_pitch;
+  const int cs = p->dual_slot ^ 1;                  // slot written by this launch
+  a.pw_c = (const PwDesc*)p->descs.ptr + d0;
+  a.Bc = Bc;
+  a.nstack = nstack;
+  a.Tc = (cf*)p->T.ptr + (size_t)cs * tm_per * p->batch;
+  a.pw_r = (const PwDesc*)p->descs.ptr + p->dual_d0;
+  a.Br = p->dual_B;
+  a.Tr = (const cf*)p->T.ptr + (size_t)p->dual_slot * tm_per * p->batch;
+  a.out = p->dual_out ? p->dual_out : out;
+  a.trash = (float*)p->trash.ptr;
+  a.tw_N1 = (const cf*)p->tw_N1.ptr;
+  a.tw_N2h = (const cf*)p->tw_N2h.ptr;
+  a.tw_unt = (const cf*)p->tw_unt.ptr;
+  a.tw_N = (const cf*)p->tw_N.ptr;
+  a.g = g;
+  if (Bc == 0 && a.Br == 0) return XCX_OK;
+  {
+    ProfScope ps(p, KID_PAIR_FUSED, Bc > 0 ? Bc : a.Br);
+    HIP_TRY(p->dual->dual(a, ctx->stream));
+  }
+  p->launches += 1;
+  p->pair_windows += Bc;
+  p->dual_d0 = d0; p->dual_B = Bc; p->dual_slot = cs; p->dual_out = out;
+  return XCX_OK;
+}
+
 // fused XCD-local pass over descriptors [d0, d0+B): one persistent launch
 static int pair_fused(xcx_plan* p, size_t d0, int B, float* out, int nstack) {
   xcx_ctx* ctx = p->ctx;
@@ -750,6 +796,7 @@ static int pair_fused(xcx_plan* p, size_t d0, int B, float* out, int nstack) {
   a.cdone = a.ticket + 8 * 32;
   a.rdone = a.cdone + B;
   a.err = a.rdone + B;
+  a.trash = (float*)p->trash.ptr;
   p->fused_err_off = 8 * 32 + 2 * (size_t)B;
   a.g = g;
   {
@@ -839,7 +886,8 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
   }
   const int B = p->batch;
   const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
-  if ((rc = p->T.ensure(ctx, sizeof(cf) * tm_per * B))) return rc;
+  if ((rc = p->T.ensure(ctx, sizeof(cf) * tm_per * B * 2))) return rc;
+  p->dual_B = 0; p->dual_out = nullptr;
   if (stack) {
     if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)S * W))) return rc;
     if ((rc = forward(p, dtr, stride_s, stride_w, W, 0, 0, S * W, 0))) return rc;
@@ -856,11 +904,20 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
       if ((rc = forward(p, dtr, stride_s, stride_w, 1, w, 0, S, 0))) return rc;
       if (p->fused) {
         if ((rc = pair_fused(p, (size_t)w * P, P, dout, 1))) return rc;
+      } else if (p->dual) {
+        for (size_t q0 = 0; q0 < (size_t)P; q0 += B)
+          if ((rc = dual_launch(p, (size_t)w * P + q0, (int)std::min((size_t)B, P - q0), 1, dout))) return rc;
+        // the next window's forward transforms overwrite the spectra only
+        // after this window's last column pass; its row pass may trail
       } else {
         for (size_t q0 = 0; q0 < (size_t)P; q0 += B)
           if ((rc = pair_batch(p, (size_t)w * P + q0, (int)std::min((size_t)B, P - q0), dout, 1))) return rc;
       }
     }
+  }
+  if (p->dual && !p->fused) {
+    if ((rc = dual_launch(p, 0, 0, 1, dout))) return rc;      // drain: rows of the last batch
+    p->dual_B = 0; p->dual_out = nullptr;
   }
   if (p->fused && (!on_device || getenv("XCX_CHECK"))) {
     if ((rc = fused_check(p))) return rc;
