@@ -90,7 +90,7 @@ int xcx_plan_destroy(xcx_plan* plan);
  * ramps of width ftaper outside, 0 beyond. */
 int xcx_plan_set_whiten(xcx_plan* plan, double sampling_rate, double fmin,
                         double fmax, double ftaper);
-/* tuning: pair-windows per launch batch (default 64) */
+/* tuning: pair-windows per launch batch (default 512) */
 int xcx_plan_set_batch(xcx_plan* plan, int pair_windows_per_batch);
 /* out[0..5] = N, N1, N2, L (= idx_max-idx_min), batch, spectrum floats */
 int xcx_plan_info(xcx_plan* plan, int* out6);

@@ -115,6 +115,26 @@ template <int N, class F> XCX_DEV void static_for(F&& f) {
   static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+// thread index inside the cooperating group: the whole workgroup for the
+// 256-thread engine, the lane for the one-wave engine (whose workgroups may
+// pack several independent waves)
+template <int NT> XCX_DEV int tid_of() {
+  if constexpr (NT == 64) return (int)(threadIdx.x & 63u);
+  else return (int)threadIdx.x;
+}
+// group-wide sync: a real barrier for multi-wave groups; for a single wave
+// LDS instructions execute in program order, so only the compiler must be
+// kept from reordering them
+template <int NT> XCX_DEV void group_sync() {
+  if constexpr (NT == 64) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+
 // ---------------------------------------------------------------------------
 // radix butterflies, in place on a register array v[R]
 // ---------------------------------------------------------------------------
@@ -304,6 +324,8 @@ template <int L, int R, int NS, int NB, int NT> struct StageGeom {
   static constexpr int IT = (NBF + NT - 1) / NT;
   static constexpr bool GUARD = (NBF % NT) != 0;
   static constexpr int STEP = (NS > 1) ? L / (NS * R) : 0;
+  typedef cf Regs[IT][R];
+  typedef cf Base[IT];
 };
 
 template <int L, int R, int NS, int NB, int NT>
@@ -312,7 +334,7 @@ XCX_DEV void stage_tw_base(const cf* __restrict__ tw,
   using G = StageGeom<L, R, NS, NB, NT>;
 #pragma unroll
   for (int it = 0; it < G::IT; ++it) {
-    const int b = threadIdx.x + it * NT;
+    const int b = tid_of<NT>() + it * NT;
     const int j = (G::GUARD && b >= G::NBF) ? 0 : b / NB;
     base[it] = tw[(j % NS) * G::STEP];
   }
@@ -339,7 +361,7 @@ template <int L, int R, int NS, int NB, int NT, bool INV, bool SYNC, bool VEC_ST
           class LoadF, class StoreF>
 XCX_DEV void fft_stage_c(const cf (&base)[StageGeom<L, R, NS, NB, NT>::IT], LoadF ld, StoreF st) {
   using G = StageGeom<L, R, NS, NB, NT>;
-  const int tid = threadIdx.x;
+  const int tid = tid_of<NT>();
   cf v[G::IT][R];
 #pragma unroll
   for (int it = 0; it < G::IT; ++it) {
@@ -353,7 +375,7 @@ XCX_DEV void fft_stage_c(const cf (&base)[StageGeom<L, R, NS, NB, NT>::IT], Load
       Bfly<R, INV>::run(v[it]);
     }
   }
-  if constexpr (SYNC) __syncthreads();
+  if constexpr (SYNC) group_sync<NT>();
 #pragma unroll
   for (int it = 0; it < G::IT; ++it) {
     const int b = tid + it * NT;
@@ -368,6 +390,67 @@ XCX_DEV void fft_stage_c(const cf (&base)[StageGeom<L, R, NS, NB, NT>::IT], Load
 #pragma unroll
         for (int t = 0; t < R; ++t) st(j0 + t * NS, c, v[it][t]);
       }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Register-to-register stage exchange through a HALF-SIZE LDS buffer: the real
+// parts of all outputs of stage A are written (Stockham positions), read back
+// as the inputs of stage B, then the same for the imaginary parts.  The LDS
+// footprint of a wave is L*NB*4 bytes instead of L*NB*8, which doubles the
+// number of resident single-wave workgroups per CU (the kernels are LDS-
+// capacity limited, not LDS-bandwidth limited).  `idx(p, c)` maps (position,
+// sequence) to a float index of the LDS buffer.
+// ---------------------------------------------------------------------------
+template <int L, int RA, int NSA, int RB, int NB, int NT, class Idx>
+XCX_DEV void stage_exchange(float* __restrict__ ldsf, Idx idx,
+                            const typename StageGeom<L, RA, NSA, NB, NT>::Regs& src,
+                            typename StageGeom<L, RB, NSA * RA, NB, NT>::Regs& dst) {
+  using GA = StageGeom<L, RA, NSA, NB, NT>;
+  using GB = StageGeom<L, RB, NSA * RA, NB, NT>;
+  const int tid = tid_of<NT>();
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int it = 0; it < GA::IT; ++it) {
+      const int b = tid + it * NT;
+      if (!GA::GUARD || b < GA::NBF) {
+        const int c = b % NB, j = b / NB;
+        const int k = (NSA > 1) ? (j % NSA) : 0;
+        const int j0 = (j - k) * RA + k;
+#pragma unroll
+        for (int t = 0; t < RA; ++t)
+          ldsf[idx(j0 + t * NSA, c)] = half ? src[it][t].y : src[it][t].x;
+      }
+    }
+    group_sync<NT>();
+#pragma unroll
+    for (int it = 0; it < GB::IT; ++it) {
+      const int b = tid + it * NT;
+      if (!GB::GUARD || b < GB::NBF) {
+        const int c = b % NB, j = b / NB;
+#pragma unroll
+        for (int t = 0; t < RB; ++t) {
+          const float f = ldsf[idx(j + t * (L / RB), c)];
+          if (half) dst[it][t].y = f; else dst[it][t].x = f;
+        }
+      }
+    }
+    group_sync<NT>();
+  }
+}
+
+// twiddle (chain from the per-iteration base factor) + butterfly, in registers
+template <int L, int R, int NS, int NB, int NT, bool INV>
+XCX_DEV void stage_compute(typename StageGeom<L, R, NS, NB, NT>::Regs& v,
+                           const typename StageGeom<L, R, NS, NB, NT>::Base& base) {
+  using G = StageGeom<L, R, NS, NB, NT>;
+#pragma unroll
+  for (int it = 0; it < G::IT; ++it) {
+    if (!G::GUARD || (tid_of<NT>() + it * NT) < G::NBF) {
+      if constexpr (NS > 1) apply_tw_chain<R, INV>(v[it], base[it]);
+      Bfly<R, INV>::run(v[it]);
     }
   }
 }

@@ -12,25 +12,26 @@ static_assert(RXC::L == XCX_FC_L && RXR::L == XCX_FR_L, "radices do not multiply
 #define XCX_CAT3(a, b, c, d) XCX_CAT3_(a, b, c, d)
 
 hipError_t XCX_CAT3(launch_wfused_, XCX_FC_L, _, XCX_FR_L)(const WFusedArgs& a, int nblocks, hipStream_t s) {
-  constexpr size_t lc = sizeof(cf) * cpad_size(RXC::L), lr = sizeof(cf) * RXR::L * kWRB;
-  constexpr size_t lds = lc > lr ? lc : lr;
+  constexpr size_t lc = lds_col_floats(RXC::L), lr = lds_row_floats(RXR::L);
+  constexpr size_t lds = sizeof(float) * (lc > lr ? lc : lr) * kWPB;
+  nblocks = (nblocks + kWPB - 1) / kWPB;
   if (a.nstack > 1)
-    hipLaunchKernelGGL((k_wpair_fused<RXC, RXR, true>), dim3(nblocks), dim3(kWNT), lds, s, a);
+    hipLaunchKernelGGL((k_wpair_fused<RXC, RXR, true>), dim3(nblocks), dim3(kWNT * kWPB), lds, s, a);
   else
-    hipLaunchKernelGGL((k_wpair_fused<RXC, RXR, false>), dim3(nblocks), dim3(kWNT), lds, s, a);
+    hipLaunchKernelGGL((k_wpair_fused<RXC, RXR, false>), dim3(nblocks), dim3(kWNT * kWPB), lds, s, a);
   return hipGetLastError();
 }
 
 hipError_t XCX_CAT3(launch_wdual_, XCX_FC_L, _, XCX_FR_L)(const WDualArgs& a, hipStream_t s) {
-  constexpr size_t lc = sizeof(cf) * cpad_size(RXC::L), lr = sizeof(cf) * RXR::L * kWRB;
-  constexpr size_t lds = lc > lr ? lc : lr;
+  constexpr size_t lc = lds_col_floats(RXC::L), lr = lds_row_floats(RXR::L);
+  constexpr size_t lds = sizeof(float) * (lc > lr ? lc : lr) * kWPB;
   constexpr int CPX = (RXR::L + 1 + 7) / 8, RPX = (RXC::L / kWRB + 7) / 8;
   const int Bm = a.Bc > a.Br ? a.Bc : a.Br;
-  const dim3 grid(8u * (CPX + RPX) * Bm);
+  const dim3 grid(8u * (((CPX + RPX) * Bm + kWPB - 1) / kWPB));
   if (a.nstack > 1)
-    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, true>), grid, dim3(kWNT), lds, s, a);
+    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, true>), grid, dim3(kWNT * kWPB), lds, s, a);
   else
-    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, false>), grid, dim3(kWNT), lds, s, a);
+    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, false>), grid, dim3(kWNT * kWPB), lds, s, a);
   return hipGetLastError();
 }
 

@@ -10,27 +10,42 @@ static_assert(RX::L == XCX_INST_L, "radices do not multiply to the length");
 #define XCX_CAT2(a, b) a##b
 #define XCX_CAT(a, b) XCX_CAT2(a, b)
 
+template <class K> static hipError_t ensure_lds(K kernel, size_t bytes) {
+  if (bytes <= 32768) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
 #if XCX_INST_COL
-constexpr size_t kLds = sizeof(cf) * cpad_size(RX::L);
+constexpr size_t kLds = sizeof(float) * lds_col_floats(RX::L) * kWPB;
 hipError_t XCX_CAT(launch_wfwd_cols_, XCX_INST_L)(const WF2Args& a, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_wfwd_cols<RX>, grid, dim3(kWNT), kLds, s, a);
+  grid.x = (grid.x + kWPB - 1) / kWPB;
+  hipLaunchKernelGGL(k_wfwd_cols<RX>, grid, dim3(kWNT * kWPB), kLds, s, a);
   return hipGetLastError();
 }
 hipError_t XCX_CAT(launch_wpair_cols_, XCX_INST_L)(const WI1Args& a, dim3 grid, hipStream_t s) {
+  grid.x = 8u * ((grid.x / 8u + kWPB - 1) / kWPB);     // waves per XCD -> workgroups per XCD
   if (a.nstack > 1)
-    hipLaunchKernelGGL((k_wpair_cols<RX, true>), grid, dim3(kWNT), kLds, s, a);
+    hipLaunchKernelGGL((k_wpair_cols<RX, true>), grid, dim3(kWNT * kWPB), kLds, s, a);
   else
-    hipLaunchKernelGGL((k_wpair_cols<RX, false>), grid, dim3(kWNT), kLds, s, a);
+    hipLaunchKernelGGL((k_wpair_cols<RX, false>), grid, dim3(kWNT * kWPB), kLds, s, a);
   return hipGetLastError();
 }
 #else
-constexpr size_t kLds = sizeof(cf) * RX::L * kWRB;
+constexpr size_t kLdsF = sizeof(float) * lds_frow_floats(RX::L) * kWPB;   // forward rows keep full complex LDS
+constexpr size_t kLds = sizeof(float) * lds_row_floats(RX::L) * kWPB;
 hipError_t XCX_CAT(launch_wfwd_rows_, XCX_INST_L)(const WF1Args& a, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_wfwd_rows<RX>, grid, dim3(kWNT), kLds, s, a);
+  grid.x = (grid.x + kWPB - 1) / kWPB;
+  static hipError_t once = ensure_lds(k_wfwd_rows<RX>, kLdsF);
+  if (once != hipSuccess) return once;
+  hipLaunchKernelGGL(k_wfwd_rows<RX>, grid, dim3(kWNT * kWPB), kLdsF, s, a);
   return hipGetLastError();
 }
 hipError_t XCX_CAT(launch_wpair_rows_, XCX_INST_L)(const WI2Args& a, dim3 grid, hipStream_t s) {
-  hipLaunchKernelGGL(k_wpair_rows<RX>, grid, dim3(kWNT), kLds, s, a);
+  grid.x = (grid.x + kWPB - 1) / kWPB;
+  static hipError_t once = ensure_lds(k_wpair_rows<RX>, kLds);
+  if (once != hipSuccess) return once;
+  hipLaunchKernelGGL(k_wpair_rows<RX>, grid, dim3(kWNT * kWPB), kLds, s, a);
   return hipGetLastError();
 }
 #endif

@@ -28,13 +28,30 @@
 
 namespace xcx {
 
+// minimum waves per SIMD the register allocator must leave room for
+#ifndef XCX_COL_WAVES
+#define XCX_COL_WAVES 1
+#endif
+#ifndef XCX_ROW_WAVES
+#define XCX_ROW_WAVES 1
+#endif
 constexpr int kWRB = 16;     // rows per wave
 constexpr int kWNT = 64;     // one wave
+constexpr int kWPB = 4;      // independent waves packed into one 256-thread workgroup
+
+// per-wave LDS footprints (floats), 16-byte aligned
+constexpr int lds_col_floats(int L) { return (L + (L >> 3) + 1 + 3) & ~3; }
+constexpr int lds_row_floats(int L) { return ((L + (L >> 3) + 1) * 16 + 3) & ~3; }
+constexpr int lds_frow_floats(int L) { return L * 16 * 2; }
+XCX_DEV int wave_in_group() { return (int)(threadIdx.x >> 6); }
 
 // LDS index of column kernels: one 8-byte pad slot every 8 positions makes the
 // stride-R stores of the first Stockham stage bank-conflict free
 XCX_DEV int cpad(int p) { return p + (p >> 3); }
-constexpr int cpad_size(int L) { return L + (L >> 3) + 1; }
+constexpr int cpad_size(int L) { return L + (L >> 3) + 1; }   // elements (float or float2)
+// row kernels: [pos][16] with one 16-element pad row every 8 positions
+XCX_DEV int rpad(int p, int r) { return (p + (p >> 3)) * kWRB + r; }
+constexpr int rpad_size(int L) { return (L + (L >> 3) + 1) * kWRB; }
 
 // One-column complex FFT of length RX::L by one wave.  All twiddle base
 // factors are loaded before the first butterfly; after the input loads the
@@ -53,23 +70,51 @@ XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in
   constexpr int L = RX::L;
   constexpr int R0 = RX::R0, R1 = RX::R1, R2 = RX::R2;
   static_assert(RX::S == 2 || RX::S == 3, "column configs have two or three stages");
-  auto lds_ld = [=](int p, int) -> cf { return lds[cpad(p)]; };
-  auto lds_st = [=](int p, int, cf v) { lds[cpad(p)] = v; };
-  cf b0[StageGeom<L, R0, 1, 1, kWNT>::IT];
-  cf b1[StageGeom<L, R1, R0, 1, kWNT>::IT];
+  float* __restrict__ ldsf = reinterpret_cast<float*>(lds);
+  auto idx = [](int p, int) { return cpad(p); };
+  using G0 = StageGeom<L, R0, 1, 1, kWNT>;
+  using G1 = StageGeom<L, R1, R0, 1, kWNT>;
+  cf b1[G1::IT];
   stage_tw_base<L, R1, R0, 1, kWNT>(tw, b1);
+  cf v0[G0::IT][R0];
+#pragma unroll
+  for (int it = 0; it < G0::IT; ++it) {
+    const int j = tid_of<kWNT>() + it * kWNT;
+    if (!G0::GUARD || j < G0::NBF) {
+#pragma unroll
+      for (int t = 0; t < R0; ++t) v0[it][t] = in(j + t * (L / R0), 0);
+      Bfly<R0, INV>::run(v0[it]);
+    }
+  }
+  cf v1[G1::IT][R1];
   if constexpr (RX::S == 2) {
-    fft_stage_c<L, R0, 1, 1, kWNT, INV, false, false>(b0, in, lds_st);
-    __syncthreads();
-    fft_stage_c<L, R1, R0, 1, kWNT, INV, false, true>(b1, lds_ld, epi);
+    stage_exchange<L, R0, 1, R1, 1, kWNT>(ldsf, idx, v0, v1);
+    stage_compute<L, R1, R0, 1, kWNT, INV>(v1, b1);
+#pragma unroll
+    for (int it = 0; it < G1::IT; ++it) {
+      const int j = tid_of<kWNT>() + it * kWNT;
+      if (!G1::GUARD || j < G1::NBF) {
+        const int k = j % R0;
+        epi(it, (j - k) * R1 + k, 0, v1[it]);
+      }
+    }
   } else {
-    cf b2[StageGeom<L, R2, R0 * R1, 1, kWNT>::IT];
+    using G2 = StageGeom<L, R2, R0 * R1, 1, kWNT>;
+    cf b2[G2::IT];
     stage_tw_base<L, R2, R0 * R1, 1, kWNT>(tw, b2);
-    fft_stage_c<L, R0, 1, 1, kWNT, INV, false, false>(b0, in, lds_st);
-    __syncthreads();
-    fft_stage_c<L, R1, R0, 1, kWNT, INV, true, false>(b1, lds_ld, lds_st);
-    __syncthreads();
-    fft_stage_c<L, R2, R0 * R1, 1, kWNT, INV, false, true>(b2, lds_ld, epi);
+    stage_exchange<L, R0, 1, R1, 1, kWNT>(ldsf, idx, v0, v1);
+    stage_compute<L, R1, R0, 1, kWNT, INV>(v1, b1);
+    cf v2[G2::IT][R2];
+    stage_exchange<L, R1, R0, R2, 1, kWNT>(ldsf, idx, v1, v2);
+    stage_compute<L, R2, R0 * R1, 1, kWNT, INV>(v2, b2);
+#pragma unroll
+    for (int it = 0; it < G2::IT; ++it) {
+      const int j = tid_of<kWNT>() + it * kWNT;
+      if (!G2::GUARD || j < G2::NBF) {
+        const int k = j % (R0 * R1);
+        epi(it, (j - k) * R2 + k, 0, v2[it]);
+      }
+    }
   }
 }
 
@@ -112,14 +157,15 @@ struct WF1Args {
 };
 
 template <class RX>
-__global__ __launch_bounds__(kWNT) void k_wfwd_rows(WF1Args a) {
-  extern __shared__ __attribute__((aligned(16))) cf lds[];
+__global__ __launch_bounds__(kWNT * kWPB) void k_wfwd_rows(WF1Args a) {
+  extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   constexpr int N2h = RX::L;
   const Geom g = a.g;
+  cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave_in_group() * lds_frow_floats(N2h));
   const int sw = blockIdx.y;
   const int swg = a.sw0 + sw;
   const int s = swg / a.W, wl = swg % a.W;
-  const int row0 = blockIdx.x * kWRB;
+  const int row0 = (blockIdx.x * kWPB + wave_in_group()) * kWRB;
   const float* __restrict__ x = a.traces + (long)s * a.stride_s + (long)(a.w0 + wl) * a.stride_w;
   const int n = g.n, N1 = g.N1;
   const bool onebit = g.flags & XCX_F_ONEBIT;
@@ -145,11 +191,11 @@ __global__ __launch_bounds__(kWNT) void k_wfwd_rows(WF1Args a) {
   cf b1[StageGeom<N2h, RX::R1, RX::R0, kWRB, kWNT>::IT];
   stage_tw_base<N2h, RX::R1, RX::R0, kWRB, kWNT>(a.tw_sub, b1);
   fft_stage_c<N2h, RX::R0, 1, kWRB, kWNT, false, false, false>(b0, in, to_lds);
-  __syncthreads();
+  group_sync<kWNT>();
   fft_stage_c<N2h, RX::R1, RX::R0, kWRB, kWNT, false, true, false>(b1, lds_ld, to_lds);
-  __syncthreads();
+  group_sync<kWNT>();
   cf* __restrict__ Tf = a.Tf + (size_t)sw * (size_t)(N2h + 1) * N1;
-  for (int i = threadIdx.x; i < kWRB * N2h; i += kWNT) {
+  for (int i = tid_of<kWNT>(); i < kWRB * N2h; i += kWNT) {
     const int r = i % kWRB, k = i / kWRB;
     const int m1 = row0 + r;
     const cf u = lds[k * kWRB + r];
@@ -160,8 +206,8 @@ __global__ __launch_bounds__(kWNT) void k_wfwd_rows(WF1Args a) {
     H = cmul(H, twN_lookup(a.tw_N, (unsigned)m1 * (unsigned)k));
     Tf[k * N1 + m1] = H;
   }
-  if (threadIdx.x < kWRB) {
-    const int r = threadIdx.x, m1 = row0 + r;
+  if (tid_of<kWNT>() < kWRB) {
+    const int r = tid_of<kWNT>(), m1 = row0 + r;
     const cf u = lds[r];
     const float hn = u.x - u.y;
     const cf w = twN_lookup(a.tw_N, (unsigned)m1 * (unsigned)N2h);
@@ -182,13 +228,15 @@ struct WF2Args {
 };
 
 template <class RX>
-__global__ __launch_bounds__(kWNT) void k_wfwd_cols(WF2Args a) {
-  extern __shared__ __attribute__((aligned(16))) cf lds[];
+__global__ __launch_bounds__(kWNT * kWPB) void k_wfwd_cols(WF2Args a) {
+  extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   constexpr int N1 = RX::L;
   const Geom g = a.g;
   const int N2h = g.N2h, N2 = g.N2, N = g.N;
+  cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave_in_group() * lds_col_floats(N1));
   const int sw = blockIdx.y;
-  const int k2 = blockIdx.x;
+  const int k2 = blockIdx.x * kWPB + wave_in_group();
+  if (k2 > N2h) return;
   const float scale = sw_scale(a.psq, sw, N, g.flags, a.fixed_norm);
   const bool whiten = g.flags & XCX_F_WHITEN;
   const cf* __restrict__ src = a.Tf + ((size_t)sw * (N2h + 1) + k2) * N1;
@@ -247,14 +295,16 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
   cf f0[CG::Last::IT];
 #pragma unroll
   for (int it = 0; it < CG::Last::IT; ++it) {
-    const int b = threadIdx.x + it * kWNT;
+    const int b = tid_of<kWNT>() + it * kWNT;
     const int j = (CG::Last::GUARD && b >= CG::Last::NBF) ? 0 : b;
     const int k = j % CG::NSL;
     f0[it] = twN_lookup(twN, (unsigned)((j - k) * CG::RL + k) * kk);
   }
   const cf gstep = twN_lookup(twN, (unsigned)CG::NSL * kk);
+  const int lmask = (g.flags & XCX_F_DBG_NOLOAD) ? 255 : 0x7fffffff;
+  const int smask = (g.flags & XCX_F_DBG_NOSTORE) ? 255 : 0x7fffffff;
   auto in = [=](int k1, int) -> cf {
-    cf acc = cmulc(A[k1], Bp[k1]);
+    cf acc = cmulc(A[k1 & lmask], Bp[k1 & lmask]);
     if constexpr (STACK) {
       for (int w = 1; w < nstack; ++w)
         acc = cadd(acc, cmulc(A[k1 + w * sstride], Bp[k1 + w * sstride]));
@@ -274,19 +324,20 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
       }
       int res = j0 + t * CG::NSL + shift;
       if (res >= N1) res -= N1;
-      Tc[(res >> 4) * trow + (res & 15)] = cmulc(v[t], f);
+      Tc[((res >> 4) * trow + (res & 15)) & smask] = cmulc(v[t], f);
     });
   };
   wave_col_fft<RX, true>(lds, tw_sub, in, epi);
 }
 
 template <class RX, bool STACK>
-__global__ __launch_bounds__(kWNT) void k_wpair_cols(WI1Args a) {
-  extern __shared__ __attribute__((aligned(16))) cf lds[];
+__global__ __launch_bounds__(kWNT * kWPB) void k_wpair_cols(WI1Args a) {
+  extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   const Geom g = a.g;
   const int N2h = g.N2h;
+  cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave_in_group() * lds_col_floats(RX::L));
   const int x = blockIdx.x & 7;
-  const int q = blockIdx.x >> 3;
+  const int q = (blockIdx.x >> 3) * kWPB + wave_in_group();
   const int k2 = (q / a.B) * 8 + x;
   const int pwl = q % a.B;
   if (k2 > N2h) return;
@@ -330,12 +381,15 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
   constexpr int TOTAL = NITEM * kWRB;
   constexpr int IT = (TOTAL + kWNT - 1) / kWNT;
   const int N1 = g.N1, N = g.N, n = g.n;
-  const int lane = threadIdx.x;
+  const int lane = tid_of<kWNT>();
   static_assert(RX::S == 2, "row configs have two stages");
   cf b1[StageGeom<N2h, RX::R1, RX::R0, kWRB, kWNT>::IT];
   stage_tw_base<N2h, RX::R1, RX::R0, kWRB, kWNT>(tw_sub, b1);
+  const int lmask = (g.flags & XCX_F_DBG_NOLOAD) ? 255 : 0x7fffffff;
+  const bool nostore = g.flags & XCX_F_DBG_NOSTORE;
 
   // ---- stage 0: paired butterflies (j, S-j) with the Hermitian untangle ----
+  cf s0a[IT][R], s0b[IT][R];
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
     const int w = lane + it * kWNT;
@@ -346,10 +400,10 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
     const bool single = jp == j;
     cf av[R], bv[R];
 #pragma unroll
-    for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(Tt + (j + S * t) * kWRB + r);
+    for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(Tt + (((j + S * t) * kWRB + r) & lmask));
     if (!single) {
 #pragma unroll
-      for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(Tt + (jp + S * t) * kWRB + r);
+      for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(Tt + (((jp + S * t) * kWRB + r) & lmask));
     } else if (j == 0) {
 #pragma unroll
       for (int t = 0; t < R; ++t) bv[t] = av[(t + 1) % R];   // mirror of S*t' is S*(R-t')
@@ -381,15 +435,47 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
       uj[0] = make_float2(dc + ny, dc - ny);
     }
     Bfly<R, true>::run(uj);
+    if (!single) Bfly<R, true>::run(ujp);
+    // Stockham positions of stage 0 (NS = 1): butterfly j -> j*R + t; real and
+    // imaginary parts go through the half-size LDS buffer in two rounds below
 #pragma unroll
-    for (int t = 0; t < R; ++t) lds[(j * R + t) * kWRB + r] = uj[t];
-    if (!single) {
-      Bfly<R, true>::run(ujp);
-#pragma unroll
-      for (int t = 0; t < R; ++t) lds[(jp * R + t) * kWRB + r] = ujp[t];
-    }
+    for (int t = 0; t < R; ++t) { s0a[it][t] = uj[t]; s0b[it][t] = ujp[t]; }
   }
-  __syncthreads();
+  float* __restrict__ ldsf = reinterpret_cast<float*>(lds);
+  using G1 = StageGeom<N2h, RX::R1, RX::R0, kWRB, kWNT>;
+  cf v1[G1::IT][RX::R1];
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int w = lane + it * kWNT;
+      if ((TOTAL % kWNT) != 0 && w >= TOTAL) continue;
+      const int r = w % kWRB;
+      const int j = w / kWRB;
+      const int jp = (j == 0) ? 0 : (S - j);
+#pragma unroll
+      for (int t = 0; t < R; ++t) ldsf[rpad(j * R + t, r)] = half ? s0a[it][t].y : s0a[it][t].x;
+      if (jp != j) {
+#pragma unroll
+        for (int t = 0; t < R; ++t) ldsf[rpad(jp * R + t, r)] = half ? s0b[it][t].y : s0b[it][t].x;
+      }
+    }
+    group_sync<kWNT>();
+#pragma unroll
+    for (int it = 0; it < G1::IT; ++it) {
+      const int b = lane + it * kWNT;
+      if (!G1::GUARD || b < G1::NBF) {
+        const int c = b % kWRB, j = b / kWRB;
+#pragma unroll
+        for (int t = 0; t < RX::R1; ++t) {
+          const float f = ldsf[rpad(j + t * (N2h / RX::R1), c)];
+          if (half) v1[it][t].y = f; else v1[it][t].x = f;
+        }
+      }
+    }
+    group_sync<kWNT>();
+  }
+  stage_compute<N2h, RX::R1, RX::R0, kWRB, kWNT, true>(v1, b1);
   // ---- second stage + output ---------------------------------------------
   // Branch-free stores: a lag outside [idx_min, idx_max) (the N-(2n-1) padding
   // lags, or a clipped slice) is redirected to a per-lane trash word instead
@@ -412,20 +498,30 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
         lag = lag < 0 ? -lag : lag;
         v *= (float)n / (float)(n - lag);
       }
-      float* dst = ((unsigned)o < Lout) ? out + o : trash_l;
+      float* dst = ((unsigned)o < Lout && !nostore) ? out + o : trash_l;
       if constexpr (SC1) __builtin_nontemporal_store(v, dst);
       else *dst = v;
     }
   };
-  auto lds_ld = [=](int p, int r) -> cf { return lds[p * kWRB + r]; };
-  fft_stage_c<N2h, RX::R1, RX::R0, kWRB, kWNT, true, false, false>(b1, lds_ld, out_f);
+#pragma unroll
+  for (int it = 0; it < G1::IT; ++it) {
+    const int b = lane + it * kWNT;
+    if (!G1::GUARD || b < G1::NBF) {
+      const int j = b / kWRB;
+      const int k = j % RX::R0;
+      const int j0 = (j - k) * RX::R1 + k;
+#pragma unroll
+      for (int t = 0; t < RX::R1; ++t) out_f(j0 + t * RX::R0, 0, v1[it][t]);
+    }
+  }
 }
 
 template <class RX>
-__global__ __launch_bounds__(kWNT) void k_wpair_rows(WI2Args a) {
-  extern __shared__ __attribute__((aligned(16))) cf lds[];
+__global__ __launch_bounds__(kWNT * kWPB) void k_wpair_rows(WI2Args a) {
+  extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   const Geom g = a.g;
-  const int pwl = blockIdx.y, blk = blockIdx.x;
+  cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave_in_group() * lds_row_floats(RX::L));
+  const int pwl = blockIdx.y, blk = blockIdx.x * kWPB + wave_in_group();
   const cf* __restrict__ Tt = a.T + ((size_t)pwl * (g.N1 / kWRB) + blk) * (size_t)(RX::L + 1) * kWRB;
   if (g.flags & XCX_F_UNBIAS)
     pair_row_body<RX, false, true>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, a.trash, g);
@@ -470,15 +566,17 @@ XCX_DEV void spin_until(const int* p, int target, int* err) {
     }
     __builtin_amdgcn_s_sleep(16);
   }
-  if (threadIdx.x == 0) *err = 1;
+  if (tid_of<kWNT>() == 0) *err = 1;
 }
 
 template <class RXC, class RXR, bool STACK>
-__global__ __launch_bounds__(kWNT) void k_wpair_fused(WFusedArgs a) {
-  extern __shared__ __attribute__((aligned(16))) cf lds[];
+__global__ __launch_bounds__(kWNT * kWPB) void k_wpair_fused(WFusedArgs a) {
+  extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   const Geom g = a.g;
   constexpr int N1 = RXC::L;
   constexpr int N2h = RXR::L;
+  constexpr int kPerWave = lds_col_floats(N1) > lds_row_floats(N2h) ? lds_col_floats(N1) : lds_row_floats(N2h);
+  cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave_in_group() * kPerWave);
   constexpr int NC = N2h + 1;            // column tickets per pair-window
   constexpr int NR = N1 / kWRB;          // row tickets per pair-window
   unsigned xcc;
@@ -496,7 +594,7 @@ __global__ __launch_bounds__(kWNT) void k_wpair_fused(WFusedArgs a) {
   int* tick = a.ticket + x * 32;
   for (;;) {
     int t = 0;
-    if (threadIdx.x == 0) t = __hip_atomic_fetch_add(tick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid_of<kWNT>() == 0) t = __hip_atomic_fetch_add(tick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     t = __builtin_amdgcn_readfirstlane(t);
     if (t >= total) break;
     // decode: C(0) | [C(g+1) R(g)] for g = 0..M-2 | R(M-1)
@@ -518,7 +616,7 @@ __global__ __launch_bounds__(kWNT) void k_wpair_fused(WFusedArgs a) {
       }
       pair_col_body<RXC, STACK>(lds, a.X, a.spec_pitch, a.pw[pw], a.nstack, sub, T, a.tw_N1, a.tw_N, g);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // T stores are in L2
-      if (threadIdx.x == 0) __hip_atomic_fetch_add(a.cdone + pw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid_of<kWNT>() == 0) __hip_atomic_fetch_add(a.cdone + pw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       spin_until(a.cdone + pw, NC, a.err);
       if (g.flags & XCX_F_UNBIAS)
@@ -528,9 +626,9 @@ __global__ __launch_bounds__(kWNT) void k_wpair_fused(WFusedArgs a) {
         pair_row_body<RXR, true, false>(lds, T + (size_t)sub * NC * kWRB, a.out + a.pw[pw].out_off, sub,
                                         a.tw_N2h, a.tw_unt, a.trash, g);
       // all T loads of this wave have returned (their values were consumed)
-      if (threadIdx.x == 0) __hip_atomic_fetch_add(a.rdone + pw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid_of<kWNT>() == 0) __hip_atomic_fetch_add(a.rdone + pw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __syncthreads();
+    group_sync<kWNT>();
   }
 }
 
@@ -550,16 +648,18 @@ struct WDualArgs {
 };
 
 template <class RXC, class RXR, bool STACK>
-__global__ __launch_bounds__(kWNT) void k_wpair_dual(WDualArgs a) {
-  extern __shared__ __attribute__((aligned(16))) cf lds[];
+__global__ __launch_bounds__(kWNT * kWPB) void k_wpair_dual(WDualArgs a) {
+  extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   const Geom g = a.g;
   constexpr int N1 = RXC::L;
   constexpr int N2h = RXR::L;
   constexpr int NR = N1 / kWRB;            // row waves per pair-window
   constexpr int CPX = (N2h + 1 + 7) / 8;   // column slots per XCD
   constexpr int RPX = (NR + 7) / 8;        // row slots per XCD and pair-window
+  constexpr int kPerWave = lds_col_floats(N1) > lds_row_floats(N2h) ? lds_col_floats(N1) : lds_row_floats(N2h);
+  cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave_in_group() * kPerWave);
   const int x = blockIdx.x & 7;
-  const int q = blockIdx.x >> 3;
+  const int q = (blockIdx.x >> 3) * kWPB + wave_in_group();
   const int Bm = a.Bc > a.Br ? a.Bc : a.Br;
   const int c = q / (CPX + RPX), r = q % (CPX + RPX);
   if (r < CPX) {

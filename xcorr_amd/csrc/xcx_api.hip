@@ -316,7 +316,7 @@ struct xcx_plan {
   size_t fused_err_off = 0;  // index of the error flag inside fsync
   DevBuf psum, psq;          // partial statistics of a forward chunk
   int L = 0;                 // retained lags
-  int batch = 64;            // pair-windows per launch batch
+  int batch = 512;           // pair-windows per launch batch
   size_t spec_pitch = 0;     // float2 per spectrum slot
   // whitening
   float wb[4] = {0, 0, 0, 0};
@@ -442,7 +442,8 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
   g.idx_max = idx_max;
   g.shift = (int)(((long long)n - 1 - idx_min) % g.N1);
   if (g.shift < 0) g.shift += g.N1;
-  g.flags = flags;
+  g.flags = flags & 0xffff;
+  if (const char* dbg = getenv("XCX_DBG")) g.flags |= (atoi(dbg) & 3) << 16;
   p->L = idx_max - idx_min;
   size_t sp = (size_t)g.N1 * g.N2h + g.N1;
   p->spec_pitch = (sp + 15) / 16 * 16;
