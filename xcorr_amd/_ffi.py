@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'lib', 'libxcx.so')
+LIB_PATH = os.environ.get('XCX_LIB_PATH') or os.path.join(_HERE, 'lib', 'libxcx.so')   # override: A/B builds
 
 # plan flags (include/xcx.h)
 NORMALIZE, UNBIAS, STACK, ONEBIT, WHITEN, DEMEAN = 1, 2, 4, 8, 16, 32

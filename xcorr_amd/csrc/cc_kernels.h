@@ -41,9 +41,6 @@ enum : int {
   XCX_F_ONEBIT = 8,
   XCX_F_WHITEN = 16,
   XCX_F_DEMEAN = 32,
-  // timing-only diagnostics (XCX_DBG env, never set by the API): results are wrong
-  XCX_F_DBG_NOSTORE = 1 << 16,   // pair kernels: stores land in a tiny region
-  XCX_F_DBG_NOLOAD = 1 << 17,    // pair kernels: loads hit a tiny region
 };
 
 struct Geom {

@@ -1,5 +1,7 @@
 // wave_fused_inst.hip -- one instantiation of the fused XCD-local pair kernel.
 // Compile with -DXCX_FC_L=<N1> -DXCX_FC_R=<radices> -DXCX_FR_L=<N2h> -DXCX_FR_R=<radices>
+#include <algorithm>
+#include <cstdlib>
 #include "wave_launch.h"
 
 namespace xcx {
@@ -28,10 +30,20 @@ hipError_t XCX_CAT3(launch_wdual_, XCX_FC_L, _, XCX_FR_L)(const WDualArgs& a, hi
   constexpr int CPX = (RXR::L + 1 + 7) / 8, RPX = (RXC::L / kWRB + 7) / 8;
   const int Bm = a.Bc > a.Br ? a.Bc : a.Br;
   const dim3 grid(8u * (((CPX + RPX) * Bm + kWPB - 1) / kWPB));
+  // occupancy knob: pad the LDS request so that at most `wgs` workgroups share a CU
+  static const int wgs = getenv("XCX_DUAL_WGS") ? atoi(getenv("XCX_DUAL_WGS")) : 0;
+  size_t lds_req = lds;
+  if (wgs > 0) {
+    lds_req = std::max(lds, (size_t)(160 * 1024 / wgs) & ~(size_t)255);
+    static hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wpair_dual<RXC, RXR, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wpair_dual<RXC, RXR, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e1 != hipSuccess) return e1;
+    if (e2 != hipSuccess) return e2;
+  }
   if (a.nstack > 1)
-    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, true>), grid, dim3(kWNT * kWPB), lds, s, a);
+    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, true>), grid, dim3(kWNT * kWPB), lds_req, s, a);
   else
-    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, false>), grid, dim3(kWNT * kWPB), lds, s, a);
+    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, false>), grid, dim3(kWNT * kWPB), lds_req, s, a);
   return hipGetLastError();
 }
 

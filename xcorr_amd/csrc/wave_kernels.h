@@ -301,10 +301,8 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
     f0[it] = twN_lookup(twN, (unsigned)((j - k) * CG::RL + k) * kk);
   }
   const cf gstep = twN_lookup(twN, (unsigned)CG::NSL * kk);
-  const int lmask = (g.flags & XCX_F_DBG_NOLOAD) ? 255 : 0x7fffffff;
-  const int smask = (g.flags & XCX_F_DBG_NOSTORE) ? 255 : 0x7fffffff;
   auto in = [=](int k1, int) -> cf {
-    cf acc = cmulc(A[k1 & lmask], Bp[k1 & lmask]);
+    cf acc = cmulc(A[k1], Bp[k1]);
     if constexpr (STACK) {
       for (int w = 1; w < nstack; ++w)
         acc = cadd(acc, cmulc(A[k1 + w * sstride], Bp[k1 + w * sstride]));
@@ -324,7 +322,7 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
       }
       int res = j0 + t * CG::NSL + shift;
       if (res >= N1) res -= N1;
-      Tc[((res >> 4) * trow + (res & 15)) & smask] = cmulc(v[t], f);
+      Tc[(res >> 4) * trow + (res & 15)] = cmulc(v[t], f);
     });
   };
   wave_col_fft<RX, true>(lds, tw_sub, in, epi);
@@ -385,8 +383,6 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
   static_assert(RX::S == 2, "row configs have two stages");
   cf b1[StageGeom<N2h, RX::R1, RX::R0, kWRB, kWNT>::IT];
   stage_tw_base<N2h, RX::R1, RX::R0, kWRB, kWNT>(tw_sub, b1);
-  const int lmask = (g.flags & XCX_F_DBG_NOLOAD) ? 255 : 0x7fffffff;
-  const bool nostore = g.flags & XCX_F_DBG_NOSTORE;
 
   // ---- stage 0: paired butterflies (j, S-j) with the Hermitian untangle ----
   cf s0a[IT][R], s0b[IT][R];
@@ -400,10 +396,10 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
     const bool single = jp == j;
     cf av[R], bv[R];
 #pragma unroll
-    for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(Tt + (((j + S * t) * kWRB + r) & lmask));
+    for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(Tt + (j + S * t) * kWRB + r);
     if (!single) {
 #pragma unroll
-      for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(Tt + (((jp + S * t) * kWRB + r) & lmask));
+      for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(Tt + (jp + S * t) * kWRB + r);
     } else if (j == 0) {
 #pragma unroll
       for (int t = 0; t < R; ++t) bv[t] = av[(t + 1) % R];   // mirror of S*t' is S*(R-t')
@@ -411,24 +407,20 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
 #pragma unroll
       for (int t = 0; t < R; ++t) bv[t] = av[t];             // j = S/2 mirrors inside itself
     }
-    // e^{+2 pi i (j + S t)/N2} = conj(twu[j]) * e^{+2 pi i t/(2R)}
+    // Hermitian untangle, shared by the pair: with h = H[k] (k = j + S t),
+    // g = H[N2h-k] = bv[R-1-t], e = e^{+2 pi i k/N2} = conj(twu[j]) e^{+2 pi i t/(2R)}
+    //   sm = h + conj g,  ed = e (h - conj g)
+    //   U_j [t]     = sm + i ed
+    //   U_j'[R-1-t] = conj(sm) + i conj(ed)      (because e_{N2h-k} = -conj e_k)
     const cf ej = cconj(twu[j]);
-    const cf ejp = cconj(twu[jp]);
     cf uj[R], ujp[R];
     static_for<R>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
-      {
-        const cf h = av[t], hb = cconj(bv[R - 1 - t]);
-        const cf sm = cadd(h, hb), df = csub(h, hb);
-        const cf e = cmul(mul_wconst<t, 2 * R, true>(ej), df);
-        uj[t] = make_float2(sm.x - e.y, sm.y + e.x);
-      }
-      {
-        const cf h = bv[t], hb = cconj(av[R - 1 - t]);
-        const cf sm = cadd(h, hb), df = csub(h, hb);
-        const cf e = cmul(mul_wconst<t, 2 * R, true>(ejp), df);
-        ujp[t] = make_float2(sm.x - e.y, sm.y + e.x);
-      }
+      const cf h = av[t], hb = cconj(bv[R - 1 - t]);
+      const cf sm = cadd(h, hb), df = csub(h, hb);
+      const cf ed = cmul(mul_wconst<t, 2 * R, true>(ej), df);
+      uj[t] = make_float2(sm.x - ed.y, sm.y + ed.x);
+      ujp[R - 1 - t] = make_float2(sm.x + ed.y, ed.x - sm.y);
     });
     if (j == 0) {                                  // DC and Nyquist of the row are real
       const float dc = av[0].x, ny = load_t<SC1>(Tt + N2h * kWRB + r).x;
@@ -498,7 +490,7 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
         lag = lag < 0 ? -lag : lag;
         v *= (float)n / (float)(n - lag);
       }
-      float* dst = ((unsigned)o < Lout && !nostore) ? out + o : trash_l;
+      float* dst = ((unsigned)o < Lout) ? out + o : trash_l;
       if constexpr (SC1) __builtin_nontemporal_store(v, dst);
       else *dst = v;
     }
@@ -647,8 +639,12 @@ struct WDualArgs {
   Geom g;
 };
 
+#ifndef XCX_DUAL_WAVES
+#define XCX_DUAL_WAVES 3
+#endif
 template <class RXC, class RXR, bool STACK>
-__global__ __launch_bounds__(kWNT * kWPB) void k_wpair_dual(WDualArgs a) {
+__global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(XCX_DUAL_WAVES, XCX_DUAL_WAVES)))
+void k_wpair_dual(WDualArgs a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   const Geom g = a.g;
   constexpr int N1 = RXC::L;

@@ -443,7 +443,6 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
   g.shift = (int)(((long long)n - 1 - idx_min) % g.N1);
   if (g.shift < 0) g.shift += g.N1;
   g.flags = flags & 0xffff;
-  if (const char* dbg = getenv("XCX_DBG")) g.flags |= (atoi(dbg) & 3) << 16;
   p->L = idx_max - idx_min;
   size_t sp = (size_t)g.N1 * g.N2h + g.N1;
   p->spec_pitch = (sp + 15) / 16 * 16;
