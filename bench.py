@@ -128,7 +128,11 @@ def main():
     import xcorr_amd as X
     from xcorr_amd import _ffi
     from xcorr_amd import ops
-    ctx = X.Context(local)
+    import ctypes as _C
+    ndev = _C.c_int(0)
+    _ffi.check(_ffi.lib().xcx_device_count(_C.byref(ndev)))
+    # one rank per GPU; the modulo only matters when rehearsing N ranks on a smaller box
+    ctx = X.Context(local % max(ndev.value, 1))
 
     S = a.stations
     T = int(round(a.seconds * FS))
@@ -244,8 +248,8 @@ def main():
             # and k_pair_rows (I2).  I2 writes every algorithmic output byte and
             # is the kernel the roofline is quoted for; `pass` prices the whole
             # two-launch pass against the full algorithmic bytes per pair-window.
-            dom = 'k_pair_fused' if 'k_pair_fused' in kern else 'k_pair_rows'
-            names = [k for k in ('k_pair_cols', 'k_pair_rows', 'k_pair_fused') if k in kern]
+            dom = 'k_pair_dual' if 'k_pair_dual' in kern else 'k_pair_rows'
+            names = [k for k in ('k_pair_cols', 'k_pair_rows', 'k_pair_dual') if k in kern]
             B = kern[dom]['units_per_launch']
             pmc = {}
             pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_latest.json')
@@ -254,7 +258,7 @@ def main():
                     pmc = json.load(open(pmc_path))
                 except Exception:
                     pmc = {}
-            alg_dom = B * (b_pw if dom == 'k_pair_fused' else 4.0 * L)
+            alg_dom = B * (b_pw if dom == 'k_pair_dual' else 4.0 * L)
             ach = alg_dom / (kern[dom]['avg_us'] * 1e-6) / 1e9
             pass_us = sum(kern[k]['avg_us'] * kern[k]['launches'] for k in names) / kern[dom]['launches']
             pass_ach = B * b_pw / (pass_us * 1e-6) / 1e9

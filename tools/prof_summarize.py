@@ -54,7 +54,7 @@ for k in set(fetch) | set(write):
 summ['pmc'] = hbm
 json.dump(summ, open(os.path.join(out, 'summary.json'), 'w'), indent=1)
 # bench.py reads this (kernel ids as reported by xcx_plan_profile_read)
-alias = {'k_wpair_rows': 'k_pair_rows', 'k_wpair_cols': 'k_pair_cols', 'k_wpair_fused': 'k_pair_fused',
+alias = {'k_wpair_rows': 'k_pair_rows', 'k_wpair_cols': 'k_pair_cols', 'k_wpair_fused': 'k_pair_dual', 'k_wpair_dual': 'k_pair_dual',
          'k_wfwd_rows': 'k_fwd_rows', 'k_wfwd_cols': 'k_fwd_cols'}
 latest = {alias.get(k, k): v for k, v in hbm.items()}
 json.dump(latest, open(os.path.join(out, 'pmc_latest.json'), 'w'), indent=1)

@@ -657,17 +657,21 @@ void k_wpair_dual(WDualArgs a) {
   const int x = blockIdx.x & 7;
   const int q = (blockIdx.x >> 3) * kWPB + wave_in_group();
   const int Bm = a.Bc > a.Br ? a.Bc : a.Br;
-  const int c = q / (CPX + RPX), r = q % (CPX + RPX);
-  if (r < CPX) {
-    // column item ci = r*Bm + c: pair-window fastest for a fixed column
-    const int k2 = r * 8 + x;
-    const int pwl = c;
+  // per-XCD work sequence: CPX*Bm column items (column-major: all pair-windows
+  // of one column k2 back to back, so a station column stays in this XCD's L2
+  // for the 8 pairs of its tile) interleaved CPX:RPX with RPX*Bm row items
+  const int grp = q / (CPX + RPX), pos = q % (CPX + RPX);
+  if (pos < CPX) {
+    const int ci = grp * CPX + pos;
+    const int k2 = (ci / Bm) * 8 + x;
+    const int pwl = ci % Bm;
     if (k2 > N2h || pwl >= a.Bc) return;
     pair_col_body<RXC, STACK>(lds, a.X, a.spec_pitch, a.pw_c[pwl], a.nstack, k2,
                               a.Tc + (size_t)pwl * N1 * (N2h + 1), a.tw_N1, a.tw_N, g);
   } else {
-    const int blk = (r - CPX) * 8 + x;
-    const int pwl = c;
+    const int ri = grp * RPX + (pos - CPX);
+    const int pwl = ri / RPX;
+    const int blk = (ri % RPX) * 8 + x;
     if (blk >= NR || pwl >= a.Br) return;
     const cf* __restrict__ Tt = a.Tr + ((size_t)pwl * NR + blk) * (size_t)(N2h + 1) * kWRB;
     if (g.flags & XCX_F_UNBIAS)
@@ -675,7 +679,6 @@ void k_wpair_dual(WDualArgs a) {
     else
       pair_row_body<RXR, false, false>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, a.trash, g);
   }
-  (void)Bm;
 }
 
 }  // namespace xcx

@@ -337,7 +337,7 @@ struct xcx_plan {
 
 enum { KID_STATS = 0, KID_FWD_ROWS, KID_FWD_COLS, KID_PAIR_COLS, KID_PAIR_ROWS, KID_PAIR_FUSED, KID_COUNT };
 static const char* kKernelNames[KID_COUNT] = {"k_stats", "k_fwd_rows", "k_fwd_cols",
-                                              "k_pair_cols", "k_pair_rows", "k_pair_fused"};
+                                              "k_pair_cols", "k_pair_rows", "k_pair_dual"};
 
 struct ProfScope {
   xcx_plan* p; size_t idx; bool on;
