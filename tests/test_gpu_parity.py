@@ -268,3 +268,39 @@ def test_baseline_config_checksum(ctx):
         b = t64[j, w * hop:w * hop + n]
         ref = R.cc_fair(a - a.mean(), b - b.mean(), dtype=np.float64)
         assert relerr(got[p, w], ref) < TOL
+
+
+@pytest.mark.parametrize('env', [{'XCX_DUAL': '0'}, {'XCX_FUSED': '1'}, {'XCX_ENGINE': 'wg'}],
+                         ids=['two-launch', 'fused-xcd', 'workgroup-engine'])
+def test_alternative_engines_agree(ctx, env, monkeypatch):
+    """The alternative kernel paths (separate I1/I2 launches, the XCD-local
+    fused kernel, the first-generation 256-thread engine) stay parity-green."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv('XCX_CHECK', '1')
+    S, n, hop, W = 6, 3000, 1500, 3
+    tr = R.synthetic_traces(S, hop * (W - 1) + n)
+    pairs = R.all_pairs(S)
+    ref = R.cc_pairs(tr, pairs, n, hop, dtype=np.float64)
+    plan = X.CCPlan(ctx, n, batch=4)
+    got = plan.pairs(tr, pairs, W, hop)
+    assert relerr(got, ref) < TOL
+    st = X.CCPlan(ctx, n, stack=True).pairs(tr, pairs, W, hop)
+    assert relerr(st, ref.sum(axis=1)) < TOL
+    plan.close()
+
+
+def test_rccl_stack_reduce_single_rank(ctx):
+    """RCCL communicator on one rank: init from a unique id, all-reduce and
+    reduce-scatter of a partial stack are identities."""
+    uid = X.Context.comm_unique_id()
+    assert len(uid) == 128
+    ctx.comm_init(uid, 1, 0)
+    a = np.arange(4096, dtype=np.float32).reshape(4, 1024)
+    d = ctx.array(a)
+    ctx.stack_reduce(d)
+    ctx.sync()
+    np.testing.assert_array_equal(d.to_host(), a)
+    ctx.stack_reduce(d, reduce_scatter=True)
+    ctx.sync()
+    np.testing.assert_array_equal(d.to_host(), a)

@@ -655,8 +655,12 @@ void k_wpair_dual(WDualArgs a) {
   constexpr int kPerWave = lds_col_floats(N1) > lds_row_floats(N2h) ? lds_col_floats(N1) : lds_row_floats(N2h);
   cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave_in_group() * kPerWave);
   const int x = blockIdx.x & 7;
-  const int q = (blockIdx.x >> 3) * kWPB + wave_in_group();
   const int Bm = a.Bc > a.Br ? a.Bc : a.Br;
+  // persistent waves: the grid is sized to what the chip holds (a.nwg_xcd
+  // workgroups per XCD); every wave strides through its XCD's work sequence
+  const int qtot = (CPX + RPX) * Bm;
+  const int stride = (int)(gridDim.x >> 3) * kWPB;
+  for (int q = (blockIdx.x >> 3) * kWPB + wave_in_group(); q < qtot; q += stride) {
   // per-XCD work sequence: CPX*Bm column items (column-major: all pair-windows
   // of one column k2 back to back, so a station column stays in this XCD's L2
   // for the 8 pairs of its tile) interleaved CPX:RPX with RPX*Bm row items
@@ -665,19 +669,20 @@ void k_wpair_dual(WDualArgs a) {
     const int ci = grp * CPX + pos;
     const int k2 = (ci / Bm) * 8 + x;
     const int pwl = ci % Bm;
-    if (k2 > N2h || pwl >= a.Bc) return;
+    if (k2 > N2h || pwl >= a.Bc) continue;
     pair_col_body<RXC, STACK>(lds, a.X, a.spec_pitch, a.pw_c[pwl], a.nstack, k2,
                               a.Tc + (size_t)pwl * N1 * (N2h + 1), a.tw_N1, a.tw_N, g);
   } else {
     const int ri = grp * RPX + (pos - CPX);
     const int pwl = ri / RPX;
     const int blk = (ri % RPX) * 8 + x;
-    if (blk >= NR || pwl >= a.Br) return;
+    if (blk >= NR || pwl >= a.Br) continue;
     const cf* __restrict__ Tt = a.Tr + ((size_t)pwl * NR + blk) * (size_t)(N2h + 1) * kWRB;
     if (g.flags & XCX_F_UNBIAS)
       pair_row_body<RXR, false, true>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, a.trash, g);
     else
       pair_row_body<RXR, false, false>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, a.trash, g);
+  }
   }
 }
 
