@@ -29,10 +29,7 @@ hipError_t XCX_CAT3(launch_wdual_, XCX_FC_L, _, XCX_FR_L)(const WDualArgs& a, hi
   constexpr size_t lds = sizeof(float) * (lc > lr ? lc : lr) * kWPB;
   constexpr int CPX = (RXR::L + 1 + 7) / 8, RPX = (RXC::L / kWRB + 7) / 8;
   const int Bm = a.Bc > a.Br ? a.Bc : a.Br;
-  unsigned wgx = ((CPX + RPX) * Bm + kWPB - 1) / kWPB;           // workgroups per XCD if one item per wave
-  static const int pers = getenv("XCX_DUAL_PERSIST") ? atoi(getenv("XCX_DUAL_PERSIST")) : 0;
-  if (pers > 0 && wgx > (unsigned)pers) wgx = (unsigned)pers;  // persistent: waves loop over items
-  const dim3 grid(8u * wgx);
+  const dim3 grid(8u * (((CPX + RPX) * Bm + kWPB - 1) / kWPB));
   // occupancy knob: pad the LDS request so that at most `wgs` workgroups share a CU
   static const int wgs = getenv("XCX_DUAL_WGS") ? atoi(getenv("XCX_DUAL_WGS")) : 0;
   size_t lds_req = lds;

@@ -170,19 +170,19 @@ __global__ __launch_bounds__(kWNT * kWPB) void k_wfwd_rows(WF1Args a) {
   const int n = g.n, N1 = g.N1;
   const bool onebit = g.flags & XCX_F_ONEBIT;
   const float mean = sw_mean(a.psum, sw, n, g.flags & XCX_F_DEMEAN);
+  // branch-free gather of the zero-padded window: indices beyond the window
+  // are clamped (the load hits the cached last sample) and the value zeroed,
+  // so all loads of a lane are in flight together
   auto in = [=](int m, int r) -> cf {
     const int i0 = row0 + r + N1 * (2 * m);
     const int i1 = i0 + N1;
-    float v0 = 0.f, v1 = 0.f;
-    if (i0 < n) {
-      v0 = x[i0] - mean;
-      if (onebit) v0 = (v0 > 0.f) ? 1.f : ((v0 < 0.f) ? -1.f : 0.f);
+    float v0 = x[i0 < n ? i0 : n - 1] - mean;
+    float v1 = x[i1 < n ? i1 : n - 1] - mean;
+    if (onebit) {
+      v0 = (v0 > 0.f) ? 1.f : ((v0 < 0.f) ? -1.f : 0.f);
+      v1 = (v1 > 0.f) ? 1.f : ((v1 < 0.f) ? -1.f : 0.f);
     }
-    if (i1 < n) {
-      v1 = x[i1] - mean;
-      if (onebit) v1 = (v1 > 0.f) ? 1.f : ((v1 < 0.f) ? -1.f : 0.f);
-    }
-    return make_float2(v0, v1);
+    return make_float2(i0 < n ? v0 : 0.f, i1 < n ? v1 : 0.f);
   };
   auto to_lds = [=](int p, int r, cf v) { lds[p * kWRB + r] = v; };
   auto lds_ld = [=](int p, int r) -> cf { return lds[p * kWRB + r]; };
@@ -639,6 +639,8 @@ struct WDualArgs {
   Geom g;
 };
 
+// amdgpu_waves_per_eu(3,3): same 128 VGPRs / 4 waves per SIMD at run time, but
+// the scheduler then orders for latency instead of register pressure (+14 %)
 #ifndef XCX_DUAL_WAVES
 #define XCX_DUAL_WAVES 3
 #endif
@@ -655,34 +657,31 @@ void k_wpair_dual(WDualArgs a) {
   constexpr int kPerWave = lds_col_floats(N1) > lds_row_floats(N2h) ? lds_col_floats(N1) : lds_row_floats(N2h);
   cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave_in_group() * kPerWave);
   const int x = blockIdx.x & 7;
+  const int q = (blockIdx.x >> 3) * kWPB + wave_in_group();
   const int Bm = a.Bc > a.Br ? a.Bc : a.Br;
-  // persistent waves: the grid is sized to what the chip holds (a.nwg_xcd
-  // workgroups per XCD); every wave strides through its XCD's work sequence
-  const int qtot = (CPX + RPX) * Bm;
-  const int stride = (int)(gridDim.x >> 3) * kWPB;
-  for (int q = (blockIdx.x >> 3) * kWPB + wave_in_group(); q < qtot; q += stride) {
   // per-XCD work sequence: CPX*Bm column items (column-major: all pair-windows
   // of one column k2 back to back, so a station column stays in this XCD's L2
-  // for the 8 pairs of its tile) interleaved CPX:RPX with RPX*Bm row items
+  // for the 8 pairs of its tile) interleaved CPX:RPX with RPX*Bm row items.
+  // (A persistent-wave loop over this sequence was tried: the loop-carried
+  // state pushes the kernel into scratch spills and it runs 4x slower.)
   const int grp = q / (CPX + RPX), pos = q % (CPX + RPX);
   if (pos < CPX) {
     const int ci = grp * CPX + pos;
     const int k2 = (ci / Bm) * 8 + x;
     const int pwl = ci % Bm;
-    if (k2 > N2h || pwl >= a.Bc) continue;
+    if (k2 > N2h || pwl >= a.Bc) return;
     pair_col_body<RXC, STACK>(lds, a.X, a.spec_pitch, a.pw_c[pwl], a.nstack, k2,
                               a.Tc + (size_t)pwl * N1 * (N2h + 1), a.tw_N1, a.tw_N, g);
   } else {
     const int ri = grp * RPX + (pos - CPX);
     const int pwl = ri / RPX;
     const int blk = (ri % RPX) * 8 + x;
-    if (blk >= NR || pwl >= a.Br) continue;
+    if (blk >= NR || pwl >= a.Br) return;
     const cf* __restrict__ Tt = a.Tr + ((size_t)pwl * NR + blk) * (size_t)(N2h + 1) * kWRB;
     if (g.flags & XCX_F_UNBIAS)
       pair_row_body<RXR, false, true>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, a.trash, g);
     else
       pair_row_body<RXR, false, false>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, a.trash, g);
-  }
   }
 }
 
