@@ -157,7 +157,8 @@ struct WF1Args {
 };
 
 template <class RX>
-__global__ __launch_bounds__(kWNT * kWPB) void k_wfwd_rows(WF1Args a) {
+__global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_wfwd_rows(WF1Args a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   constexpr int N2h = RX::L;
   const Geom g = a.g;
@@ -228,7 +229,8 @@ struct WF2Args {
 };
 
 template <class RX>
-__global__ __launch_bounds__(kWNT * kWPB) void k_wfwd_cols(WF2Args a) {
+__global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_wfwd_cols(WF2Args a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   constexpr int N1 = RX::L;
   const Geom g = a.g;
@@ -329,7 +331,8 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
 }
 
 template <class RX, bool STACK>
-__global__ __launch_bounds__(kWNT * kWPB) void k_wpair_cols(WI1Args a) {
+__global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_wpair_cols(WI1Args a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   const Geom g = a.g;
   const int N2h = g.N2h;
@@ -509,7 +512,8 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
 }
 
 template <class RX>
-__global__ __launch_bounds__(kWNT * kWPB) void k_wpair_rows(WI2Args a) {
+__global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
+void k_wpair_rows(WI2Args a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   const Geom g = a.g;
   cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave_in_group() * lds_row_floats(RX::L));
