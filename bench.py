@@ -60,7 +60,7 @@ def parse():
 
 
 def synth_day(S, T, day):
-    from oracle.ref_numpy import synthetic_traces   # input generator only
+    from xcorr_amd.synth import synthetic_traces
     return synthetic_traces(S, T, day=day)
 
 
@@ -276,7 +276,7 @@ def main():
                          'traffic': (sum(tr) if all(t is not None for t in tr) else None)},
                 'kernels_us': {k: v['avg_us'] for k, v in kern.items()},
             }
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:
             cb = cpu_baseline(n, a.cpu_seconds)
             res['cpu_baseline'] = {
                 'value': cb['faithful'], 'unit': 'pair-windows/s', 'cores': cb['cores'],

@@ -92,3 +92,11 @@ def test_signal_host_helpers():
         sig.filter(np.zeros((2, 100), np.float32), 3, sampling_rate=50.)
     with pytest.raises(KeyError):
         sig.detrend(np.zeros((2, 10), np.float32), type='cubic')
+
+
+def test_synthetic_generator_matches_oracle_copy():
+    from xcorr_amd.synth import synthetic_traces
+    a = synthetic_traces(3, 500, day=2)
+    b = R.synthetic_traces(3, 500, day=2)
+    np.testing.assert_array_equal(a, b)
+    assert a.dtype == np.float32 and a.shape == (3, 500)
