@@ -169,6 +169,18 @@ def main():
 
     lib = _ffi.lib()
 
+    # time-stack across ranks (configs[3]): the only exchange step of the path,
+    # one RCCL all-reduce of the per-rank partial stacks over xGMI
+    rccl = None
+    if a.stack and dist is not None:
+        try:
+            uid = [X.Context.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(uid[0], world, rank)
+            rccl = True
+        except Exception as e:          # e.g. two ranks rehearsing on one GPU
+            rccl = f'unavailable: {e}'
+
     def step():
         if preprocess:
             ops.copy(ctx, work, raw)
@@ -176,6 +188,8 @@ def main():
             ops.taper(ctx, work, taper_n, wtype='cosine')
             ops.sosfilt(ctx, work, sos)
         plan.pairs(work, pairs, W, hop, out=out, ld_out=ld)
+        if rccl is True:
+            ctx.stack_reduce(out, count=nrows * ld)
 
     def barrier():
         ctx.sync()
@@ -210,7 +224,7 @@ def main():
         kern = plan.profile_step(step)
 
     res = {
-        'metric': 'pair-windows/s',
+        'metric': 'pair-windows/s' if not a.stack else 'pair-windows/s (stacked: windows summed per pair)',
         'value': value,
         'unit': 'pair-windows/s',
         'n_gpus': world,
@@ -234,6 +248,8 @@ def main():
         'cc_samples_per_s': value * L,
         'event_ms_per_step_rank0': ev_ms / a.steps,
     }
+    if a.stack:
+        res['rccl_stack_reduce'] = rccl
     if rank == 0:
         # algorithmic bytes per pair-window: every CCF written once
         # + every station window read once (+ the preprocess pass over the day)

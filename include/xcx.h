@@ -119,8 +119,8 @@ int xcx_plan_counters(xcx_plan* plan, long long* launches,
 
 /* Per-kernel timing with HIP events recorded on the plan's stream around
  * every launch (bench.py roofline leg).  enable != 0 clears and starts;
- * xcx_plan_profile_read synchronises and returns, for kernel_id 0..5
- * (k_stats, k_fwd_rows, k_fwd_cols, k_pair_cols, k_pair_rows, k_pair_dual), the summed
+ * xcx_plan_profile_read synchronises and returns, for kernel_id 0..6
+ * (k_stats, k_fwd_rows, k_fwd_cols, k_pair_cols, k_pair_rows, k_pair_dual, k_gram), the summed
  * duration, the launch count and the units (station-windows / pair-windows)
  * those launches processed. */
 int xcx_plan_profile(xcx_plan* plan, int enable);

@@ -304,3 +304,27 @@ def test_rccl_stack_reduce_single_rank(ctx):
     ctx.stack_reduce(d, reduce_scatter=True)
     ctx.sync()
     np.testing.assert_array_equal(d.to_host(), a)
+
+
+def test_stack_gram_many_stations_and_odd_pairs(ctx, monkeypatch):
+    """Time-stack through the Gram (batched rank-W update) kernel: 11 stations
+    (two 8-station tiles, ragged), pairs in arbitrary order with i > j, an
+    auto-pair and a duplicate; also the per-element stack loop (XCX_GRAM=0)."""
+    S, n, hop, W = 11, 1200, 600, 5
+    tr = R.synthetic_traces(S, hop * (W - 1) + n)
+    rng = np.random.default_rng(5)
+    pairs = np.array([(int(a), int(b)) for a, b in rng.integers(0, S, size=(40, 2))] + [(3, 3), (10, 0), (10, 0)],
+                     np.int32)
+    ref = R.cc_pairs(tr, pairs, n, hop, dtype=np.float64).sum(axis=1)
+    got = X.CCPlan(ctx, n, stack=True).pairs(tr, pairs, W, hop)
+    assert got.shape == (len(pairs), 2 * n - 1)
+    assert relerr(got, ref) < TOL
+    monkeypatch.setenv('XCX_GRAM', '0')
+    got0 = X.CCPlan(ctx, n, stack=True).pairs(tr, pairs, W, hop)
+    assert relerr(got0, ref) < TOL
+    # with one-bit + whitening the stack is still the sum of the per-window CCFs
+    monkeypatch.delenv('XCX_GRAM')
+    kw = dict(onebit=True, demean=True, whiten=(50., 1., 10., .5))
+    per = X.CCPlan(ctx, n, **kw).pairs(tr, pairs, W, hop).astype(np.float64).sum(axis=1)
+    st = X.CCPlan(ctx, n, stack=True, **kw).pairs(tr, pairs, W, hop)
+    assert relerr(st, per) < TOL

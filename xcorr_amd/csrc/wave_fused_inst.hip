@@ -18,9 +18,9 @@ hipError_t XCX_CAT3(launch_wfused_, XCX_FC_L, _, XCX_FR_L)(const WFusedArgs& a, 
   constexpr size_t lds = sizeof(float) * (lc > lr ? lc : lr) * kWPB;
   nblocks = (nblocks + kWPB - 1) / kWPB;
   if (a.nstack > 1)
-    hipLaunchKernelGGL((k_wpair_fused<RXC, RXR, true>), dim3(nblocks), dim3(kWNT * kWPB), lds, s, a);
+    hipLaunchKernelGGL((k_wpair_fused<RXC, RXR, 1>), dim3(nblocks), dim3(kWNT * kWPB), lds, s, a);
   else
-    hipLaunchKernelGGL((k_wpair_fused<RXC, RXR, false>), dim3(nblocks), dim3(kWNT * kWPB), lds, s, a);
+    hipLaunchKernelGGL((k_wpair_fused<RXC, RXR, 0>), dim3(nblocks), dim3(kWNT * kWPB), lds, s, a);
   return hipGetLastError();
 }
 
@@ -35,15 +35,17 @@ hipError_t XCX_CAT3(launch_wdual_, XCX_FC_L, _, XCX_FR_L)(const WDualArgs& a, hi
   size_t lds_req = lds;
   if (wgs > 0) {
     lds_req = std::max(lds, (size_t)(160 * 1024 / wgs) & ~(size_t)255);
-    static hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wpair_dual<RXC, RXR, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wpair_dual<RXC, RXR, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wpair_dual<RXC, RXR, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    static hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wpair_dual<RXC, RXR, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e1 != hipSuccess) return e1;
     if (e2 != hipSuccess) return e2;
   }
-  if (a.nstack > 1)
-    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, true>), grid, dim3(kWNT * kWPB), lds_req, s, a);
+  if (a.nstack < 0)
+    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, 2>), grid, dim3(kWNT * kWPB), lds_req, s, a);
+  else if (a.nstack > 1)
+    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, 1>), grid, dim3(kWNT * kWPB), lds_req, s, a);
   else
-    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, false>), grid, dim3(kWNT * kWPB), lds_req, s, a);
+    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, 0>), grid, dim3(kWNT * kWPB), lds_req, s, a);
   return hipGetLastError();
 }
 

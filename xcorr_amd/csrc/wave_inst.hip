@@ -25,10 +25,12 @@ hipError_t XCX_CAT(launch_wfwd_cols_, XCX_INST_L)(const WF2Args& a, dim3 grid, h
 }
 hipError_t XCX_CAT(launch_wpair_cols_, XCX_INST_L)(const WI1Args& a, dim3 grid, hipStream_t s) {
   grid.x = 8u * ((grid.x / 8u + kWPB - 1) / kWPB);     // waves per XCD -> workgroups per XCD
-  if (a.nstack > 1)
-    hipLaunchKernelGGL((k_wpair_cols<RX, true>), grid, dim3(kWNT * kWPB), kLds, s, a);
+  if (a.nstack < 0)
+    hipLaunchKernelGGL((k_wpair_cols<RX, 2>), grid, dim3(kWNT * kWPB), kLds, s, a);
+  else if (a.nstack > 1)
+    hipLaunchKernelGGL((k_wpair_cols<RX, 1>), grid, dim3(kWNT * kWPB), kLds, s, a);
   else
-    hipLaunchKernelGGL((k_wpair_cols<RX, false>), grid, dim3(kWNT * kWPB), kLds, s, a);
+    hipLaunchKernelGGL((k_wpair_cols<RX, 0>), grid, dim3(kWNT * kWPB), kLds, s, a);
   return hipGetLastError();
 }
 #else

@@ -280,7 +280,9 @@ struct WI1Args {
 
 // column body shared by k_wpair_cols and the fused kernel: pair-window
 // descriptor d, column k2, T slot base `T`
-template <class RX, bool STACK>
+// MODE 0: C = X_a conj X_b;  1: sum of that over nstack consecutive slots;
+// 2: C is read from a precomputed cross-spectrum (slot_a of the Gram buffer)
+template <class RX, int MODE>
 XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_t spec_pitch,
                            const PwDesc d, int nstack, int k2, cf* __restrict__ T,
                            const cf* __restrict__ tw_sub, const cf* __restrict__ twN, const Geom& g) {
@@ -304,12 +306,16 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
   }
   const cf gstep = twN_lookup(twN, (unsigned)CG::NSL * kk);
   auto in = [=](int k1, int) -> cf {
-    cf acc = cmulc(A[k1], Bp[k1]);
-    if constexpr (STACK) {
-      for (int w = 1; w < nstack; ++w)
-        acc = cadd(acc, cmulc(A[k1 + w * sstride], Bp[k1 + w * sstride]));
+    if constexpr (MODE == 2) {
+      return A[k1];
+    } else {
+      cf acc = cmulc(A[k1], Bp[k1]);
+      if constexpr (MODE == 1) {
+        for (int w = 1; w < nstack; ++w)
+          acc = cadd(acc, cmulc(A[k1 + w * sstride], Bp[k1 + w * sstride]));
+      }
+      return acc;
     }
-    return acc;
   };
   cf* __restrict__ Tc = T + k2 * kWRB;
   const int trow = (N2h + 1) * kWRB;          // float2 per 16-row tile
@@ -330,7 +336,7 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
   wave_col_fft<RX, true>(lds, tw_sub, in, epi);
 }
 
-template <class RX, bool STACK>
+template <class RX, int MODE>
 __global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_wpair_cols(WI1Args a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
@@ -342,7 +348,7 @@ void k_wpair_cols(WI1Args a) {
   const int k2 = (q / a.B) * 8 + x;
   const int pwl = q % a.B;
   if (k2 > N2h) return;
-  pair_col_body<RX, STACK>(lds, a.X, a.spec_pitch, a.pw[pwl], a.nstack, k2,
+  pair_col_body<RX, MODE>(lds, a.X, a.spec_pitch, a.pw[pwl], a.nstack, k2,
                            a.T + (size_t)pwl * RX::L * (N2h + 1), a.tw_sub, a.tw_N, g);
 }
 
@@ -565,7 +571,7 @@ XCX_DEV void spin_until(const int* p, int target, int* err) {
   if (tid_of<kWNT>() == 0) *err = 1;
 }
 
-template <class RXC, class RXR, bool STACK>
+template <class RXC, class RXR, int MODE>
 __global__ __launch_bounds__(kWNT * kWPB) void k_wpair_fused(WFusedArgs a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   const Geom g = a.g;
@@ -610,7 +616,7 @@ __global__ __launch_bounds__(kWNT * kWPB) void k_wpair_fused(WFusedArgs a) {
         const int kp = k - 3;
         spin_until(a.rdone + (((kp >> 3) << 6) | (x << 3) | (kp & 7)), NR, a.err);
       }
-      pair_col_body<RXC, STACK>(lds, a.X, a.spec_pitch, a.pw[pw], a.nstack, sub, T, a.tw_N1, a.tw_N, g);
+      pair_col_body<RXC, MODE>(lds, a.X, a.spec_pitch, a.pw[pw], a.nstack, sub, T, a.tw_N1, a.tw_N, g);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // T stores are in L2
       if (tid_of<kWNT>() == 0) __hip_atomic_fetch_add(a.cdone + pw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
@@ -648,7 +654,7 @@ struct WDualArgs {
 #ifndef XCX_DUAL_WAVES
 #define XCX_DUAL_WAVES 3
 #endif
-template <class RXC, class RXR, bool STACK>
+template <class RXC, class RXR, int MODE>
 __global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(XCX_DUAL_WAVES, XCX_DUAL_WAVES)))
 void k_wpair_dual(WDualArgs a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
@@ -674,7 +680,7 @@ void k_wpair_dual(WDualArgs a) {
     const int k2 = (ci / Bm) * 8 + x;
     const int pwl = ci % Bm;
     if (k2 > N2h || pwl >= a.Bc) return;
-    pair_col_body<RXC, STACK>(lds, a.X, a.spec_pitch, a.pw_c[pwl], a.nstack, k2,
+    pair_col_body<RXC, MODE>(lds, a.X, a.spec_pitch, a.pw_c[pwl], a.nstack, k2,
                               a.Tc + (size_t)pwl * N1 * (N2h + 1), a.tw_N1, a.tw_N, g);
   } else {
     const int ri = grp * RPX + (pos - CPX);
@@ -688,5 +694,28 @@ void k_wpair_dual(WDualArgs a) {
       pair_row_body<RXR, false, false>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, a.trash, g);
   }
 }
+
+// ---------------------------------------------------------------------------
+// Time-stack as a batched Hermitian rank-W update (the cgemm reformulation of
+// SURVEY 8d): for every frequency k, G_k[i][j] = sum_w X_{i,w}[k] conj X_{j,w}[k].
+// One wave = 64 consecutive frequencies (one per lane, so every load is a
+// contiguous 512-byte run) x one 8x8 station tile held as 64 complex
+// accumulators in registers; per window it loads 16 values and does 64 complex
+// multiply-adds.  XCD-aware order: all tiles of a frequency chunk run back to
+// back on one XCD, so the chunk of the S*W spectra is fetched from HBM once
+// and re-read from that L2 by the other tiles.
+// ---------------------------------------------------------------------------
+constexpr int kGT = 8;           // station tile edge
+
+struct GramArgs {
+  const cf* X; size_t spec_pitch;   // X[(s*W + w)*spec_pitch + k]
+  int S, W;
+  int nfreq;                        // spectrum elements (N1*(N2h+1))
+  const int2* tiles; int ntiles;    // (first station of the i block, of the j block)
+  const int* pidx;                  // [S*S] -> row of C, or -1
+  cf* C; size_t c_pitch;            // C[p*c_pitch + k]
+};
+
+hipError_t launch_gram(const GramArgs& a, hipStream_t s);
 
 }  // namespace xcx

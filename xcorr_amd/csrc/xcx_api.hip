@@ -308,12 +308,16 @@ struct xcx_plan {
   bool wave = true;          // one-wave-per-workgroup engine (default)
   const WFusedEntry* fused = nullptr;   // XCD-local fused pair kernel, if built for (N1, N2h)
   DevBuf Tring, fsync;       // T ring [8][3][slot], ticket / completion counters
+  DevBuf gramC, gramTiles, gramPidx;   // time-stack cross-spectra [P][spec_pitch], tile list, pair lookup
+  bool gram = true;          // stack via the Gram kernel (XCX_GRAM=0: per-element loop)
   DevBuf trash;              // 64 floats: sink of out-of-range lags (branch-free stores)
   int fused_blocks = 0;
   const WFusedEntry* dual = nullptr;    // one-launch I2(b-1) + I1(b) kernel, if built for (N1, N2h)
   // pending row pass of the dual pipeline
   size_t dual_d0 = 0; int dual_B = 0; int dual_slot = 0; float* dual_out = nullptr;
   size_t fused_err_off = 0;  // index of the error flag inside fsync
+  unsigned long long gram_key = 0; int gram_ntiles = 0;
+  bool fused_ran = false;
   DevBuf psum, psq;          // partial statistics of a forward chunk
   int L = 0;                 // retained lags
   int batch = 512;           // pair-windows per launch batch
@@ -335,9 +339,9 @@ struct xcx_plan {
   std::vector<Ev> evs;
 };
 
-enum { KID_STATS = 0, KID_FWD_ROWS, KID_FWD_COLS, KID_PAIR_COLS, KID_PAIR_ROWS, KID_PAIR_FUSED, KID_COUNT };
+enum { KID_STATS = 0, KID_FWD_ROWS, KID_FWD_COLS, KID_PAIR_COLS, KID_PAIR_ROWS, KID_PAIR_FUSED, KID_GRAM, KID_COUNT };
 static const char* kKernelNames[KID_COUNT] = {"k_stats", "k_fwd_rows", "k_fwd_cols",
-                                              "k_pair_cols", "k_pair_rows", "k_pair_dual"};
+                                              "k_pair_cols", "k_pair_rows", "k_pair_dual", "k_gram"};
 
 struct ProfScope {
   xcx_plan* p; size_t idx; bool on;
@@ -421,6 +425,7 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
   g.N1 = wave ? kWCols[bi].L : kCols[bi].L;
   g.N2h = wave ? kWRows[bj].L : kRows[bj].L;
   g.N2 = 2 * g.N2h;
+  if (const char* ge = getenv("XCX_GRAM")) p->gram = strcmp(ge, "0") != 0;
   if (wave) {
     if (p->trash.ensure(ctx, sizeof(float) * 64)) { delete p; return XCX_ENOMEM; }
     // opt-in (XCX_FUSED=1): parity-green but not yet faster than the two-launch
@@ -474,7 +479,7 @@ extern "C" int xcx_plan_destroy(xcx_plan* p) {
   for (auto& e : p->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   DevBuf* bufs[] = {&p->tw_N1, &p->tw_N2h, &p->tw_unt, &p->tw_N, &p->stats,
                     &p->Tm_f, &p->Tn_f, &p->spectra, &p->T, &p->descs,
-                    &p->dtraces, &p->dout, &p->dpairs, &p->psum, &p->psq, &p->Tring, &p->fsync, &p->trash};
+                    &p->dtraces, &p->dout, &p->dpairs, &p->psum, &p->psq, &p->Tring, &p->fsync, &p->trash, &p->gramC, &p->gramTiles, &p->gramPidx};
   for (DevBuf* b : bufs) b->release();
   delete p;
   return XCX_OK;
@@ -664,13 +669,13 @@ static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_
 }
 
 // pair-window batch: descriptors [d0, d0+B) of the device descriptor array
-static int pair_batch(xcx_plan* p, size_t d0, int B, float* out, int nstack) {
+static int pair_batch(xcx_plan* p, size_t d0, int B, float* out, int nstack, const cf* Xsrc = nullptr) {
   xcx_ctx* ctx = p->ctx;
   const Geom& g = p->g;
   const size_t tm_per = (size_t)g.N1 * g.N2h;
   if (p->wave) {
     WI1Args a{};
-    a.X = (const cf*)p->spectra.ptr;
+    a.X = Xsrc ? Xsrc : (const cf*)p->spectra.ptr;
     a.spec_pitch = p->spec_pitch;
     a.pw = (const PwDesc*)p->descs.ptr + d0;
     a.B = B;
@@ -737,12 +742,12 @@ static int pair_batch(xcx_plan* p, size_t d0, int B, float* out, int nstack) {
 // Dual pipeline: dual_push(batch) launches [rows of the pending batch +
 // columns of this batch]; dual_flush() launches the rows of the last batch.
 // T holds two batch-sized buffers used alternately.
-static int dual_launch(xcx_plan* p, size_t d0, int Bc, int nstack, float* out) {
+static int dual_launch(xcx_plan* p, size_t d0, int Bc, int nstack, float* out, const cf* Xsrc = nullptr) {
   xcx_ctx* ctx = p->ctx;
   const Geom& g = p->g;
   const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
   WDualArgs a{};
-  a.X = (const cf*)p->spectra.ptr;
+  a.X = Xsrc ? Xsrc : (const cf*)p->spectra.ptr;
   a.spec_pitch = p->spec_pitch;
   const int cs = p->dual_slot ^ 1;                  // slot written by this launch
   a.pw_c = (const PwDesc*)p->descs.ptr + d0;
@@ -805,11 +810,14 @@ static int pair_fused(xcx_plan* p, size_t d0, int B, float* out, int nstack) {
   }
   p->launches += 1;
   p->pair_windows += B;
+  p->fused_ran = true;
   return XCX_OK;
 }
 
 static int fused_check(xcx_plan* p) {
   int err = 0;
+  if (!p->fsync.ptr || !p->fused_ran) return XCX_OK;
+  p->fused_ran = false;
   HIP_TRY(hipMemcpyAsync(&err, (int*)p->fsync.ptr + p->fused_err_off, sizeof(int), hipMemcpyDeviceToHost,
                          p->ctx->stream));
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));
@@ -891,11 +899,68 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
   if (stack) {
     if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)S * W))) return rc;
     if ((rc = forward(p, dtr, stride_s, stride_w, W, 0, 0, S * W, 0))) return rc;
-    if (p->fused) {
-      if ((rc = pair_fused(p, 0, P, dout, W))) return rc;
+    const cf* src = nullptr;
+    int ns = W;
+    if (p->wave && p->gram && W > 1) {
+      // cgemm-style stack: G_k = A_k A_k^H per frequency, then one inverse per pair
+      if (key != p->gram_key) {
+        std::vector<int> pidx((size_t)S * S, -1);
+        std::vector<char> used((size_t)((S + kGT - 1) / kGT) * ((S + kGT - 1) / kGT), 0);
+        const int nb = (S + kGT - 1) / kGT;
+        for (size_t q = 0; q < (size_t)P; ++q) {
+          // hdescs are in processing order: row q of C belongs to descriptor q
+          const int pi = (int)(p->hdescs[q].out_off / ld_out);
+          const int i = pairs[2 * pi], j = pairs[2 * pi + 1];
+          if (pidx[(size_t)i * S + j] < 0) pidx[(size_t)i * S + j] = (int)q;
+          used[(size_t)(i / kGT) * nb + j / kGT] = 1;
+        }
+        std::vector<int2> tiles;
+        for (int bi = 0; bi < nb; ++bi)
+          for (int bj = 0; bj < nb; ++bj)
+            if (used[(size_t)bi * nb + bj]) tiles.push_back(make_int2(bi * kGT, bj * kGT));
+        if ((rc = upload(ctx, p->gramPidx, pidx.data(), pidx.size() * sizeof(int)))) return rc;
+        if ((rc = upload(ctx, p->gramTiles, tiles.data(), tiles.size() * sizeof(int2)))) return rc;
+        p->gram_ntiles = (int)tiles.size();
+        p->gram_key = key;
+        // duplicate pairs share a row of C: point their descriptors at it
+        bool dup = false;
+        for (size_t q = 0; q < (size_t)P; ++q) {
+          const int pi = (int)(p->hdescs[q].out_off / ld_out);
+          const int row = pidx[(size_t)pairs[2 * pi] * S + pairs[2 * pi + 1]];
+          p->hdescs[q].slot_a = row;
+          p->hdescs[q].slot_b = row;
+          dup |= row != (int)q;
+        }
+        (void)dup;
+        if ((rc = upload(ctx, p->descs, p->hdescs.data(), ndesc * sizeof(PwDesc)))) return rc;
+      }
+      if ((rc = p->gramC.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)P))) return rc;
+      GramArgs ga{};
+      ga.X = (const cf*)p->spectra.ptr;
+      ga.spec_pitch = p->spec_pitch;
+      ga.S = S; ga.W = W;
+      ga.nfreq = g.N1 * (g.N2h + 1);
+      ga.tiles = (const int2*)p->gramTiles.ptr;
+      ga.ntiles = p->gram_ntiles;
+      ga.pidx = (const int*)p->gramPidx.ptr;
+      ga.C = (cf*)p->gramC.ptr;
+      ga.c_pitch = p->spec_pitch;
+      {
+        ProfScope ps(p, KID_GRAM, P);
+        HIP_TRY(launch_gram(ga, ctx->stream));
+      }
+      p->launches += 1;
+      src = (const cf*)p->gramC.ptr;
+      ns = -1;
+    }
+    if (p->fused && ns > 0) {
+      if ((rc = pair_fused(p, 0, P, dout, ns))) return rc;
+    } else if (p->dual) {
+      for (size_t d0 = 0; d0 < (size_t)P; d0 += B)
+        if ((rc = dual_launch(p, d0, (int)std::min((size_t)B, P - d0), ns, dout, src))) return rc;
     } else {
       for (size_t d0 = 0; d0 < (size_t)P; d0 += B)
-        if ((rc = pair_batch(p, d0, (int)std::min((size_t)B, P - d0), dout, W))) return rc;
+        if ((rc = pair_batch(p, d0, (int)std::min((size_t)B, P - d0), dout, ns, src))) return rc;
     }
   } else {
     if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)S))) return rc;
@@ -915,7 +980,7 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
       }
     }
   }
-  if (p->dual && !p->fused) {
+  if (p->dual && p->dual_B > 0) {
     if ((rc = dual_launch(p, 0, 0, 1, dout))) return rc;      // drain: rows of the last batch
     p->dual_B = 0; p->dual_out = nullptr;
   }

@@ -194,7 +194,7 @@ class CCPlan:
         check(L.xcx_plan_profile(self.handle, 1))
         fn()
         out = {}
-        for kid in range(6):
+        for kid in range(7):
             name = C.create_string_buffer(64)
             tot, nl, nu = C.c_double(), C.c_longlong(), C.c_longlong()
             check(L.xcx_plan_profile_read(self.handle, kid, name, 64,
