@@ -571,7 +571,8 @@ static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_
                    int W, int w0, int sw_begin, int sw_end, int slot0) {
   xcx_ctx* ctx = p->ctx;
   const Geom& g = p->g;
-  const int kChunk = 64;
+  // station-windows per forward launch: large launches fill the chip
+  const int kChunk = std::max(64, std::min(512, sw_end - sw_begin));
   const size_t tm_per = (size_t)g.N1 * g.N2h;
   int rc;
   if ((g.flags & XCX_F_WHITEN) && !p->whiten_set)
@@ -863,7 +864,9 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
   // processing order: pairs grouped by 8x8 station tiles so that one launch
   // batch touches few distinct spectra (L2 / Infinity-Cache reuse)
   unsigned long long key = fnv(pairs, sizeof(int) * 2 * (size_t)P, 1469598103934665603ULL);
-  int hdr[4] = {S, W, P, (int)stack};
+  // spectra of all windows resident at once when they fit in 24 GB (1.5 MB each)
+  const bool allw = !stack && W > 1 && sizeof(cf) * p->spec_pitch * (size_t)S * W <= ((size_t)24 << 30);
+  int hdr[5] = {S, W, P, (int)stack, (int)allw};
   key = fnv(hdr, sizeof hdr, key);
   key = fnv(&ld_out, sizeof ld_out, key);
   const size_t ndesc = stack ? (size_t)P : (size_t)P * W;
@@ -886,7 +889,8 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
         for (int q = 0; q < P; ++q) {
           int pi = perm[q];
           p->hdescs[(size_t)w * P + q] =
-              PwDesc{pairs[2 * pi], pairs[2 * pi + 1], ((long long)pi * W + w) * ld_out};
+              allw ? PwDesc{pairs[2 * pi] * W + w, pairs[2 * pi + 1] * W + w, ((long long)pi * W + w) * ld_out}
+                   : PwDesc{pairs[2 * pi], pairs[2 * pi + 1], ((long long)pi * W + w) * ld_out};
         }
     }
     if ((rc = upload(ctx, p->descs, p->hdescs.data(), ndesc * sizeof(PwDesc)))) return rc;
@@ -962,6 +966,20 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
       for (size_t d0 = 0; d0 < (size_t)P; d0 += B)
         if ((rc = pair_batch(p, d0, (int)std::min((size_t)B, P - d0), dout, ns, src))) return rc;
     }
+  } else if (allw) {
+    // every window's station spectra first (few large launches), then the pairs
+    if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)S * W))) return rc;
+    if ((rc = forward(p, dtr, stride_s, stride_w, W, 0, 0, S * W, 0))) return rc;
+    if (p->fused) {
+      for (int w = 0; w < W; ++w)
+        if ((rc = pair_fused(p, (size_t)w * P, P, dout, 1))) return rc;
+    } else if (p->dual) {
+      for (size_t d0 = 0; d0 < ndesc; d0 += B)
+        if ((rc = dual_launch(p, d0, (int)std::min((size_t)B, ndesc - d0), 1, dout))) return rc;
+    } else {
+      for (size_t d0 = 0; d0 < ndesc; d0 += B)
+        if ((rc = pair_batch(p, d0, (int)std::min((size_t)B, ndesc - d0), dout, 1))) return rc;
+    }
   } else {
     if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)S))) return rc;
     for (int w = 0; w < W; ++w) {
@@ -972,8 +990,6 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
       } else if (p->dual) {
         for (size_t q0 = 0; q0 < (size_t)P; q0 += B)
           if ((rc = dual_launch(p, (size_t)w * P + q0, (int)std::min((size_t)B, P - q0), 1, dout))) return rc;
-        // the next window's forward transforms overwrite the spectra only
-        // after this window's last column pass; its row pass may trail
       } else {
         for (size_t q0 = 0; q0 < (size_t)P; q0 += B)
           if ((rc = pair_batch(p, (size_t)w * P + q0, (int)std::min((size_t)B, P - q0), dout, 1))) return rc;
