@@ -27,7 +27,7 @@ hipError_t XCX_CAT3(launch_wfused_, XCX_FC_L, _, XCX_FR_L)(const WFusedArgs& a, 
 hipError_t XCX_CAT3(launch_wdual_, XCX_FC_L, _, XCX_FR_L)(const WDualArgs& a, hipStream_t s) {
   constexpr size_t lc = lds_col_floats(RXC::L), lr = lds_row_floats(RXR::L);
   constexpr size_t lds = sizeof(float) * (lc > lr ? lc : lr) * kWPB;
-  constexpr int CPX = (RXR::L + 1 + 7) / 8, RPX = (RXC::L / kWRB + 7) / 8;
+  constexpr int CPX = (RXR::L + 1 + 7) / 8, RPX = 2 * (((RXC::L / kWRB + 1) / 2 + 7) / 8);
   const int Bm = a.Bc > a.Br ? a.Bc : a.Br;
   const dim3 grid(8u * (((CPX + RPX) * Bm + kWPB - 1) / kWPB));
   // occupancy knob: pad the LDS request so that at most `wgs` workgroups share a CU

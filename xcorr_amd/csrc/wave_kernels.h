@@ -663,7 +663,7 @@ void k_wpair_dual(WDualArgs a) {
   constexpr int N2h = RXR::L;
   constexpr int NR = N1 / kWRB;            // row waves per pair-window
   constexpr int CPX = (N2h + 1 + 7) / 8;   // column slots per XCD
-  constexpr int RPX = (NR + 7) / 8;        // row slots per XCD and pair-window
+  constexpr int RPX = 2 * (((NR + 1) / 2 + 7) / 8);   // row slots per XCD and pair-window (tile pairs)
   constexpr int kPerWave = lds_col_floats(N1) > lds_row_floats(N2h) ? lds_col_floats(N1) : lds_row_floats(N2h);
   cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave_in_group() * kPerWave);
   const int x = blockIdx.x & 7;
@@ -683,9 +683,13 @@ void k_wpair_dual(WDualArgs a) {
     pair_col_body<RXC, MODE>(lds, a.X, a.spec_pitch, a.pw_c[pwl], a.nstack, k2,
                               a.Tc + (size_t)pwl * N1 * (N2h + 1), a.tw_N1, a.tw_N, g);
   } else {
+    // adjacent 16-row tiles (2bp, 2bp+1) are consecutive items of the SAME XCD:
+    // the two 64-byte halves of every 128-byte output line are written from one
+    // XCD within microseconds of each other and merge in its L2
     const int ri = grp * RPX + (pos - CPX);
     const int pwl = ri / RPX;
-    const int blk = (ri % RPX) * 8 + x;
+    const int rr = ri % RPX;
+    const int blk = 2 * ((rr >> 1) * 8 + x) + (rr & 1);
     if (blk >= NR || pwl >= a.Br) return;
     const cf* __restrict__ Tt = a.Tr + ((size_t)pwl * NR + blk) * (size_t)(N2h + 1) * kWRB;
     if (g.flags & XCX_F_UNBIAS)
