@@ -158,6 +158,18 @@ int xcx_sosfiltfilt(xcx_ctx* ctx, float* x, long batch, long n,
 int xcx_sosfilt(xcx_ctx* ctx, float* x, long batch, long n, const double* sos,
                 int n_sections, int on_device);
 
+/* Fractional time shift of every row (xcorr/signal/timeshift.py:90-96, fast=True):
+ * n = size - (size & 1) (the reference's rfft drops the last sample of an
+ * odd-length axis, signal/fft.py:357); y[r] = irfft(rfft(x[r][:n]) *
+ * exp(-2 pi i delay[r] f)) with f = linspace(0, fN, n/2+1) and
+ * fN = round(n/2 / ((n-1)/sampling_rate)) (signal/fft.py:358).
+ * x: [batch][size], y: [batch][n], delay: [batch] seconds (host pointer).
+ * Computed as a period-n circular convolution with the analytic Dirichlet
+ * kernel on the cross-correlation engine (no length-n FFT is needed);
+ * supported for 2n-1 <= the largest transform length (n <= 393216). */
+int xcx_timeshift(xcx_ctx* ctx, const float* x, float* y, long batch, long size,
+                  const double* delay, double sampling_rate, int on_device);
+
 /* ---- multi-GPU time-stack reduction (RCCL over xGMI) --------------------
  * One communicator per process/GPU.  id_bytes is the 128-byte ncclUniqueId
  * created by rank 0 with xcx_comm_unique_id() and distributed by the host

@@ -109,3 +109,56 @@ def test_postprocess_chain_stages(ctx):
     r = R.sosfiltfilt(sos, r)
     r = R.taper(r, fs, max_length=1.5)
     assert relerr(y, r) < TOL
+
+
+@pytest.mark.parametrize('size', [64, 1001, 5999, 60001])
+def test_timeshift_matches_reference_semantics(ctx, size):
+    """signal/timeshift.py:90-96 (rfft drops the last sample of odd axes,
+    integer-Hz Nyquist rounding) as a Dirichlet-kernel circular convolution."""
+    rng = np.random.default_rng(size)
+    fs = 50.
+    x = rng.standard_normal((5, size)).astype(np.float32)
+    x *= np.hanning(size).astype(np.float32)          # tapered like a post-processed CCF
+    delay = np.array([0.0, 0.02, -0.013, 0.25 / fs, 1.37])
+    got = ops.timeshift(ctx, x, delay, fs)
+    ref = R.timeshift(x, delay, fs)
+    assert got.shape == ref.shape == (5, size - (size & 1))
+    assert relerr(got, ref) < TOL
+    # zero delay is the identity on the first n samples; one sample = roll
+    n = size - (size & 1)
+    assert relerr(got[0], x[0, :n]) < TOL
+    assert relerr(got[1], np.roll(x[1, :n], 1)) < TOL
+    # scalar delay broadcasts
+    assert relerr(ops.timeshift(ctx, x, -0.013, fs), R.timeshift(x, -0.013, fs)) < TOL
+
+
+def test_timeshift_full_lag_axis(ctx):
+    """L = 359999 lags -> n = 359998 = 2 * 179999 (prime): no FFT of that length
+    exists in the engine; the circular convolution runs at N = 737280."""
+    rng = np.random.default_rng(11)
+    fs, size = 50., 359999
+    x = (rng.standard_normal((2, size)) * np.hanning(size)).astype(np.float32)
+    delay = np.array([0.0071, -0.0183])
+    got = ops.timeshift(ctx, x, delay, fs)
+    ref = R.timeshift(x, delay, fs)
+    assert got.shape == (2, 359998)
+    assert relerr(got, ref) < TOL
+
+
+def test_postprocess_chain_complete(ctx):
+    """core/postprocess.py:133-141: unbias -> demean -> taper(5 s) ->
+    timeshift(-(pair_offset+time_offset)) -> highpass sosfiltfilt -> taper(1.5 s)."""
+    rng = np.random.default_rng(6)
+    n, fs = 3000, 50.
+    c = (rng.standard_normal((6, 2 * n - 1)) * 0.01).astype(np.float32)
+    delay = rng.uniform(-0.02, 0.02, 6)
+    y = ops.unbias(ctx, c, n)
+    y = ops.demean(ctx, y)
+    y = ops.taper(ctx, y, 250)
+    y = ops.timeshift(ctx, y, delay, fs)
+    sos = R.butter_sos(2, 3., 'highpass', fs)
+    y = ops.sosfiltfilt(ctx, y, sos)
+    y = ops.taper(ctx, y, 75)
+    ref = R.postprocess_chain(c, n, fs, 0, 2 * n - 1, delay)
+    assert y.shape == ref.shape
+    assert relerr(y, ref) < TOL

@@ -68,7 +68,8 @@ def test_reference_full_size_digest(ctx, golden):
     assert relerr(r, R.cc_fair(a, b, dtype=np.float64)) < TOL
 
 
-@pytest.mark.parametrize('n', [1, 2, 3, 7, 64, 255, 256, 257, 1000, 4097, 20000, 65536, 131072, 200000, 262144])
+@pytest.mark.parametrize('n', [1, 2, 3, 7, 64, 255, 256, 257, 1000, 4097, 20000, 65536, 131072, 200000, 262144,
+                               300000, 393216])
 def test_sizes_and_planner(ctx, n):
     rng = np.random.default_rng(n)
     x = rng.standard_normal((2, n)).astype(np.float32)
@@ -84,7 +85,7 @@ def test_sizes_and_planner(ctx, n):
 def test_unsupported_and_invalid_arguments(ctx):
     from xcorr_amd._ffi import XcxError
     with pytest.raises(XcxError, match='no supported transform length'):
-        X.CCPlan(ctx, 300000)
+        X.CCPlan(ctx, 400000)
     with pytest.raises(XcxError, match='lag slice'):
         X.CCPlan(ctx, 100, index_min=150, index_max=100)
     with pytest.raises(XcxError, match='n must be'):

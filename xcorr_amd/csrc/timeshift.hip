@@ -1,0 +1,135 @@
+// timeshift.hip -- fractional time shift of [batch][size] float32 rows with the
+// reference's semantics (xcorr/signal/timeshift.py:90-96 with
+// xcorr/signal/fft.py:357-358, 475-479):
+//     n = size - (size & 1);  X = rfft(x[:n]);  X *= exp(-2 pi i delay f);
+//     y = irfft(X, n)        with f = linspace(0, fN, n/2+1), fN = round(n/2 / ((n-1) delta))
+// i.e. a circular convolution of period n with the Dirichlet kernel
+//     h[m] = (1/n) [ sin((n-1) pi u)/sin(pi u) + cos(pi n alpha) (-1)^m ],  u = m/n - alpha,
+//     alpha = delay * fN / (n/2)   (cycles per frequency bin),
+// which needs no length-n FFT (n = 359 998 = 2 * 179 999 has a prime factor): the
+// kernel is generated analytically in float64 on the device, the circular
+// convolution is the linear cross-correlation engine at a fast length
+// N >= 2n-1 followed by the wrap-around fold  y[m] = R[m] + R[m-n].
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "../../include/xcx.h"
+#include "cc_kernels.h"
+#include "xcx_internal.h"
+
+using namespace xcx;
+
+#define HIP_TRY(expr)                                                     \
+  do {                                                                    \
+    hipError_t e_ = (expr);                                               \
+    if (e_ != hipSuccess)                                                 \
+      return set_err(e_ == hipErrorOutOfMemory ? XCX_ENOMEM : XCX_EHIP,   \
+                     "%s: %s (%s:%d)", #expr, hipGetErrorString(e_),      \
+                     __FILE__, __LINE__);                                 \
+  } while (0)
+
+int xcx_internal_forward(xcx_plan* p, const float* traces, long stride_s, long stride_w,
+                         int W, int w0, int sw_begin, int sw_end, int slot0);
+int xcx_internal_pairs(xcx_plan* p, const PwDesc* hdesc, int count, float* out);
+int xcx_internal_spectra(xcx_plan* p, size_t slots);
+
+namespace {
+
+// hr[r][t] = h_r[(-t) mod n]: the correlation engine computes
+// R[lag] = sum_t x[t+lag] hr[t], so R folded over the period is x (*) h
+__global__ void k_dirichlet(float* __restrict__ hr, long n, long rows, const double* __restrict__ alpha) {
+  const long total = rows * n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / n, t = i % n;
+    const long m = (t == 0) ? 0 : n - t;
+    const double al = alpha[r];
+    double u = (double)m / (double)n - al;
+    u -= rint(u);                                   // [-1/2, 1/2]
+    const double s = sin(M_PI * u);
+    double ratio;
+    if (fabs(s) < 1e-12) ratio = (double)(n - 1);
+    else ratio = sin((double)(n - 1) * M_PI * u) / s;
+    const double nyq = cos(M_PI * (double)n * al) * ((m & 1) ? -1.0 : 1.0);
+    hr[i] = (float)((ratio + nyq) / (double)n);
+  }
+}
+
+// y[r][m] = R[r][m + n - 1] + (m >= 1 ? R[r][m - 1] : 0)
+__global__ void k_fold(const float* __restrict__ lin, long ld, float* __restrict__ y, long n, long rows) {
+  const long total = rows * n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / n, m = i % n;
+    const float* R = lin + r * ld;
+    float v = R[m + n - 1];
+    if (m >= 1) v += R[m - 1];
+    y[i] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int xcx_timeshift(xcx_ctx* ctx, const float* x, float* y, long batch, long size,
+                             const double* delay, double sampling_rate, int on_device) {
+  if (!ctx || !x || !y || !delay) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || size < 2) return set_err(XCX_EINVAL, "batch >= 1 and size >= 2 required");
+  if (!(sampling_rate > 0)) return set_err(XCX_EINVAL, "sampling_rate must be positive");
+  const long n = size - (size & 1);
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc;
+  if (!ctx->ts_plan || ctx->ts_n != n) {
+    if (ctx->ts_plan) { xcx_plan_destroy(ctx->ts_plan); ctx->ts_plan = nullptr; }
+    if (n > 0x7fffffffL / 2) return set_err(XCX_EUNSUPPORTED, "row too long");
+    if ((rc = xcx_plan_cc1d(ctx, (int)n, 0, 0, 0, 0, &ctx->ts_plan))) return rc;
+    ctx->ts_n = n;
+  }
+  xcx_plan* plan = ctx->ts_plan;
+  // alpha = delay * fN / (n/2), fN = round(n/2 / ((n-1) delta))   (fft.py:358)
+  const double delta = 1.0 / sampling_rate;
+  const double fN = std::round((double)(n / 2) / ((double)(n - 1) * delta));
+  std::vector<double> alpha(batch);
+  for (long r = 0; r < batch; ++r) alpha[r] = delay[r] * fN / (double)(n / 2);
+  const long L = 2 * n - 1;
+  const long ld = (L + 31) / 32 * 32;
+  const int kRows = 128;
+  DevBuf &hr = ctx->scratch[1], &lin = ctx->scratch[2], &dal = ctx->scratch[3], &dx = ctx->scratch[4],
+         &dy = ctx->scratch[5];
+  const int chunk = (int)std::min<long>(kRows, batch);
+  if ((rc = hr.ensure(ctx, sizeof(float) * n * chunk))) return rc;
+  if ((rc = lin.ensure(ctx, sizeof(float) * ld * chunk))) return rc;
+  if ((rc = dal.ensure(ctx, sizeof(double) * batch))) return rc;
+  HIP_TRY(hipMemcpyAsync(dal.ptr, alpha.data(), sizeof(double) * batch, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const float* xd = x;
+  float* yd = y;
+  if (!on_device) {
+    if ((rc = dx.ensure(ctx, sizeof(float) * size * batch))) return rc;
+    if ((rc = dy.ensure(ctx, sizeof(float) * n * batch))) return rc;
+    HIP_TRY(hipMemcpyAsync(dx.ptr, x, sizeof(float) * size * batch, hipMemcpyHostToDevice, ctx->stream));
+    xd = (const float*)dx.ptr;
+    yd = (float*)dy.ptr;
+  }
+  if ((rc = xcx_internal_spectra(plan, 2 * (size_t)chunk))) return rc;
+  std::vector<PwDesc> d(chunk);
+  for (long r0 = 0; r0 < batch; r0 += chunk) {
+    const int cnt = (int)std::min<long>(chunk, batch - r0);
+    const long tot = (long)cnt * n;
+    const int grid = (int)std::min<long>((tot + 255) / 256, 256L * 16);
+    hipLaunchKernelGGL(k_dirichlet, dim3(grid), dim3(256), 0, ctx->stream, (float*)hr.ptr, n, (long)cnt,
+                       (const double*)dal.ptr + r0);
+    HIP_TRY(hipGetLastError());
+    if ((rc = xcx_internal_forward(plan, xd + r0 * size, size, 0, 1, 0, 0, cnt, 0))) return rc;
+    if ((rc = xcx_internal_forward(plan, (const float*)hr.ptr, n, 0, 1, 0, 0, cnt, cnt))) return rc;
+    for (int i = 0; i < cnt; ++i) d[i] = PwDesc{i, cnt + i, (long long)i * ld};
+    if ((rc = xcx_internal_pairs(plan, d.data(), cnt, (float*)lin.ptr))) return rc;
+    hipLaunchKernelGGL(k_fold, dim3(grid), dim3(256), 0, ctx->stream, (const float*)lin.ptr, ld, yd + r0 * n, n,
+                       (long)cnt);
+    HIP_TRY(hipGetLastError());
+  }
+  if (!on_device) {
+    HIP_TRY(hipMemcpyAsync(y, yd, sizeof(float) * n * batch, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  return XCX_OK;
+}

@@ -229,7 +229,7 @@ struct WF2Args {
 };
 
 template <class RX>
-__global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(RX::L > 2048 ? 1 : 3, RX::L > 2048 ? 2 : 3)))
 void k_wfwd_cols(WF2Args a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   constexpr int N1 = RX::L;
@@ -337,7 +337,7 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
 }
 
 template <class RX, int MODE>
-__global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(RX::L > 2048 ? 1 : 3, RX::L > 2048 ? 2 : 3)))
 void k_wpair_cols(WI1Args a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   const Geom g = a.g;

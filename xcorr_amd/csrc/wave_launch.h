@@ -5,7 +5,7 @@
 
 namespace xcx {
 
-#define XCX_WCOL_LIST(X) X(64) X(128) X(256) X(512) X(768) X(1024) X(1536) X(2048)
+#define XCX_WCOL_LIST(X) X(64) X(128) X(256) X(512) X(768) X(1024) X(1536) X(2048) X(3072)
 #define XCX_WROW_LIST(X) X(16) X(32) X(64) X(120) X(128)
 
 #define XCX_DECL_WCOL(L)                                                       \

@@ -190,6 +190,7 @@ extern "C" int xcx_destroy(xcx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   xcx_comm_destroy(ctx);
+  if (ctx->ts_plan) xcx_plan_destroy(ctx->ts_plan);
   for (auto& b : ctx->scratch) b.release();
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
@@ -402,7 +403,9 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
       if (!better && N == best) {
         const int b1 = wave ? kWCols[bi].L : kCols[bi].L;
         const int b2 = wave ? kWRows[bj].L : kRows[bj].L;
-        better = wave ? (L1 > b1) : (std::abs(L1 - L2) < std::abs(b1 - b2));
+        // wave engine: longest column up to 2048 (3072 runs at two waves per SIMD)
+        auto pref = [](int l) { return l <= 2048 ? l : 1; };
+        better = wave ? (pref(L1) > pref(b1)) : (std::abs(L1 - L2) < std::abs(b1 - b2));
       }
       if (better) { best = N; bi = i; bj = j; }
     }
@@ -567,6 +570,8 @@ extern "C" int xcx_plan_profile_read(xcx_plan* p, int kernel_id, char* name, siz
 // forward: station-windows sw in [sw_begin, sw_end) of an S x W grid
 // (sw = s*W + wl, window index w0 + wl) -> spectrum slots slot0 + sw
 // ---------------------------------------------------------------------------
+int xcx_internal_forward(xcx_plan* p, const float* traces, long stride_s, long stride_w,
+                         int W, int w0, int sw_begin, int sw_end, int slot0);
 static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_w,
                    int W, int w0, int sw_begin, int sw_end, int slot0) {
   xcx_ctx* ctx = p->ctx;
@@ -1058,3 +1063,29 @@ extern "C" int xcx_cc1d(xcx_plan* p, const float* x, const float* y, int batch,
   }
   return XCX_OK;
 }
+
+// ---------------------------------------------------------------------------
+// internals shared with timeshift.hip
+// ---------------------------------------------------------------------------
+int xcx_internal_forward(xcx_plan* p, const float* traces, long stride_s, long stride_w,
+                         int W, int w0, int sw_begin, int sw_end, int slot0) {
+  return forward(p, traces, stride_s, stride_w, W, w0, sw_begin, sw_end, slot0);
+}
+int xcx_internal_pairs(xcx_plan* p, const PwDesc* hdesc, int count, float* out) {
+  xcx_ctx* ctx = p->ctx;
+  int rc;
+  const Geom& g = p->g;
+  const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
+  if ((rc = p->T.ensure(ctx, sizeof(cf) * tm_per * p->batch * 2))) return rc;
+  if ((rc = p->descs.ensure(ctx, sizeof(PwDesc) * (size_t)count))) return rc;
+  p->desc_key = 0;
+  HIP_TRY(hipMemcpyAsync(p->descs.ptr, hdesc, sizeof(PwDesc) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (int q0 = 0; q0 < count; q0 += p->batch)
+    if ((rc = pair_batch(p, q0, std::min(p->batch, count - q0), out, 1))) return rc;
+  return XCX_OK;
+}
+int xcx_internal_spectra(xcx_plan* p, size_t slots) {
+  return p->spectra.ensure(p->ctx, sizeof(cf) * p->spec_pitch * slots);
+}
+xcx_ctx* xcx_internal_ctx(xcx_plan* p) { return p->ctx; }

@@ -23,4 +23,6 @@ struct xcx_ctx {
   void* comm = nullptr;      // ncclComm_t
   int nranks = 1, rank = 0;
   xcx::DevBuf scratch[8];    // grow-only workspaces of the row ops / filters
+  struct xcx_plan* ts_plan = nullptr;   // cached plan of xcx_timeshift
+  long ts_n = 0;
 };

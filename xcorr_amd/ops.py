@@ -14,7 +14,7 @@ from ._ffi import check, ptr
 from .engine import DeviceArray, default_context
 
 __all__ = ['copy', 'norm1d', 'demean', 'detrend_linear', 'taper', 'unbias',
-           'onebit', 'sosfiltfilt', 'sosfilt']
+           'onebit', 'sosfiltfilt', 'sosfilt', 'timeshift']
 
 
 def _prep(x):
@@ -120,3 +120,32 @@ def sosfilt(ctx, x, sos):
     check(_ffi.lib().xcx_sosfilt(ctx.handle, ptr(buf), b, n, ptr(sos),
                                  sos.shape[0], dev))
     return buf
+
+
+def timeshift(ctx, x, delay, sampling_rate, out=None):
+    """Fractional time shift (xcorr/signal/timeshift.py:90-96, fast=True):
+    rows of length `size` -> rows of length size - (size & 1).  `delay` is a
+    scalar or one value per row (seconds)."""
+    ctx = _ctx(ctx, x)
+    if isinstance(x, DeviceArray):
+        size = x.shape[-1]
+        batch = int(np.prod(x.shape[:-1])) if len(x.shape) > 1 else 1
+        n = size - (size & 1)
+        if out is None:
+            out = DeviceArray(ctx, (batch, n))
+        src, dev, lead = x, 1, None
+    else:
+        src = np.ascontiguousarray(x, dtype=np.float32)
+        size = src.shape[-1]
+        lead = src.shape[:-1]
+        batch = int(np.prod(lead)) if src.ndim > 1 else 1
+        n = size - (size & 1)
+        out = np.empty(lead + (n,), dtype=np.float32)
+        dev = 0
+    d = np.ascontiguousarray(np.broadcast_to(np.asarray(delay, dtype=np.float64),
+                                             lead if lead is not None else (batch,)).reshape(-1))
+    if d.size != batch:
+        raise ValueError('delay must be a scalar or one value per row')
+    check(_ffi.lib().xcx_timeshift(ctx.handle, ptr(src), ptr(out), batch, size, ptr(d),
+                                   float(sampling_rate), dev))
+    return out
