@@ -114,3 +114,38 @@ def test_process_batched_equals_process(ctx):
     ref = R.cc_pairs(tr, R.all_pairs(4), n, n // 2, demean_=True, dtype=np.float64,
                      index_min=n - 1 - 500, index_max=n - 1 + 500)
     assert relerr(out, ref) < TOL
+
+
+def test_signal_timeshift_and_core_postprocess(ctx):
+    """signal.timeshift (array form) and the whole core.postprocess chain on a
+    processed dataset, against the oracle chain (core/postprocess.py:133-141)."""
+    rng = np.random.default_rng(3)
+    a = (rng.standard_normal((2, 3, 801)) * np.hanning(801)).astype(np.float32)
+    d = rng.uniform(-0.05, 0.05, (2, 3))
+    y = sig.timeshift(a, d, sampling_rate=50.)
+    assert y.shape == (2, 3, 800) and y.dtype == np.float32
+    assert relerr(y, R.timeshift(a, d, 50.)) < TOL
+    with pytest.raises(NotImplementedError):
+        sig.timeshift(a, 0.1, sampling_rate=50., fast=False)
+    with pytest.raises(TypeError):
+        sig.timeshift(a, 1, sampling_rate=50.)
+    # process + postprocess on an in-memory client with sub-sample start offsets
+    fs, wl = 50., 40.
+    n = int(wl * fs)
+    tr = R.synthetic_traces(3, 9000)
+    names = ['A', 'B', 'C']
+    client = core.ArrayClient(dict(zip(names, tr)), fs)
+    ds = core.init(['A-B', 'B-C'], 0., 9000 / fs, fs, window_length=wl, window_overlap=.5)
+    core.process(ds, client)
+    ds.pair_offset[...] = rng.uniform(-0.01, 0.01, ds.pair_offset.shape)    # as if starts were offset
+    pp = core.postprocess(ds, lag_lim=(-20., 20.), filter_kwargs={'frequency': 3., 'order': 2})
+    valid = ds.status == 1
+    lag = ds.lag
+    m = (lag >= -20.) & (lag <= 20.)
+    i0 = int(np.flatnonzero(m)[0]); i1 = int(np.flatnonzero(m)[-1]) + 1
+    rows = ds.cc[valid][:, i0:i1]
+    delay = -(ds.pair_offset + ds.time_offset)[valid]
+    ref = R.postprocess_chain(rows, n, fs, i0, i1, delay)
+    assert pp.cc.shape[-1] == ref.shape[-1] == (i1 - i0) - ((i1 - i0) & 1)
+    assert relerr(pp.cc[valid], ref) < TOL
+    assert np.all(pp.cc[~valid] == 0) and pp.cc_attrs['unbiased'] == 1

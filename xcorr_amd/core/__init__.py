@@ -2,5 +2,6 @@
 from .init import init, CCDataset  # noqa: F401
 from .process import process, process_batched  # noqa: F401
 from .client import ArrayClient  # noqa: F401
+from .postprocess import postprocess  # noqa: F401
 
-__all__ = ['init', 'process', 'process_batched', 'CCDataset', 'ArrayClient']
+__all__ = ['init', 'process', 'process_batched', 'postprocess', 'CCDataset', 'ArrayClient']

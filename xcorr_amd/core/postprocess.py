@@ -1,0 +1,69 @@
+"""
+Post-correlation chain of xcorr (core/postprocess.py:21-150) on the GPU:
+
+    cc.where(lag window).unbias().demean().taper(max_length=5.)
+      .timeshift(delay=-(pair_offset+time_offset), dim='lag', fast=True)
+      .filter(frequency=3., btype='highpass', order=2).taper(max_length=3/2)
+
+run on all valid (status == 1) pair x time rows at once.  Celerity-based lag
+limits (cmin/cmax) need the pair distance, which this build's container does not
+carry (util/receiver.py geodesy is out of scope): pass `lag_lim` instead.
+"""
+import numpy as np
+
+from .. import ops
+from ..engine import default_context
+from .init import CCDataset
+
+__all__ = ['postprocess']
+
+
+def postprocess(ds, lag_lim=None, lag_min=None, lag_max=None, filter_kwargs=None, ctx=None):
+    """Returns a new :class:`CCDataset` holding the valid rows, postprocessed.
+
+    Mirrors core/postprocess.py:81-148: rows with status != 1 are dropped
+    (their cc is zero-filled here, status kept), the lag axis is cut to
+    [lag_min, lag_max], and -- like the reference's rfft-based timeshift -- an
+    odd number of lags loses its last sample."""
+    if 'postprocess' in ds.cc_attrs:
+        return ds
+    if lag_lim is not None:
+        lag_min, lag_max = lag_lim
+    import scipy.signal
+    fk = {'frequency': 3., 'btype': 'highpass', 'order': 2, **(filter_kwargs or {})}
+    lag = ds.lag
+    lag_min = lag.min() if lag_min is None else lag_min
+    lag_max = lag.max() if lag_max is None else lag_max
+    m = (lag >= lag_min) & (lag <= lag_max)
+    if not m.any():
+        raise ValueError("No data after extracting time lag")
+    sel = np.flatnonzero(m)
+    i0, i1 = int(sel[0]), int(sel[-1]) + 1
+    la = ds.lag_attrs
+    fs, npts = la['sampling_rate'], la['npts']
+    imin = la['index_min'] + i0
+    imax = la['index_min'] + i1
+    valid = ds.status == 1
+    if not valid.any():
+        raise ValueError("No data after extracting valid times")
+    rows = np.ascontiguousarray(ds.cc[valid][:, i0:i1], dtype=np.float32)
+    delay = -(ds.pair_offset + ds.time_offset)[valid]
+    ctx = ctx or default_context()
+    y = ops.unbias(ctx, rows, npts, imin, imax)
+    y = ops.demean(ctx, y)
+    y = ops.taper(ctx, y, int(round(5. * fs)))              # timeshift phase wrapping
+    y = ops.timeshift(ctx, y, delay, fs)
+    sos = scipy.signal.butter(N=fk['order'], Wn=fk['frequency'], btype=fk['btype'], output='sos', fs=fs)
+    y = ops.sosfiltfilt(ctx, y, sos)
+    y = ops.taper(ctx, y, int(round(1.5 * fs)))             # filter artefacts
+    n = y.shape[-1]
+    out = CCDataset(ds.pair, ds.time, lag[i0:i0 + n],
+                    {**la, 'index_min': imin, 'index_max': imin + n},
+                    {**ds.cc_attrs, 'unbiased': np.byte(1), 'postprocess': 'xcorr_amd'},
+                    ds.time_attrs, dtype=ds.cc.dtype)
+    out.cc[valid] = y.astype(ds.cc.dtype)
+    out.status[...] = ds.status
+    out.pair_offset[...] = ds.pair_offset
+    out.time_offset[...] = ds.time_offset
+    out.attrs = dict(ds.attrs)
+    return out

@@ -41,3 +41,7 @@ class SignalAccessor():
     @wraps(_f.unbias)
     def unbias(self, **kwargs):
         return _f.unbias(self._da, **kwargs)
+
+    @wraps(_f.timeshift)
+    def timeshift(self, **kwargs):
+        return _f.timeshift(self._da, **kwargs)

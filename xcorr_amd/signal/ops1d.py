@@ -240,3 +240,47 @@ def unbias(x, npts=None, index_min=0, index_max=None, dim=None):
     if npts is None:
         raise ValueError('npts is required for array input')
     return _ops.unbias(None, x, npts, index_min, index_max or 0)
+
+
+# -- a10: signal/timeshift.py:23-117 ---------------------------------------------
+def timeshift(x, delay, dtype=None, dim=None, fast=True, sampling_rate=None):
+    """Shift along the last axis (or `dim`) by `delay` seconds through the
+    phase ramp exp(-2 pi i delay f) (signal/timeshift.py:90-96).  `delay` is a
+    float or an array broadcasting over the leading dimensions.  Like the
+    reference (rfft path, signal/fft.py:357) an odd-length axis loses its last
+    sample.  Only ``fast=True`` (rfft/irfft) is built."""
+    if not fast:
+        raise NotImplementedError('only fast=True (rfft/irfft) is built on the GPU path')
+    if _is_da(x):
+        dim = _check_dim(x, dim)
+        if not np.all(np.abs(x[dim].diff(dim, 2)) < 1e-10):
+            raise ValueError(f'coordinate "{dim}" should be regularly spaced')
+        if _is_da(delay):
+            if dim in delay.dims:
+                raise ValueError(f'delay cannot depend on dim "{dim}"')
+            for d in delay.dims:
+                if d not in x.dims:
+                    raise ValueError(f'delay dim "{d}" not existing in x')
+        elif not isinstance(delay, float):
+            raise TypeError('delay should be a float or DataArray')
+        fs = x[dim].attrs.get('sampling_rate')
+        if fs is None:
+            c = x[dim].values
+            fs = 1.0 / float(c[1] - c[0])
+        xt = x.transpose(..., dim)
+        dl = delay
+        if _is_da(delay):
+            dl = delay.broadcast_like(xt.isel({dim: 0})).transpose(*xt.dims[:-1]).values
+        out = _ops.timeshift(None, np.ascontiguousarray(xt.values, np.float32), dl, fs)
+        y = xt.isel({dim: slice(0, out.shape[-1])}).copy(data=out.astype(x.dtype))
+        y = y.transpose(*x.dims)
+        y.attrs = x.attrs
+        y.name = x.name
+        return y
+    if sampling_rate is None:
+        raise ValueError('sampling_rate is required for array input')
+    if not isinstance(delay, (float, np.ndarray, np.floating)):
+        raise TypeError('delay should be a float or an array')
+    x = np.asarray(x)
+    out = _ops.timeshift(None, x, delay, sampling_rate)
+    return out.astype(dtype or x.dtype)
