@@ -158,6 +158,15 @@ int xcx_sosfiltfilt(xcx_ctx* ctx, float* x, long batch, long n,
 int xcx_sosfilt(xcx_ctx* ctx, float* x, long batch, long n, const double* sos,
                 int n_sections, int on_device);
 
+/* Signal-to-noise pieces of xcorr/signal/snr.py:107-116 (envelope=False): per
+ * row, s = max |x| over the signal mask with its index (first occurrence) and
+ * noise_rms = sqrt(mean(x^2)) over the noise mask (signal/rms.py:52-58).
+ * Masks are n bytes (host pointers); s, noise_rms, argmax are host arrays of
+ * `batch` entries.  snr = s / noise_rms is left to the caller (power / dB). */
+int xcx_snr(xcx_ctx* ctx, const float* x, long batch, long n,
+            const unsigned char* signal_mask, const unsigned char* noise_mask,
+            float* s, float* noise_rms, int* argmax, int on_device);
+
 /* Fractional time shift of every row (xcorr/signal/timeshift.py:90-96, fast=True):
  * n = size - (size & 1) (the reference's rfft drops the last sample of an
  * odd-length axis, signal/fft.py:357); y[r] = irfft(rfft(x[r][:n]) *

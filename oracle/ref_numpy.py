@@ -32,7 +32,7 @@ __all__ = [
     'onebit', 'whiten_weights', 'whiten_spectrum', 'whiten_norm',
     'cosine_taper_obspy', 'clip_lag_indices', 'cc_pairs', 'stack',
     'next_fast_len', 'synthetic_traces', 'window_starts', 'all_pairs',
-    'postprocess_chain',
+    'postprocess_chain', 'snr',
 ]
 
 
@@ -297,6 +297,23 @@ def timeshift(x, delay, sampling_rate):
     delay = np.asarray(delay, dtype=np.float64)[..., None]
     X = X * np.exp(-1j * 2 * np.pi * delay * f)
     return np.fft.irfft(X, n=n, axis=-1).astype(x.dtype)
+
+
+# --------------------------------------------------------------------------
+# signal/snr.py:107-116, signal/rms.py:52-58  (envelope=False)
+# --------------------------------------------------------------------------
+def snr(x, signal, noise):
+    """(snr, s, n, argmax): n = sqrt(mean(x[noise]^2)), s = max |x[signal]| and
+    its index along the full axis (first occurrence, like ``argmax``)."""
+    x = np.asarray(x, dtype=np.float64)
+    signal = np.asarray(signal, bool)
+    noise = np.asarray(noise, bool)
+    n = np.sqrt(np.mean(np.square(x[..., noise]), axis=-1))
+    xs = np.abs(x[..., signal])
+    am = xs.argmax(axis=-1)
+    s = np.take_along_axis(xs, am[..., None], axis=-1)[..., 0]
+    idx = np.flatnonzero(signal)[am]
+    return s / n, s, n, idx
 
 
 # --------------------------------------------------------------------------

@@ -162,3 +162,29 @@ def test_postprocess_chain_complete(ctx):
     ref = R.postprocess_chain(c, n, fs, 0, 2 * n - 1, delay)
     assert y.shape == ref.shape
     assert relerr(y, ref) < TOL
+
+
+def test_snr_pieces(ctx):
+    """signal/snr.py:107-116: rms of the noise window, max |x| (and where) in
+    the signal window."""
+    import xcorr_amd.signal as sig
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((4, 3, 5000)).astype(np.float32)
+    x[..., 2600] = 9.0
+    x[1, 2, 2600] = 1.0
+    x[1, 2, 3100] = -7.5
+    lag = (np.arange(5000) - 2500) / 50.
+    signal = (lag >= 0.) & (lag <= 20.)
+    noise = (lag >= 30.) | (lag <= -30.)
+    r, s, n, a = sig.snr(x, signal, noise, extend=True)
+    rr, rs, rn, ra = R.snr(x, signal, noise)
+    assert r.shape == (4, 3)
+    np.testing.assert_array_equal(a, ra)
+    assert a[1, 2] == 3100 and a[0, 0] == 2600
+    np.testing.assert_allclose(s, rs, rtol=1e-6)
+    np.testing.assert_allclose(n, rn, rtol=1e-5)
+    np.testing.assert_allclose(sig.snr(x, signal, noise, decibels=True), 20 * np.log10(rr), rtol=1e-5)
+    with pytest.raises(NotImplementedError):
+        sig.snr(x, signal, noise, envelope=True)
+    with pytest.raises(ValueError):
+        sig.snr(x, np.zeros(5000, bool), noise)

@@ -70,6 +70,7 @@ SIGNATURES = {
     'xcx_onebit': [_vp, _vp, _l, _l, _i],
     'xcx_sosfiltfilt': [_vp, _vp, _l, _l, _vp, _i, _i],
     'xcx_sosfilt': [_vp, _vp, _l, _l, _vp, _i, _i],
+    'xcx_snr': [_vp, _vp, _l, _l, _vp, _vp, _vp, _vp, _vp, _i],
     'xcx_timeshift': [_vp, _vp, _vp, _l, _l, _vp, C.c_double, _i],
     'xcx_comm_unique_id': [C.c_char_p],
     'xcx_comm_init': [_vp, C.c_char_p, _i, _i],

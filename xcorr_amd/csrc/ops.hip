@@ -176,6 +176,47 @@ __global__ void k_onebit(float* __restrict__ x, long total) {
   }
 }
 
+// snr pieces (xcorr/signal/snr.py:107-116): per row the rms over the noise
+// mask and the maximum absolute value (first occurrence) over the signal mask
+__global__ __launch_bounds__(NT) void k_snr(const float* __restrict__ x, long n,
+                                            const unsigned char* __restrict__ sig,
+                                            const unsigned char* __restrict__ noise,
+                                            float* __restrict__ s_out, float* __restrict__ n_out,
+                                            int* __restrict__ arg_out) {
+  __shared__ double red[NT];
+  __shared__ float smax[NT];
+  __shared__ long sidx[NT];
+  const float* __restrict__ row = x + (size_t)blockIdx.x * n;
+  const int tid = threadIdx.x;
+  double acc = 0.0, cnt = 0.0;
+  float best = -1.f;
+  long bi = 0x7fffffffffffffffL;
+  for (long i = tid; i < n; i += NT) {
+    const float v = row[i];
+    if (noise[i]) { acc += (double)v * (double)v; cnt += 1.0; }
+    if (sig[i]) {
+      const float a = fabsf(v);
+      if (a > best) { best = a; bi = i; }        // strided scan keeps the smallest index per thread
+    }
+  }
+  const double ss = block_sum(acc, red);
+  const double cc = block_sum(cnt, red);
+  smax[tid] = best; sidx[tid] = bi;
+  __syncthreads();
+  for (int o = NT / 2; o > 0; o >>= 1) {
+    if (tid < o) {
+      const float b2 = smax[tid + o]; const long i2 = sidx[tid + o];
+      if (b2 > smax[tid] || (b2 == smax[tid] && i2 < sidx[tid])) { smax[tid] = b2; sidx[tid] = i2; }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    n_out[blockIdx.x] = (float)sqrt(ss / cc);
+    s_out[blockIdx.x] = smax[0];
+    arg_out[blockIdx.x] = (int)sidx[0];
+  }
+}
+
 // stage host data on the device when on_device == 0
 struct Staged {
   xcx_ctx* ctx; float* host; float* dev; size_t bytes; bool staged;
@@ -274,4 +315,33 @@ extern "C" int xcx_onebit(xcx_ctx* ctx, float* x, long batch, long n, int on_dev
   hipLaunchKernelGGL(k_onebit, dim3(grid_for(batch * n)), dim3(NT), 0, ctx->stream, st.dev, batch * n);
   HIP_TRY(hipGetLastError());
   return st.end();
+}
+
+extern "C" int xcx_snr(xcx_ctx* ctx, const float* x, long batch, long n, const unsigned char* signal_mask,
+                       const unsigned char* noise_mask, float* s, float* noise_rms, int* argmax, int on_device) {
+  if (!ctx || !x || !signal_mask || !noise_mask || !s || !noise_rms || !argmax)
+    return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || n < 1) return set_err(XCX_EINVAL, "batch and n must be >= 1");
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc;
+  const float* dx = x;
+  if ((rc = ctx->scratch[0].ensure(ctx, 2 * (size_t)n + (size_t)batch * 12 + 64))) return rc;
+  unsigned char* dm = (unsigned char*)ctx->scratch[0].ptr;
+  float* ds = (float*)(dm + ((2 * (size_t)n + 15) & ~(size_t)15));
+  float* dn = ds + batch;
+  int* da = (int*)(dn + batch);
+  HIP_TRY(hipMemcpyAsync(dm, signal_mask, n, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(dm + n, noise_mask, n, hipMemcpyHostToDevice, ctx->stream));
+  if (!on_device) {
+    if ((rc = ctx->scratch[1].ensure(ctx, sizeof(float) * (size_t)batch * n))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->scratch[1].ptr, x, sizeof(float) * (size_t)batch * n, hipMemcpyHostToDevice, ctx->stream));
+    dx = (const float*)ctx->scratch[1].ptr;
+  }
+  hipLaunchKernelGGL(k_snr, dim3((unsigned)batch), dim3(NT), 0, ctx->stream, dx, n, dm, dm + n, ds, dn, da);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(s, ds, sizeof(float) * batch, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(noise_rms, dn, sizeof(float) * batch, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(argmax, da, sizeof(int) * batch, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return XCX_OK;
 }

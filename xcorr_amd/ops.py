@@ -14,7 +14,7 @@ from ._ffi import check, ptr
 from .engine import DeviceArray, default_context
 
 __all__ = ['copy', 'norm1d', 'demean', 'detrend_linear', 'taper', 'unbias',
-           'onebit', 'sosfiltfilt', 'sosfilt', 'timeshift']
+           'onebit', 'sosfiltfilt', 'sosfilt', 'timeshift', 'snr']
 
 
 def _prep(x):
@@ -149,3 +149,30 @@ def timeshift(ctx, x, delay, sampling_rate, out=None):
     check(_ffi.lib().xcx_timeshift(ctx.handle, ptr(src), ptr(out), batch, size, ptr(d),
                                    float(sampling_rate), dev))
     return out
+
+
+def snr(ctx, x, signal, noise):
+    """Per row: (s, n, argmax) with s = max|x| over the boolean `signal` mask,
+    n = rms over the `noise` mask (xcorr/signal/snr.py:107-116, envelope=False)."""
+    ctx = _ctx(ctx, x)
+    if isinstance(x, DeviceArray):
+        src, dev = x, 1
+        nn = x.shape[-1]
+        lead = x.shape[:-1]
+    else:
+        src = np.ascontiguousarray(x, dtype=np.float32)
+        dev = 0
+        nn = src.shape[-1]
+        lead = src.shape[:-1]
+    batch = int(np.prod(lead)) if len(lead) else 1
+    sm = np.ascontiguousarray(signal, dtype=np.uint8)
+    nm = np.ascontiguousarray(noise, dtype=np.uint8)
+    if sm.shape != (nn,) or nm.shape != (nn,):
+        raise ValueError('masks must be 1-D with the length of the last axis')
+    if not sm.any() or not nm.any():
+        raise ValueError('empty signal or noise window')
+    s = np.empty(batch, np.float32)
+    n = np.empty(batch, np.float32)
+    a = np.empty(batch, np.int32)
+    check(_ffi.lib().xcx_snr(ctx.handle, ptr(src), batch, nn, ptr(sm), ptr(nm), ptr(s), ptr(n), ptr(a), dev))
+    return s.reshape(lead), n.reshape(lead), a.reshape(lead)

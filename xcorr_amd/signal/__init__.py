@@ -11,10 +11,10 @@ returned.  (xarray is not installed in the build container: the DataArray
 branch is exercised only where xarray exists.)
 """
 from .ops1d import (correlate1d, norm1d, norm, demean, detrend, window, taper,
-                    filter, unbias, unbias_weights, timeshift)  # noqa: F401
+                    filter, unbias, unbias_weights, timeshift, snr)  # noqa: F401
 
 __all__ = ['correlate1d', 'norm1d', 'norm', 'demean', 'detrend', 'window',
-           'taper', 'filter', 'unbias', 'unbias_weights', 'timeshift']
+           'taper', 'filter', 'unbias', 'unbias_weights', 'timeshift', 'snr']
 
 try:                                    # B4 seam: DataArray.signal accessor
     from . import accessor  # noqa: F401

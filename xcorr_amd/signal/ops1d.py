@@ -284,3 +284,20 @@ def timeshift(x, delay, dtype=None, dim=None, fast=True, sampling_rate=None):
     x = np.asarray(x)
     out = _ops.timeshift(None, x, delay, sampling_rate)
     return out.astype(dtype or x.dtype)
+
+
+# -- signal/snr.py:27-168, signal/rms.py:23-68 (envelope=False) ------------------
+def snr(x, signal, noise, dim=None, power=False, decibels=False, extend=False, envelope=False):
+    """Signal-to-noise ratio along the last axis: max|x| in the `signal` mask
+    over the rms of the `noise` mask (signal/snr.py:107-116).  ``extend=True``
+    returns (snr, s, n, argmax).  The Hilbert envelope variant is not built."""
+    if envelope:
+        raise NotImplementedError('envelope=True (Hilbert transform) is not built on the GPU path')
+    x = np.asarray(x)
+    s, n, a = _ops.snr(None, x, np.asarray(signal), np.asarray(noise))
+    r = s / n
+    if decibels:
+        r = 20 * np.log10(r)
+    elif power:
+        r = np.square(r)
+    return (r, s, n, a) if extend else r
