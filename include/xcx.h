@@ -118,9 +118,11 @@ int xcx_plan_counters(xcx_plan* plan, long long* launches,
                       long long* pair_windows);
 
 /* Per-kernel timing with HIP events recorded on the plan's stream around
- * every launch (bench.py roofline leg).  enable != 0 clears and starts;
- * xcx_plan_profile_read synchronises and returns, for kernel_id 0..6
- * (k_stats, k_fwd_rows, k_fwd_cols, k_pair_cols, k_pair_rows, k_pair_dual, k_gram), the summed
+ * every launch (bench.py roofline leg).  enable = 2 clears and starts per-launch timing,
+ * 1 times only whole pair phases (no perturbation of the overlapping pipelines), 0 stops;
+ * xcx_plan_profile_read synchronises and returns, for kernel_id 0..7
+ * (k_stats, k_fwd_rows, k_fwd_cols, k_pair_cols, k_pair_rows, k_pair_dual, k_gram,
+ * and pair_phase = wall time of a whole pair phase: its pipelines overlap), the summed
  * duration, the launch count and the units (station-windows / pair-windows)
  * those launches processed. */
 int xcx_plan_profile(xcx_plan* plan, int enable);

@@ -315,13 +315,22 @@ struct xcx_plan {
   int fused_blocks = 0;
   const WFusedEntry* dual = nullptr;    // one-launch I2(b-1) + I1(b) kernel, if built for (N1, N2h)
   // pending row pass of the dual pipeline
-  size_t dual_d0 = 0; int dual_B = 0; int dual_slot = 0; float* dual_out = nullptr;
+  // dual pipelines ("chains"): each chain owns a stream and a double-buffered T
+  // and runs its launches in order; chains interleave on the GPU so that one
+  // chain's launch ramps up while another's drains, with small enough batches
+  // that the whole T ring stays resident in the 256 MiB Infinity Cache
+  struct Chain { hipStream_t stream = nullptr; hipEvent_t done = nullptr; size_t d0 = 0; int B = 0; int slot = 0; };
+  static const int kMaxChains = 4;
+  Chain chains[kMaxChains];
+  int nchains = 2;
+  hipEvent_t ev_fwd = nullptr;
   size_t fused_err_off = 0;  // index of the error flag inside fsync
   unsigned long long gram_key = 0; int gram_ntiles = 0;
   bool fused_ran = false;
   DevBuf psum, psq;          // partial statistics of a forward chunk
   int L = 0;                 // retained lags
   int batch = 512;           // pair-windows per launch batch
+  bool batch_user = false;   // set through xcx_plan_set_batch
   size_t spec_pitch = 0;     // float2 per spectrum slot
   // whitening
   float wb[4] = {0, 0, 0, 0};
@@ -335,26 +344,28 @@ struct xcx_plan {
   unsigned long long desc_key = 0;
   long long launches = 0, pair_windows = 0;
   // optional per-kernel HIP-event timing (xcx_plan_profile)
-  bool profiling = false;
+  int profiling = 0;         // 0 off, 1 phases only, 2 every kernel launch
   struct Ev { hipEvent_t a, b; int kid; int units; };
   std::vector<Ev> evs;
 };
 
-enum { KID_STATS = 0, KID_FWD_ROWS, KID_FWD_COLS, KID_PAIR_COLS, KID_PAIR_ROWS, KID_PAIR_FUSED, KID_GRAM, KID_COUNT };
+enum { KID_STATS = 0, KID_FWD_ROWS, KID_FWD_COLS, KID_PAIR_COLS, KID_PAIR_ROWS, KID_PAIR_FUSED, KID_GRAM, KID_PAIR_PHASE, KID_COUNT };
 static const char* kKernelNames[KID_COUNT] = {"k_stats", "k_fwd_rows", "k_fwd_cols",
-                                              "k_pair_cols", "k_pair_rows", "k_pair_dual", "k_gram"};
+                                              "k_pair_cols", "k_pair_rows", "k_pair_dual", "k_gram",
+                                              "pair_phase"};
 
 struct ProfScope {
-  xcx_plan* p; size_t idx; bool on;
-  ProfScope(xcx_plan* p_, int kid, int units) : p(p_), idx(0), on(p_->profiling) {
+  xcx_plan* p; size_t idx; bool on; hipStream_t st;
+  ProfScope(xcx_plan* p_, int kid, int units, hipStream_t s = nullptr)
+      : p(p_), idx(0), on(p_->profiling >= (kid == KID_PAIR_PHASE ? 1 : 2)), st(s ? s : p_->ctx->stream) {
     if (!on) return;
     xcx_plan::Ev e{nullptr, nullptr, kid, units};
     if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess) { on = false; return; }
-    (void)hipEventRecord(e.a, p->ctx->stream);
+    (void)hipEventRecord(e.a, st);
     p->evs.push_back(e);
     idx = p->evs.size() - 1;
   }
-  ~ProfScope() { if (on) (void)hipEventRecord(p->evs[idx].b, p->ctx->stream); }
+  ~ProfScope() { if (on) (void)hipEventRecord(p->evs[idx].b, st); }
 };
 
 static void fill_table(std::vector<float2>& v, int count, int L, int mul = 1) {
@@ -441,6 +452,15 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
     if (!(de && strcmp(de, "0") == 0))
       for (int i = 0; i < kNWFused; ++i)
         if (kWFused[i].N1 == g.N1 && kWFused[i].N2h == g.N2h) p->dual = &kWFused[i];
+    if (const char* ce = getenv("XCX_CHAINS")) p->nchains = std::max(1, std::min(xcx_plan::kMaxChains, atoi(ce)));
+    if (!p->dual) p->nchains = 1;
+    if (p->dual) {
+      // batch so that the whole T ring (chains x 2 buffers) is ~144 MB: it then stays
+      // in the 256 MiB Infinity Cache next to the spectra, and T traffic stops at the cache
+      const size_t tm_bytes = sizeof(cf) * (size_t)g.N1 * (g.N2h + 1);
+      const size_t ring = (size_t)144 << 20;
+      p->batch = (int)std::max<size_t>(4, std::min<size_t>(512, ring / (2 * (size_t)p->nchains * tm_bytes)));
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
       p->fused_blocks = prop.multiProcessorCount * 12;
@@ -480,6 +500,11 @@ extern "C" int xcx_plan_destroy(xcx_plan* p) {
   (void)hipSetDevice(p->ctx->device);
   (void)hipStreamSynchronize(p->ctx->stream);
   for (auto& e : p->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  for (auto& ch : p->chains) {
+    if (ch.stream && ch.stream != p->ctx->stream) { (void)hipStreamSynchronize(ch.stream); (void)hipStreamDestroy(ch.stream); }
+    if (ch.done) (void)hipEventDestroy(ch.done);
+  }
+  if (p->ev_fwd) (void)hipEventDestroy(p->ev_fwd);
   DevBuf* bufs[] = {&p->tw_N1, &p->tw_N2h, &p->tw_unt, &p->tw_N, &p->stats,
                     &p->Tm_f, &p->Tn_f, &p->spectra, &p->T, &p->descs,
                     &p->dtraces, &p->dout, &p->dpairs, &p->psum, &p->psq, &p->Tring, &p->fsync, &p->trash, &p->gramC, &p->gramTiles, &p->gramPidx};
@@ -520,6 +545,7 @@ extern "C" int xcx_plan_set_whiten(xcx_plan* p, double fs, double fmin,
 extern "C" int xcx_plan_set_batch(xcx_plan* p, int b) {
   if (!p || b < 1 || b > 65535) return set_err(XCX_EINVAL, "batch must be in [1,65535]");
   p->batch = b;
+  p->batch_user = true;
   p->desc_key = 0;
   return XCX_OK;
 }
@@ -543,7 +569,7 @@ extern "C" int xcx_plan_profile(xcx_plan* p, int enable) {
   HIP_TRY(hipStreamSynchronize(p->ctx->stream));
   for (auto& e : p->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   p->evs.clear();
-  p->profiling = enable != 0;
+  p->profiling = enable < 0 ? 0 : enable;
   return XCX_OK;
 }
 
@@ -748,22 +774,23 @@ static int pair_batch(xcx_plan* p, size_t d0, int B, float* out, int nstack, con
 // Dual pipeline: dual_push(batch) launches [rows of the pending batch +
 // columns of this batch]; dual_flush() launches the rows of the last batch.
 // T holds two batch-sized buffers used alternately.
-static int dual_launch(xcx_plan* p, size_t d0, int Bc, int nstack, float* out, const cf* Xsrc = nullptr) {
-  xcx_ctx* ctx = p->ctx;
+static int dual_launch(xcx_plan* p, int chain, size_t d0, int Bc, int nstack, float* out, const cf* Xsrc = nullptr) {
   const Geom& g = p->g;
+  xcx_plan::Chain& ch = p->chains[chain];
   const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
+  cf* Tbase = (cf*)p->T.ptr + (size_t)chain * 2 * tm_per * p->batch;
   WDualArgs a{};
   a.X = Xsrc ? Xsrc : (const cf*)p->spectra.ptr;
   a.spec_pitch = p->spec_pitch;
-  const int cs = p->dual_slot ^ 1;                  // slot written by this launch
+  const int cs = ch.slot ^ 1;                       // slot written by this launch
   a.pw_c = (const PwDesc*)p->descs.ptr + d0;
   a.Bc = Bc;
   a.nstack = nstack;
-  a.Tc = (cf*)p->T.ptr + (size_t)cs * tm_per * p->batch;
-  a.pw_r = (const PwDesc*)p->descs.ptr + p->dual_d0;
-  a.Br = p->dual_B;
-  a.Tr = (const cf*)p->T.ptr + (size_t)p->dual_slot * tm_per * p->batch;
-  a.out = p->dual_out ? p->dual_out : out;
+  a.Tc = Tbase + (size_t)cs * tm_per * p->batch;
+  a.pw_r = (const PwDesc*)p->descs.ptr + ch.d0;
+  a.Br = ch.B;
+  a.Tr = Tbase + (size_t)ch.slot * tm_per * p->batch;
+  a.out = out;
   a.trash = (float*)p->trash.ptr;
   a.tw_N1 = (const cf*)p->tw_N1.ptr;
   a.tw_N2h = (const cf*)p->tw_N2h.ptr;
@@ -772,12 +799,52 @@ static int dual_launch(xcx_plan* p, size_t d0, int Bc, int nstack, float* out, c
   a.g = g;
   if (Bc == 0 && a.Br == 0) return XCX_OK;
   {
-    ProfScope ps(p, KID_PAIR_FUSED, Bc > 0 ? Bc : a.Br);
-    HIP_TRY(p->dual->dual(a, ctx->stream));
+    ProfScope ps(p, KID_PAIR_FUSED, Bc > 0 ? Bc : a.Br, ch.stream);
+    HIP_TRY(p->dual->dual(a, ch.stream));
   }
   p->launches += 1;
   p->pair_windows += Bc;
-  p->dual_d0 = d0; p->dual_B = Bc; p->dual_slot = cs; p->dual_out = out;
+  ch.d0 = d0; ch.B = Bc; ch.slot = cs;
+  return XCX_OK;
+}
+
+// run descriptors [first, first+count) through the dual pipelines: batches are
+// dealt round-robin to the chains; on return every chain has been drained and
+// the context's main stream waits for all of them
+static int dual_run(xcx_plan* p, size_t first, size_t count, int nstack, float* out, const cf* Xsrc = nullptr) {
+  xcx_ctx* ctx = p->ctx;
+  int rc;
+  const int B = p->batch;
+  const int nch = p->nchains;
+  for (int c = 0; c < nch; ++c) {
+    xcx_plan::Chain& ch = p->chains[c];
+    if (!ch.stream) {
+      if (nch == 1) ch.stream = ctx->stream;
+      else HIP_TRY(hipStreamCreateWithFlags(&ch.stream, hipStreamNonBlocking));
+      HIP_TRY(hipEventCreateWithFlags(&ch.done, hipEventDisableTiming));
+    }
+    ch.B = 0;
+  }
+  if (!p->ev_fwd) HIP_TRY(hipEventCreateWithFlags(&p->ev_fwd, hipEventDisableTiming));
+  // wall time of the whole pair phase on the main stream (the pipelines overlap,
+  // so per-launch durations do not add up)
+  ProfScope phase(p, KID_PAIR_PHASE, (int)count);
+  if (nch > 1) {
+    HIP_TRY(hipEventRecord(p->ev_fwd, ctx->stream));          // spectra / descriptors are ready
+    for (int c = 0; c < nch; ++c) HIP_TRY(hipStreamWaitEvent(p->chains[c].stream, p->ev_fwd, 0));
+  }
+  size_t k = 0;
+  for (size_t d0 = first; d0 < first + count; d0 += B, ++k)
+    if ((rc = dual_launch(p, (int)(k % nch), d0, (int)std::min((size_t)B, first + count - d0), nstack, out, Xsrc)))
+      return rc;
+  for (int c = 0; c < nch; ++c) {
+    if (p->chains[c].B > 0 && (rc = dual_launch(p, c, 0, 0, 1, out, Xsrc))) return rc;   // rows of the last batch
+    p->chains[c].B = 0;
+    if (nch > 1) {
+      HIP_TRY(hipEventRecord(p->chains[c].done, p->chains[c].stream));
+      HIP_TRY(hipStreamWaitEvent(ctx->stream, p->chains[c].done, 0));
+    }
+  }
   return XCX_OK;
 }
 
@@ -903,8 +970,7 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
   }
   const int B = p->batch;
   const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
-  if ((rc = p->T.ensure(ctx, sizeof(cf) * tm_per * B * 2))) return rc;
-  p->dual_B = 0; p->dual_out = nullptr;
+  if ((rc = p->T.ensure(ctx, sizeof(cf) * tm_per * B * 2 * (p->dual ? p->nchains : 1)))) return rc;
   if (stack) {
     if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)S * W))) return rc;
     if ((rc = forward(p, dtr, stride_s, stride_w, W, 0, 0, S * W, 0))) return rc;
@@ -965,8 +1031,7 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
     if (p->fused && ns > 0) {
       if ((rc = pair_fused(p, 0, P, dout, ns))) return rc;
     } else if (p->dual) {
-      for (size_t d0 = 0; d0 < (size_t)P; d0 += B)
-        if ((rc = dual_launch(p, d0, (int)std::min((size_t)B, P - d0), ns, dout, src))) return rc;
+      if ((rc = dual_run(p, 0, (size_t)P, ns, dout, src))) return rc;
     } else {
       for (size_t d0 = 0; d0 < (size_t)P; d0 += B)
         if ((rc = pair_batch(p, d0, (int)std::min((size_t)B, P - d0), dout, ns, src))) return rc;
@@ -979,8 +1044,7 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
       for (int w = 0; w < W; ++w)
         if ((rc = pair_fused(p, (size_t)w * P, P, dout, 1))) return rc;
     } else if (p->dual) {
-      for (size_t d0 = 0; d0 < ndesc; d0 += B)
-        if ((rc = dual_launch(p, d0, (int)std::min((size_t)B, ndesc - d0), 1, dout))) return rc;
+      if ((rc = dual_run(p, 0, ndesc, 1, dout))) return rc;
     } else {
       for (size_t d0 = 0; d0 < ndesc; d0 += B)
         if ((rc = pair_batch(p, d0, (int)std::min((size_t)B, ndesc - d0), dout, 1))) return rc;
@@ -993,17 +1057,12 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
       if (p->fused) {
         if ((rc = pair_fused(p, (size_t)w * P, P, dout, 1))) return rc;
       } else if (p->dual) {
-        for (size_t q0 = 0; q0 < (size_t)P; q0 += B)
-          if ((rc = dual_launch(p, (size_t)w * P + q0, (int)std::min((size_t)B, P - q0), 1, dout))) return rc;
+        if ((rc = dual_run(p, (size_t)w * P, (size_t)P, 1, dout))) return rc;
       } else {
         for (size_t q0 = 0; q0 < (size_t)P; q0 += B)
           if ((rc = pair_batch(p, (size_t)w * P + q0, (int)std::min((size_t)B, P - q0), dout, 1))) return rc;
       }
     }
-  }
-  if (p->dual && p->dual_B > 0) {
-    if ((rc = dual_launch(p, 0, 0, 1, dout))) return rc;      // drain: rows of the last batch
-    p->dual_B = 0; p->dual_out = nullptr;
   }
   if (p->fused && (!on_device || getenv("XCX_CHECK"))) {
     if ((rc = fused_check(p))) return rc;

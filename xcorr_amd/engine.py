@@ -187,14 +187,16 @@ class CCPlan:
         check(_ffi.lib().xcx_plan_counters(self.handle, C.byref(a), C.byref(b)))
         return a.value, b.value
 
-    def profile_step(self, fn):
-        """Run fn() once with per-kernel HIP-event timing enabled; returns
-        {kernel: {avg_us, total_us, launches, units_per_launch}}."""
+    def profile_step(self, fn, level=2):
+        """Run fn() once with HIP-event timing enabled (level 2: every kernel
+        launch; level 1: only the pair phase as a whole, which does not perturb
+        the overlapping pipelines); returns {kernel: {avg_us, total_us,
+        launches, units_per_launch}}."""
         L = _ffi.lib()
-        check(L.xcx_plan_profile(self.handle, 1))
+        check(L.xcx_plan_profile(self.handle, int(level)))
         fn()
         out = {}
-        for kid in range(7):
+        for kid in range(8):
             name = C.create_string_buffer(64)
             tot, nl, nu = C.c_double(), C.c_longlong(), C.c_longlong()
             check(L.xcx_plan_profile_read(self.handle, kid, name, 64,
