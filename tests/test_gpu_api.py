@@ -149,3 +149,28 @@ def test_signal_timeshift_and_core_postprocess(ctx):
     assert pp.cc.shape[-1] == ref.shape[-1] == (i1 - i0) - ((i1 - i0) & 1)
     assert relerr(pp.cc[valid], ref) < TOL
     assert np.all(pp.cc[~valid] == 0) and pp.cc_attrs['unbiased'] == 1
+
+
+def test_bench_contract_small(ctx):
+    """bench.py prints ONE JSON line with the contract's keys (tiny workload)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--stations', '6', '--seconds', '14400',
+                          '--steps', '1', '--warmup', '1', '--no-cpu-baseline'],
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better',
+              'scaling', 'vs_baseline', 'dtype', 'data', 'config', 'roofline'):
+        assert k in d, k
+    assert d['n_gpus'] == 1 and d['steps'] == 1 and d['vs_baseline'] is None and d['value'] > 0
+    assert d['config']['workload'].startswith('6 stations') and 'model' not in d['config']
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and 0 < r['frac'] < 1
