@@ -181,6 +181,22 @@ int xcx_snr(xcx_ctx* ctx, const float* x, long batch, long n,
 int xcx_timeshift(xcx_ctx* ctx, const float* x, float* y, long batch, long size,
                   const double* delay, double sampling_rate, int on_device);
 
+/* Two-dimensional cross-correlation of tiles (xcorr/signal/correlate.py:162-291
+ * with norm2d of signal/normalize.py:95-155; the inner call of
+ * scripts/timelapse.py:243-268 which keeps max and argmax only).
+ * tiles: [T][F][L] float32 (host or device per on_device);  pairs: [P][2] host
+ * int32 tile indices (a, b).  For every pair
+ *   cc[i][j] = sum_{u,v} a[u + i-(F-1)][v + j-(L-1)] b[u][v],  i < 2F-1, j < 2L-1
+ * (the fftshift-ed layout of the reference), divided by ||a||_F ||b||_F when
+ * normalize != 0.  peak_val[P] / peak_idx[P][2] (host) receive the maximum and
+ * its (i, j), first occurrence in row-major order (numpy.argmax).  full, when
+ * non-NULL, receives all [P][2F-1][2L-1] values (host or device per on_device).
+ * Computed at the padded size P1 x P2 >= (2F-1) x (2L-1) with P1, P2 powers of
+ * two; F <= 256, L <= 4096 (XCX_EUNSUPPORTED beyond). */
+int xcx_cc2d(xcx_ctx* ctx, const float* tiles, int T, int F, int L,
+             const int* pairs, int P, int normalize, float* peak_val,
+             int* peak_idx, float* full, int on_device);
+
 /* ---- multi-GPU time-stack reduction (RCCL over xGMI) --------------------
  * One communicator per process/GPU.  id_bytes is the 128-byte ncclUniqueId
  * created by rank 0 with xcx_comm_unique_id() and distributed by the host

@@ -475,3 +475,41 @@ def synthetic_traces(S, T, day=0, dtype=np.float32):
         off = 25 * (S - 1 - s)
         out[s] = (0.5 * c[off:off + T] + nse + (3.0 + 1e-6 * t)).astype(dtype)
     return out
+
+
+def norm2d(x):
+    """x / ||x||_F over the last two axes (xcorr/signal/normalize.py:95-155)."""
+    x = np.asarray(x, dtype=np.float64)
+    return x / np.linalg.norm(x, ord='fro', axis=(-2, -1), keepdims=True)
+
+
+def correlate2d(in1, in2, normalize=True):
+    """Two-dimensional linear cross-correlation over the last two axes
+    (xcorr/signal/correlate.py:230-246): zero-pad to (2F-1, 2L-1), F conj(G),
+    real inverse, fftshift of both axes.  float64."""
+    f = np.asarray(in1, dtype=np.float64)
+    g = np.asarray(in2, dtype=np.float64)
+    assert f.shape == g.shape
+    if normalize:
+        f, g = norm2d(f), norm2d(g)
+    npad = [2 * f.shape[-2] - 1, 2 * f.shape[-1] - 1]
+    F = np.fft.fft2(f, s=npad, axes=(-2, -1))
+    G = np.fft.fft2(g, s=npad, axes=(-2, -1))
+    return np.fft.fftshift(np.real(np.fft.ifft2(F * np.conjugate(G), axes=(-2, -1))), axes=(-2, -1))
+
+
+def correlate2d_direct(f, g):
+    """The defining double sum of correlate2d (no FFT), for tiny tiles:
+    cc[i][j] = sum_{u,v} f[u + i-(F-1)][v + j-(L-1)] g[u][v]."""
+    f = np.asarray(f, dtype=np.float64)
+    g = np.asarray(g, dtype=np.float64)
+    Fn, Ln = f.shape
+    out = np.zeros((2 * Fn - 1, 2 * Ln - 1))
+    for i in range(2 * Fn - 1):
+        di = i - (Fn - 1)
+        u0, u1 = max(0, -di), min(Fn, Fn - di)
+        for j in range(2 * Ln - 1):
+            dj = j - (Ln - 1)
+            v0, v1 = max(0, -dj), min(Ln, Ln - dj)
+            out[i, j] = np.sum(f[u0 + di:u1 + di, v0 + dj:v1 + dj] * g[u0:u1, v0:v1])
+    return out

@@ -1,0 +1,117 @@
+"""GPU: two-dimensional cross-correlation (xcorr/signal/correlate.py:162-291)
+against the float64 oracle; tolerance 1e-5 of max|cc2| (float32 path)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_numpy as R          # noqa: E402
+from xcorr_amd import ops, signal          # noqa: E402
+from xcorr_amd._ffi import XcxError        # noqa: E402
+
+TOL = 1e-5
+
+
+def tiles_of(T, F, L, seed=0):
+    rng = np.random.default_rng(seed)
+    base = rng.standard_normal((F, L))
+    out = []
+    for t in range(T):
+        out.append(np.roll(base, (t, 3 * t), axis=(0, 1)) + 0.3 * rng.standard_normal((F, L)))
+    return np.abs(np.asarray(out)).astype(np.float32)      # spectrogram-like: non-negative
+
+
+@pytest.mark.parametrize('F,L', [(1, 1), (1, 7), (5, 1), (3, 4), (8, 16), (9, 33), (17, 100), (40, 129),
+                                 (64, 1000), (100, 257), (129, 64)])
+@pytest.mark.parametrize('normalize', [True, False])
+def test_full_output_matches_oracle(ctx, F, L, normalize):
+    t = tiles_of(3, F, L, seed=F * 1000 + L)
+    pairs = [(0, 1), (2, 0), (1, 1)]
+    peak, idx, full = ops.correlate2d(ctx, t, pairs, normalize=normalize, full=True)
+    assert full.shape == (3, 2 * F - 1, 2 * L - 1)
+    for p, (a, b) in enumerate(pairs):
+        ref = R.correlate2d(t[a], t[b], normalize=normalize)
+        scale = np.abs(ref).max()
+        assert np.abs(full[p] - ref).max() <= TOL * scale, (F, L, p)
+        # reported peak is the maximum of the output the GPU produced itself
+        assert peak[p] == full[p].max()
+        assert tuple(idx[p]) == np.unravel_index(np.argmax(full[p]), full[p].shape)
+        assert abs(peak[p] - ref.max()) <= TOL * scale
+
+
+def test_definition_small(ctx):
+    t = tiles_of(2, 4, 6, seed=5)
+    _, _, full = ops.correlate2d(ctx, t, [(0, 1)], normalize=False, full=True)
+    ref = R.correlate2d_direct(t[0], t[1])
+    assert np.abs(full[0] - ref).max() <= TOL * np.abs(ref).max()
+
+
+def test_autocorrelation_peak_and_known_shift(ctx):
+    F, L = 32, 400
+    rng = np.random.default_rng(2)
+    big = rng.standard_normal((F + 8, L + 40))
+    a = big[4:4 + F, 20:20 + L]
+    b = big[4 + 3:4 + 3 + F, 20 - 11:20 - 11 + L]           # b[u, v] = a[u + 3, v - 11]
+    t = np.stack([a, b]).astype(np.float32)
+    peak, idx = ops.correlate2d(ctx, t, [(0, 0), (0, 1), (1, 0)])
+    assert abs(peak[0] - 1.0) < 1e-5 and tuple(idx[0]) == (F - 1, L - 1)
+    # cc[i, j] = sum a[u + di, v + dj] b[u, v] peaks at (di, dj) = (3, -11)
+    assert tuple(idx[1]) == (F - 1 + 3, L - 1 - 11)
+    assert tuple(idx[2]) == (F - 1 - 3, L - 1 + 11)
+    assert peak[1] == pytest.approx(peak[2], rel=1e-5)
+
+
+def test_timelapse_tile_size_peak(ctx):
+    """BASELINE config 5 shape: 256 x 4096 spectrogram tiles; numpy finishes one
+    pair in a few seconds."""
+    F, L = 256, 4096
+    t = tiles_of(3, F, L, seed=9)
+    peak, idx = ops.correlate2d(ctx, t, [(0, 1), (0, 2), (2, 1)])
+    for p, (a, b) in enumerate([(0, 1), (0, 2)]):
+        ref = R.correlate2d(t[a], t[b])
+        assert abs(peak[p] - ref.max()) <= TOL * np.abs(ref).max()
+        ri = np.unravel_index(np.argmax(ref), ref.shape)
+        assert ref[tuple(idx[p])] >= ref.max() - 2 * TOL * np.abs(ref).max()
+        assert tuple(idx[p]) == ri
+    # antisymmetry of the index map: cc(b, a)[i, j] = cc(a, b)[2F-2-i, 2L-2-j]
+    p2, i2 = ops.correlate2d(ctx, t, [(1, 0)])
+    assert p2[0] == pytest.approx(peak[0], rel=2e-5)
+    assert tuple(i2[0]) == (2 * F - 2 - idx[0][0], 2 * L - 2 - idx[0][1])
+
+
+def test_device_resident_and_many_pairs(ctx):
+    F, L = 16, 200
+    t = tiles_of(12, F, L, seed=3)
+    pairs = [(i, j) for i in range(12) for j in range(12)]
+    d = ctx.array(t)
+    peak, idx, full = ops.correlate2d(ctx, d, pairs, full=True)
+    host = full.to_host() if hasattr(full, 'to_host') else full.numpy()
+    peak_h, idx_h = ops.correlate2d(ctx, t, pairs)
+    assert np.array_equal(peak, peak_h) and np.array_equal(idx, idx_h)
+    for p in (0, 17, 143):
+        a, b = pairs[p]
+        ref = R.correlate2d(t[a], t[b])
+        assert np.abs(host[p] - ref).max() <= TOL * np.abs(ref).max()
+
+
+def test_signal_mirror_and_errors(ctx):
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((2, 3, 10, 50)).astype(np.float32)
+    y = rng.standard_normal((2, 3, 10, 50)).astype(np.float32)
+    cc2 = signal.correlate2d(x, y)
+    assert cc2.shape == (2, 3, 19, 99) and cc2.dtype == np.float32
+    ref = R.correlate2d(x, y)
+    assert np.abs(cc2 - ref).max() <= TOL * np.abs(ref).max()
+    pk, ix = signal.correlate2d_peak(x, y)
+    assert pk.shape == (2, 3) and ix.shape == (2, 3, 2)
+    assert np.array_equal(pk, cc2.max(axis=(-2, -1)))
+    n2 = signal.norm2d(x)
+    assert np.abs(n2 - R.norm2d(x)).max() <= TOL * np.abs(R.norm2d(x)).max()
+    with pytest.raises(ValueError):
+        signal.correlate2d(x, y[:, :, :, :49])
+    with pytest.raises(XcxError):
+        ops.correlate2d(ctx, np.zeros((1, 257, 8), np.float32), [(0, 0)])
+    with pytest.raises(XcxError):
+        ops.correlate2d(ctx, np.zeros((1, 8, 4097), np.float32), [(0, 0)])
+    with pytest.raises(XcxError):
+        ops.correlate2d(ctx, np.ones((2, 8, 8), np.float32), [(0, 2)])

@@ -136,3 +136,21 @@ def test_timeshift_integer_delay_is_roll():
     y = R.timeshift(x, 4 / 50., 50.)
     # f grid uses fN rounded to integer Hz (fft.py:358): 25 Hz exactly here
     np.testing.assert_allclose(y, np.roll(x, 4, axis=-1), atol=1e-9)
+
+
+def test_correlate2d_restatement_is_the_defining_sum():
+    """correlate.py:230-246 (fft2 / conj / ifft2 / fftshift) == the double sum,
+    and == scipy.signal.correlate2d(mode='full')."""
+    import scipy.signal
+    rng = np.random.default_rng(8)
+    for F, L in [(1, 1), (2, 5), (4, 6), (7, 3)]:
+        f = rng.standard_normal((F, L))
+        g = rng.standard_normal((F, L))
+        a = R.correlate2d(f, g, normalize=False)
+        assert a.shape == (2 * F - 1, 2 * L - 1)
+        assert np.allclose(a, R.correlate2d_direct(f, g), atol=1e-12)
+        assert np.allclose(a, scipy.signal.correlate2d(f, g, mode='full'), atol=1e-12)
+    f = rng.standard_normal((3, 5, 8))
+    n = R.norm2d(f)
+    assert np.allclose((n ** 2).sum(axis=(-2, -1)), 1.0)
+    assert np.isclose(R.correlate2d(f, f)[..., 4, 7], 1.0).all()

@@ -1,0 +1,391 @@
+// cc2d.hip -- two-dimensional cross-correlation of tiles (xcorr/signal/correlate.py:
+// 162-291, norm2d of signal/normalize.py:95-155; the kernel of the timelapse script,
+// scripts/timelapse.py:243-268, which keeps only the peak value and its position).
+//
+//   cc[i][j] = sum_{a,b} f[a + i-(F-1)][b + j-(L-1)] g[a][b] / (||f||_F ||g||_F),
+//   i in [0, 2F-1), j in [0, 2L-1)
+//
+// computed as a zero-padded 2-D FFT product at (P1 x P2), P1 >= 2F-1, P2 = 2R >= 2L-1
+// (the reference pads to exactly (2F-1) x (2L-1) = 511 x 8191, 8191 being prime):
+//   forward, per tile : rows  R2C of length P2 (one 256-thread workgroup per row,
+//                              R = P2/2 complex points through LDS)
+//                       cols  complex FFT of length P1 for 16 adjacent columns,
+//                              scaled by 1/||tile||_F
+//   per tile pair     : cols  A conj(B), inverse FFT of length P1
+//                       rows  C2R of length P2, fftshift index map, optional full
+//                              output, block arg-max (first maximum in row-major
+//                              order, like numpy.argmax)
+// Built from the 256-thread Stockham stages of fft_device.h (table twiddles).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "../../include/xcx.h"
+#include "cc_kernels.h"
+#include "xcx_internal.h"
+
+using namespace xcx;
+
+#define HIP_TRY(expr)                                                     \
+  do {                                                                    \
+    hipError_t e_ = (expr);                                               \
+    if (e_ != hipSuccess)                                                 \
+      return set_err(e_ == hipErrorOutOfMemory ? XCX_ENOMEM : XCX_EHIP,   \
+                     "%s: %s (%s:%d)", #expr, hipGetErrorString(e_),      \
+                     __FILE__, __LINE__);                                 \
+  } while (0)
+
+namespace {
+
+constexpr int NT = 256;
+constexpr int CB = 16;
+
+struct G2 {
+  int F, L;        // tile shape
+  int P1, R;       // column transform length, complex row length (P2 = 2R)
+  int pitch;       // complex elements per spectrum row (>= R+1)
+};
+
+// sum of squares of a tile -> scale[t] = 1/||tile||_F (or 1)
+__global__ __launch_bounds__(NT) void k2d_norm(const float* __restrict__ tiles, long per, int normalize,
+                                               float* __restrict__ scale) {
+  __shared__ double red[NT];
+  const float* x = tiles + (size_t)blockIdx.x * per;
+  double acc = 0.0;
+  for (long i = threadIdx.x; i < per; i += NT) { double v = x[i]; acc += v * v; }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = NT / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) scale[blockIdx.x] = normalize ? (float)(1.0 / sqrt(red[0])) : 1.f;
+}
+
+// forward rows: grid (F, T)
+template <class RX>
+__global__ __launch_bounds__(NT) void k2d_rows_fwd(const float* __restrict__ tiles, G2 g, cf* __restrict__ S1,
+                                                   const cf* __restrict__ tw_sub, const cf* __restrict__ tw_unt) {
+  extern __shared__ __attribute__((aligned(16))) cf lds[];
+  constexpr int R = RX::L;
+  const int f = blockIdx.x, t = blockIdx.y;
+  const float* __restrict__ x = tiles + ((size_t)t * g.F + f) * g.L;
+  const int L = g.L;
+  auto in = [=](int m, int) -> cf {
+    const int i0 = 2 * m, i1 = i0 + 1;
+    return make_float2(i0 < L ? x[i0] : 0.f, i1 < L ? x[i1] : 0.f);
+  };
+  auto to_lds = [=](int p, int, cf v) { lds[p] = v; };
+  auto lds_ld = [=](int p, int) -> cf { return lds[p]; };
+  fft_stage<R, RX::R0, 1, 1, NT, false, false>(tw_sub, in, to_lds);
+  __syncthreads();
+  fft_stage<R, RX::R1, RX::R0, 1, NT, false, true>(tw_sub, lds_ld, to_lds);
+  if constexpr (RX::S >= 3) {
+    __syncthreads();
+    fft_stage<R, RX::R2, RX::R0 * RX::R1, 1, NT, false, true>(tw_sub, lds_ld, to_lds);
+  }
+  __syncthreads();
+  cf* __restrict__ dst = S1 + ((size_t)t * g.F + f) * g.pitch;
+  for (int k = threadIdx.x; k < R; k += NT) {
+    const cf u = lds[k];
+    const cf v = cconj(lds[k == 0 ? 0 : R - k]);
+    const cf sm = cadd(u, v), df = csub(u, v);
+    const cf e = cmul(tw_unt[k], df);
+    dst[k] = make_float2(0.5f * (sm.x + e.y), 0.5f * (sm.y - e.x));
+  }
+  if (threadIdx.x == 0) dst[R] = make_float2(lds[0].x - lds[0].y, 0.f);     // Nyquist bin (real)
+}
+
+// columns: grid (ceil((R+1)/16), T or pairs).  INV = false: forward transform of
+// the F rows of S1 (zero rows beyond), scaled; INV = true: A conj(B), inverse.
+template <class RX, bool INV>
+__global__ __launch_bounds__(NT) void k2d_cols(const cf* __restrict__ A, const cf* __restrict__ B2, G2 g,
+                                               const float* __restrict__ scale, const int2* __restrict__ pairs,
+                                               cf* __restrict__ out, const cf* __restrict__ tw_sub) {
+  extern __shared__ __attribute__((aligned(16))) cf lds[];
+  constexpr int P1 = RX::L;
+  const int col0 = blockIdx.x * CB;
+  const int q = blockIdx.y;
+  const int ncol = g.R + 1;
+  const int pitch = g.pitch;
+  if constexpr (!INV) {
+    const cf* __restrict__ src = A + (size_t)q * g.F * pitch;
+    cf* __restrict__ dst = out + (size_t)q * P1 * pitch;
+    const float sc = scale[q];
+    const int F = g.F;
+    auto in = [=](int f, int c) -> cf {
+      const int col = col0 + c;
+      return (f < F && col < ncol) ? src[(size_t)f * pitch + col] : make_float2(0.f, 0.f);
+    };
+    auto o = [=](int k1, int c, cf v) {
+      const int col = col0 + c;
+      if (col < ncol) dst[(size_t)k1 * pitch + col] = cscale(v, sc);
+    };
+    subfft<RX, CB, CB, NT, false, false>(lds, tw_sub, in, o);
+  } else {
+    const int2 pr = pairs[q];
+    const cf* __restrict__ a = A + (size_t)pr.x * P1 * pitch;
+    const cf* __restrict__ b = B2 + (size_t)pr.y * P1 * pitch;
+    cf* __restrict__ dst = out + (size_t)q * P1 * pitch;
+    auto in = [=](int k1, int c) -> cf {
+      const int col = col0 + c;
+      if (col >= ncol) return make_float2(0.f, 0.f);
+      const size_t o2 = (size_t)k1 * pitch + col;
+      return cmulc(a[o2], b[o2]);
+    };
+    auto o = [=](int m1, int c, cf v) {
+      const int col = col0 + c;
+      if (col < ncol) dst[(size_t)m1 * pitch + col] = v;
+    };
+    subfft<RX, CB, CB, NT, true, false>(lds, tw_sub, in, o);
+  }
+}
+
+// inverse rows + fftshift map + arg-max: grid (P1, pairs)
+template <class RX>
+__global__ __launch_bounds__(NT) void k2d_rows_inv(const cf* __restrict__ T2, G2 g, float inv_n,
+                                                   float* __restrict__ full, float* __restrict__ rowbest,
+                                                   long long* __restrict__ rowidx, const cf* __restrict__ tw_sub,
+                                                   const cf* __restrict__ tw_unt) {
+  extern __shared__ __attribute__((aligned(16))) cf lds[];
+  __shared__ float bv[NT];
+  __shared__ long long bi[NT];
+  constexpr int R = RX::L;
+  const int m1 = blockIdx.x, q = blockIdx.y;
+  const int P1 = g.P1, P2 = 2 * R;
+  const cf* __restrict__ src = T2 + ((size_t)q * P1 + m1) * g.pitch;
+  for (int k = threadIdx.x; k <= R; k += NT) lds[k] = src[k];
+  __syncthreads();
+  const int F = g.F, L = g.L;
+  const int OW = 2 * L - 1, OH = 2 * F - 1;
+  int i = m1 + F - 1;                       // shifted row
+  if (i >= P1) i -= P1;
+  const bool row_ok = i < OH;
+  auto in = [=](int k, int) -> cf {
+    const cf h = lds[k];
+    if (k == 0) { const float ny = lds[R].x; return make_float2(h.x + ny, h.x - ny); }
+    const cf hb = cconj(lds[R - k]);
+    const cf sm = cadd(h, hb), df = csub(h, hb);
+    const cf e = cmulc(df, tw_unt[k]);
+    return make_float2(sm.x - e.y, sm.y + e.x);
+  };
+  float best = -INFINITY;
+  long long besti = 0x7fffffffffffffffLL;
+  float* __restrict__ frow = full ? full + ((size_t)q * OH + i) * OW : nullptr;
+  auto out_f = [&](int m, int, cf u) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      int j = 2 * m + h + L - 1;             // shifted column
+      if (j >= P2) j -= P2;
+      if (row_ok && j < OW) {
+        const float v = (h ? u.y : u.x) * inv_n;
+        if (frow) frow[j] = v;
+        const long long fi = (long long)i * OW + j;
+        if (v > best || (v == best && fi < besti)) { best = v; besti = fi; }
+      }
+    }
+  };
+  // first stage reads the untangled spectrum from LDS (barrier before it is overwritten)
+  if constexpr (RX::S == 2) {
+    auto lds_st = [=](int p, int, cf v) { lds[p] = v; };
+    auto lds_ld = [=](int p, int) -> cf { return lds[p]; };
+    fft_stage<R, RX::R0, 1, 1, NT, true, true>(tw_sub, in, lds_st);
+    __syncthreads();
+    fft_stage<R, RX::R1, RX::R0, 1, NT, true, false>(tw_sub, lds_ld, out_f);
+  } else {
+    auto lds_st = [=](int p, int, cf v) { lds[p] = v; };
+    auto lds_ld = [=](int p, int) -> cf { return lds[p]; };
+    fft_stage<R, RX::R0, 1, 1, NT, true, true>(tw_sub, in, lds_st);
+    __syncthreads();
+    fft_stage<R, RX::R1, RX::R0, 1, NT, true, true>(tw_sub, lds_ld, lds_st);
+    __syncthreads();
+    fft_stage<R, RX::R2, RX::R0 * RX::R1, 1, NT, true, false>(tw_sub, lds_ld, out_f);
+  }
+  bv[threadIdx.x] = best;
+  bi[threadIdx.x] = besti;
+  __syncthreads();
+  for (int o = NT / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const float v2 = bv[threadIdx.x + o];
+      const long long i2 = bi[threadIdx.x + o];
+      if (v2 > bv[threadIdx.x] || (v2 == bv[threadIdx.x] && i2 < bi[threadIdx.x])) {
+        bv[threadIdx.x] = v2; bi[threadIdx.x] = i2;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { rowbest[(size_t)q * P1 + m1] = bv[0]; rowidx[(size_t)q * P1 + m1] = bi[0]; }
+}
+
+// final reduction over the P1 rows of a pair
+__global__ __launch_bounds__(NT) void k2d_peak(const float* __restrict__ rowbest, const long long* __restrict__ rowidx,
+                                               int P1, int OW, float* __restrict__ peak_val, int* __restrict__ peak_idx) {
+  __shared__ float bv[NT];
+  __shared__ long long bi[NT];
+  const int q = blockIdx.x;
+  float best = -INFINITY;
+  long long besti = 0x7fffffffffffffffLL;
+  for (int r = threadIdx.x; r < P1; r += NT) {
+    const float v = rowbest[(size_t)q * P1 + r];
+    const long long ix = rowidx[(size_t)q * P1 + r];
+    if (v > best || (v == best && ix < besti)) { best = v; besti = ix; }
+  }
+  bv[threadIdx.x] = best; bi[threadIdx.x] = besti;
+  __syncthreads();
+  for (int o = NT / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      const float v2 = bv[threadIdx.x + o]; const long long i2 = bi[threadIdx.x + o];
+      if (v2 > bv[threadIdx.x] || (v2 == bv[threadIdx.x] && i2 < bi[threadIdx.x])) { bv[threadIdx.x] = v2; bi[threadIdx.x] = i2; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    peak_val[q] = bv[0];
+    peak_idx[2 * q] = (int)(bi[0] / OW);
+    peak_idx[2 * q + 1] = (int)(bi[0] % OW);
+  }
+}
+
+void fill_tw(std::vector<float2>& v, int count, int L) {
+  v.resize(count);
+  for (int q = 0; q < count; ++q) {
+    const double th = -2.0 * M_PI * (double)(q % L) / (double)L;
+    v[q] = make_float2((float)cos(th), (float)sin(th));
+  }
+}
+
+template <class K> hipError_t big_lds(K kernel, size_t bytes) {
+  if (bytes <= 32768) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+struct Bufs {
+  DevBuf &S1, &S2, &T2, &misc;
+};
+
+// everything that depends on the row / column radices
+template <class RXR, class RXC>
+int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const int2* dpairs, int P, int normalize,
+          float* dpeak_val, int* dpeak_idx, float* dfull, const cf* tw_r, const cf* tw_u, const cf* tw_c) {
+  constexpr int R = RXR::L, P1 = RXC::L;
+  DevBuf &S1 = ctx->scratch[1], &S2 = ctx->scratch[2], &T2 = ctx->scratch[4], &misc = ctx->scratch[5];
+  int rc;
+  const size_t rowb = sizeof(cf) * (size_t)g.pitch;
+  if ((rc = S1.ensure(ctx, rowb * g.F * T))) return rc;
+  if ((rc = S2.ensure(ctx, rowb * P1 * T))) return rc;
+  const int PB = (int)std::max<size_t>(1, std::min<size_t>((size_t)P, ((size_t)512 << 20) / (rowb * P1)));
+  if ((rc = T2.ensure(ctx, rowb * P1 * PB))) return rc;
+  if ((rc = misc.ensure(ctx, sizeof(float) * T + (sizeof(float) + sizeof(long long)) * (size_t)P1 * PB + 64))) return rc;
+  float* scale = (float*)misc.ptr;
+  long long* rowidx = (long long*)((char*)misc.ptr + ((sizeof(float) * T + 15) & ~(size_t)15));
+  float* rowbest = (float*)(rowidx + (size_t)P1 * PB);
+  hipStream_t s = ctx->stream;
+  hipLaunchKernelGGL(k2d_norm, dim3(T), dim3(NT), 0, s, dtiles, (long)g.F * g.L, normalize, scale);
+  const size_t lds_r = sizeof(cf) * (R + 1);
+  HIP_TRY(big_lds(k2d_rows_fwd<RXR>, lds_r));
+  HIP_TRY(big_lds(k2d_rows_inv<RXR>, lds_r));
+  hipLaunchKernelGGL(k2d_rows_fwd<RXR>, dim3(g.F, T), dim3(NT), lds_r, s, dtiles, g, (cf*)S1.ptr, tw_r, tw_u);
+  const size_t lds_c = (RXC::S > 1) ? sizeof(cf) * P1 * CB : 0;
+  HIP_TRY(big_lds((k2d_cols<RXC, false>), lds_c));
+  HIP_TRY(big_lds((k2d_cols<RXC, true>), lds_c));
+  const int ncb = (g.R + 1 + CB - 1) / CB;
+  hipLaunchKernelGGL((k2d_cols<RXC, false>), dim3(ncb, T), dim3(NT), lds_c, s, (const cf*)S1.ptr, (const cf*)nullptr, g,
+                     scale, (const int2*)nullptr, (cf*)S2.ptr, tw_c);
+  HIP_TRY(hipGetLastError());
+  const float inv_n = 1.0f / ((float)P1 * (float)(2 * R));
+  const size_t OH = 2 * (size_t)g.F - 1, OW = 2 * (size_t)g.L - 1;
+  for (int p0 = 0; p0 < P; p0 += PB) {
+    const int cnt = std::min(PB, P - p0);
+    hipLaunchKernelGGL((k2d_cols<RXC, true>), dim3(ncb, cnt), dim3(NT), lds_c, s, (const cf*)S2.ptr, (const cf*)S2.ptr, g,
+                       (const float*)nullptr, dpairs + p0, (cf*)T2.ptr, tw_c);
+    hipLaunchKernelGGL(k2d_rows_inv<RXR>, dim3(P1, cnt), dim3(NT), lds_r, s, (const cf*)T2.ptr, g, inv_n,
+                       dfull ? dfull + (size_t)p0 * OH * OW : nullptr, rowbest, rowidx, tw_r, tw_u);
+    hipLaunchKernelGGL(k2d_peak, dim3(cnt), dim3(NT), 0, s, rowbest, rowidx, P1, (int)OW, dpeak_val + p0,
+                       dpeak_idx + 2 * (size_t)p0);
+    HIP_TRY(hipGetLastError());
+  }
+  return XCX_OK;
+}
+
+template <class RXR>
+int run2d_cols(int P1, xcx_ctx* ctx, const float* dt, int T, const G2& g, const int2* dp, int P, int nrm, float* pv,
+               int* pi, float* full, const cf* tr, const cf* tu, const cf* tc) {
+  switch (P1) {
+    case 16: return run2d<RXR, Radices<4, 4>>(ctx, dt, T, g, dp, P, nrm, pv, pi, full, tr, tu, tc);
+    case 32: return run2d<RXR, Radices<8, 4>>(ctx, dt, T, g, dp, P, nrm, pv, pi, full, tr, tu, tc);
+    case 64: return run2d<RXR, Radices<8, 8>>(ctx, dt, T, g, dp, P, nrm, pv, pi, full, tr, tu, tc);
+    case 128: return run2d<RXR, Radices<8, 4, 4>>(ctx, dt, T, g, dp, P, nrm, pv, pi, full, tr, tu, tc);
+    case 256: return run2d<RXR, Radices<8, 8, 4>>(ctx, dt, T, g, dp, P, nrm, pv, pi, full, tr, tu, tc);
+    default: return run2d<RXR, Radices<8, 8, 8>>(ctx, dt, T, g, dp, P, nrm, pv, pi, full, tr, tu, tc);
+  }
+}
+
+}  // namespace
+
+extern "C" int xcx_cc2d(xcx_ctx* ctx, const float* tiles, int T, int F, int L, const int* pairs, int P,
+                        int normalize, float* peak_val, int* peak_idx, float* full, int on_device) {
+  if (!ctx || !tiles || !pairs || !peak_val || !peak_idx) return set_err(XCX_EINVAL, "null argument");
+  if (T < 1 || F < 1 || L < 1 || P < 1) return set_err(XCX_EINVAL, "T, F, L, P must be >= 1");
+  for (int i = 0; i < P; ++i)
+    if (pairs[2 * i] < 0 || pairs[2 * i] >= T || pairs[2 * i + 1] < 0 || pairs[2 * i + 1] >= T)
+      return set_err(XCX_EINVAL, "pair %d outside [0,%d)", i, T);
+  static const int kP1[] = {16, 32, 64, 128, 256, 512};
+  static const int kR[] = {32, 64, 128, 256, 512, 1024, 2048, 4096};
+  int P1 = 0, R = 0;
+  for (int v : kP1) if (v >= 2 * F - 1) { P1 = v; break; }
+  for (int v : kR) if (2 * v >= 2 * L - 1) { R = v; break; }
+  if (!P1 || !R)
+    return set_err(XCX_EUNSUPPORTED, "tile %d x %d too large (max 256 x 4096)", F, L);
+  HIP_TRY(hipSetDevice(ctx->device));
+  G2 g{F, L, P1, R, (R + 1 + 15) / 16 * 16};
+  std::vector<float2> tr, tu, tc;
+  fill_tw(tr, R, R);
+  fill_tw(tu, R, 2 * R);
+  fill_tw(tc, P1, P1);
+  int rc;
+  DevBuf& tw = ctx->scratch[3];
+  const size_t ntw = (size_t)2 * R + P1;
+  const size_t OH = 2 * (size_t)F - 1, OW = 2 * (size_t)L - 1;
+  const size_t tile_b = sizeof(float) * (size_t)T * F * L;
+  size_t extra = sizeof(int2) * (size_t)P + sizeof(float) * P + sizeof(int) * 2 * (size_t)P + 64;
+  if (!on_device) extra += tile_b + (full ? sizeof(float) * (size_t)P * OH * OW : 0);
+  if ((rc = tw.ensure(ctx, sizeof(cf) * ntw + extra + 256))) return rc;
+  cf* dtw = (cf*)tw.ptr;
+  char* cur = (char*)(dtw + ntw);
+  auto carve = [&](size_t bytes) { char* r = cur; cur += (bytes + 63) & ~(size_t)63; return r; };
+  int2* dpairs = (int2*)carve(sizeof(int2) * P);
+  float* dpv = (float*)carve(sizeof(float) * P);
+  int* dpi = (int*)carve(sizeof(int) * 2 * P);
+  const float* dtiles = tiles;
+  float* dfull = full;
+  if (!on_device) {
+    float* dt = (float*)carve(tile_b);
+    HIP_TRY(hipMemcpyAsync(dt, tiles, tile_b, hipMemcpyHostToDevice, ctx->stream));
+    dtiles = dt;
+    if (full) dfull = (float*)carve(sizeof(float) * (size_t)P * OH * OW);
+  }
+  HIP_TRY(hipMemcpyAsync(dtw, tr.data(), sizeof(cf) * R, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(dtw + R, tu.data(), sizeof(cf) * R, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(dtw + 2 * R, tc.data(), sizeof(cf) * P1, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(dpairs, pairs, sizeof(int2) * P, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  const cf *ptr_r = dtw, *ptr_u = dtw + R, *ptr_c = dtw + 2 * R;
+  switch (R) {
+    case 32: rc = run2d_cols<Radices<8, 4>>(P1, ctx, dtiles, T, g, dpairs, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
+    case 64: rc = run2d_cols<Radices<8, 8>>(P1, ctx, dtiles, T, g, dpairs, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
+    case 128: rc = run2d_cols<Radices<8, 4, 4>>(P1, ctx, dtiles, T, g, dpairs, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
+    case 256: rc = run2d_cols<Radices<16, 16>>(P1, ctx, dtiles, T, g, dpairs, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
+    case 512: rc = run2d_cols<Radices<8, 8, 8>>(P1, ctx, dtiles, T, g, dpairs, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
+    case 1024: rc = run2d_cols<Radices<16, 8, 8>>(P1, ctx, dtiles, T, g, dpairs, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
+    case 2048: rc = run2d_cols<Radices<16, 16, 8>>(P1, ctx, dtiles, T, g, dpairs, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
+    default: rc = run2d_cols<Radices<16, 16, 16>>(P1, ctx, dtiles, T, g, dpairs, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
+  }
+  if (rc) return rc;
+  HIP_TRY(hipMemcpyAsync(peak_val, dpv, sizeof(float) * P, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(peak_idx, dpi, sizeof(int) * 2 * P, hipMemcpyDeviceToHost, ctx->stream));
+  if (!on_device && full)
+    HIP_TRY(hipMemcpyAsync(full, dfull, sizeof(float) * (size_t)P * OH * OW, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return XCX_OK;
+}

@@ -176,3 +176,28 @@ def snr(ctx, x, signal, noise):
     a = np.empty(batch, np.int32)
     check(_ffi.lib().xcx_snr(ctx.handle, ptr(src), batch, nn, ptr(sm), ptr(nm), ptr(s), ptr(n), ptr(a), dev))
     return s.reshape(lead), n.reshape(lead), a.reshape(lead)
+
+
+def correlate2d(ctx, tiles, pairs, normalize=True, full=False):
+    """2-D cross-correlation of tile pairs (xcorr/signal/correlate.py:162-291).
+    tiles: [T, F, L] float32 (numpy or DeviceArray); pairs: [P, 2] tile indices.
+    Returns (peak, index[P, 2]) and, with full=True, also cc2[P, 2F-1, 2L-1]."""
+    ctx = _ctx(ctx, tiles)
+    if isinstance(tiles, DeviceArray):
+        src, dev = tiles, 1
+    else:
+        src, dev = np.ascontiguousarray(tiles, dtype=np.float32), 0
+    if len(src.shape) != 3:
+        raise ValueError('tiles should be [T, F, L]')
+    T, F, L = (int(v) for v in src.shape)
+    pr = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    P = pr.shape[0]
+    peak = np.empty(P, np.float32)
+    idx = np.empty((P, 2), np.int32)
+    out = None
+    if full:
+        shp = (P, 2 * F - 1, 2 * L - 1)
+        out = ctx.empty(shp) if dev else np.empty(shp, np.float32)
+    check(_ffi.lib().xcx_cc2d(ctx.handle, ptr(src), T, F, L, ptr(pr), P, int(bool(normalize)), ptr(peak), ptr(idx),
+                              ptr(out) if out is not None else None, dev))
+    return (peak, idx, out) if full else (peak, idx)
