@@ -41,67 +41,78 @@ namespace {
 constexpr int NT = 256;
 constexpr int CB = 16;
 
+// LDS index padding of the row kernels: one extra slot per 16 keeps the stride-16 /
+// stride-256 stage writes off a single bank group
+__device__ __forceinline__ int rp(int p) { return p + (p >> 4); }
+constexpr int rp_c(int p) { return p + (p >> 4); }
+
 struct G2 {
   int F, L;        // tile shape
   int P1, R;       // column transform length, complex row length (P2 = 2R)
   int pitch;       // complex elements per spectrum row (>= R+1)
 };
 
-// sum of squares of a tile -> scale[t] = 1/||tile||_F (or 1)
-__global__ __launch_bounds__(NT) void k2d_norm(const float* __restrict__ tiles, long per, int normalize,
-                                               float* __restrict__ scale) {
-  __shared__ double red[NT];
-  const float* x = tiles + (size_t)blockIdx.x * per;
-  double acc = 0.0;
-  for (long i = threadIdx.x; i < per; i += NT) { double v = x[i]; acc += v * v; }
-  red[threadIdx.x] = acc;
-  __syncthreads();
-  for (int o = NT / 2; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) scale[blockIdx.x] = normalize ? (float)(1.0 / sqrt(red[0])) : 1.f;
-}
-
 // forward rows: grid (F, T)
 template <class RX>
 __global__ __launch_bounds__(NT) void k2d_rows_fwd(const float* __restrict__ tiles, G2 g, cf* __restrict__ S1,
-                                                   const cf* __restrict__ tw_sub, const cf* __restrict__ tw_unt) {
+                                                   double* __restrict__ rowss, const cf* __restrict__ tw_sub,
+                                                   const cf* __restrict__ tw_unt) {
   extern __shared__ __attribute__((aligned(16))) cf lds[];
+  __shared__ double red[NT / 64];
   constexpr int R = RX::L;
   const int f = blockIdx.x, t = blockIdx.y;
   const float* __restrict__ x = tiles + ((size_t)t * g.F + f) * g.L;
   const int L = g.L;
-  auto in = [=](int m, int) -> cf {
+  float ss = 0.f;                              // sum of squares of this thread's samples (norm2d)
+  auto in = [&ss, x, L](int m, int) -> cf {
     const int i0 = 2 * m, i1 = i0 + 1;
-    return make_float2(i0 < L ? x[i0] : 0.f, i1 < L ? x[i1] : 0.f);
+    const cf v = make_float2(i0 < L ? x[i0] : 0.f, i1 < L ? x[i1] : 0.f);
+    ss = fmaf(v.x, v.x, fmaf(v.y, v.y, ss));
+    return v;
   };
-  auto to_lds = [=](int p, int, cf v) { lds[p] = v; };
-  auto lds_ld = [=](int p, int) -> cf { return lds[p]; };
-  fft_stage<R, RX::R0, 1, 1, NT, false, false>(tw_sub, in, to_lds);
+  auto to_lds = [=](int p, int, cf v) { lds[rp(p)] = v; };
+  auto lds_ld = [=](int p, int) -> cf { return lds[rp(p)]; };
+  // one base twiddle per butterfly, loaded up front; its powers are formed by multiplication
+  typename StageGeom<R, RX::R1, RX::R0, 1, NT>::Base b1;
+  typename StageGeom<R, RX::R2, RX::R0 * RX::R1, 1, NT>::Base b2;
+  stage_tw_base<R, RX::R1, RX::R0, 1, NT>(tw_sub, b1);
+  if constexpr (RX::S >= 3) stage_tw_base<R, RX::R2, RX::R0 * RX::R1, 1, NT>(tw_sub, b2);
+  typename StageGeom<R, RX::R0, 1, 1, NT>::Base b0;
+  fft_stage_c<R, RX::R0, 1, 1, NT, false, false, false>(b0, in, to_lds);
+  {   // row total in double; the column pass adds the rows of a tile
+    double acc = ss;
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  }
   __syncthreads();
-  fft_stage<R, RX::R1, RX::R0, 1, NT, false, true>(tw_sub, lds_ld, to_lds);
+  fft_stage_c<R, RX::R1, RX::R0, 1, NT, false, true, false>(b1, lds_ld, to_lds);
   if constexpr (RX::S >= 3) {
     __syncthreads();
-    fft_stage<R, RX::R2, RX::R0 * RX::R1, 1, NT, false, true>(tw_sub, lds_ld, to_lds);
+    fft_stage_c<R, RX::R2, RX::R0 * RX::R1, 1, NT, false, true, false>(b2, lds_ld, to_lds);
   }
   __syncthreads();
   cf* __restrict__ dst = S1 + ((size_t)t * g.F + f) * g.pitch;
   for (int k = threadIdx.x; k < R; k += NT) {
-    const cf u = lds[k];
-    const cf v = cconj(lds[k == 0 ? 0 : R - k]);
+    const cf u = lds[rp(k)];
+    const cf v = cconj(lds[rp(k == 0 ? 0 : R - k)]);
     const cf sm = cadd(u, v), df = csub(u, v);
     const cf e = cmul(tw_unt[k], df);
     dst[k] = make_float2(0.5f * (sm.x + e.y), 0.5f * (sm.y - e.x));
   }
-  if (threadIdx.x == 0) dst[R] = make_float2(lds[0].x - lds[0].y, 0.f);     // Nyquist bin (real)
+  if (threadIdx.x == 0) {
+    dst[R] = make_float2(lds[0].x - lds[0].y, 0.f);     // Nyquist bin (real)
+    double tot = 0.0;
+    for (int w = 0; w < NT / 64; ++w) tot += red[w];
+    rowss[(size_t)t * g.F + f] = tot;
+  }
 }
 
 // columns: grid (ceil((R+1)/16), T or pairs).  INV = false: forward transform of
 // the F rows of S1 (zero rows beyond), scaled; INV = true: A conj(B), inverse.
 template <class RX, bool INV>
 __global__ __launch_bounds__(NT) void k2d_cols(const cf* __restrict__ A, const cf* __restrict__ B2, G2 g,
-                                               const float* __restrict__ scale, const int2* __restrict__ pairs,
+                                               const double* __restrict__ rowss, int normalize,
+                                               const int2* __restrict__ pairs,
                                                cf* __restrict__ out, const cf* __restrict__ tw_sub) {
   extern __shared__ __attribute__((aligned(16))) cf lds[];
   constexpr int P1 = RX::L;
@@ -112,8 +123,18 @@ __global__ __launch_bounds__(NT) void k2d_cols(const cf* __restrict__ A, const c
   if constexpr (!INV) {
     const cf* __restrict__ src = A + (size_t)q * g.F * pitch;
     cf* __restrict__ dst = out + (size_t)q * P1 * pitch;
-    const float sc = scale[q];
     const int F = g.F;
+    float sc = 1.f;
+    if (normalize) {                       // 1/||tile||_F from the row sums (same order in every workgroup)
+      __shared__ double red[NT];
+      red[threadIdx.x] = (int)threadIdx.x < F ? rowss[(size_t)q * F + threadIdx.x] : 0.0;   // F <= NT
+      __syncthreads();
+      for (int o = NT / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+      }
+      sc = (float)(1.0 / sqrt(red[0]));
+    }
     auto in = [=](int f, int c) -> cf {
       const int col = col0 + c;
       return (f < F && col < ncol) ? src[(size_t)f * pitch + col] : make_float2(0.f, 0.f);
@@ -155,7 +176,26 @@ __global__ __launch_bounds__(NT) void k2d_rows_inv(const cf* __restrict__ T2, G2
   const int m1 = blockIdx.x, q = blockIdx.y;
   const int P1 = g.P1, P2 = 2 * R;
   const cf* __restrict__ src = T2 + ((size_t)q * P1 + m1) * g.pitch;
-  for (int k = threadIdx.x; k <= R; k += NT) lds[k] = src[k];
+  typename StageGeom<R, RX::R1, RX::R0, 1, NT>::Base b1;
+  typename StageGeom<R, RX::R2, RX::R0 * RX::R1, 1, NT>::Base b2;
+  stage_tw_base<R, RX::R1, RX::R0, 1, NT>(tw_sub, b1);
+  if constexpr (RX::S >= 3) stage_tw_base<R, RX::R2, RX::R0 * RX::R1, 1, NT>(tw_sub, b2);
+  {   // all loads of the row in flight at once, then the LDS writes
+    constexpr int NL = (R + NT - 1) / NT;
+    cf stage[NL];
+#pragma unroll
+    for (int it = 0; it < NL; ++it) {
+      const int k = threadIdx.x + it * NT;
+      stage[it] = (R % NT == 0 || k < R) ? src[k] : make_float2(0.f, 0.f);
+    }
+    const cf ny = threadIdx.x == 0 ? src[R] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < NL; ++it) {
+      const int k = threadIdx.x + it * NT;
+      if (R % NT == 0 || k < R) lds[rp(k)] = stage[it];
+    }
+    if (threadIdx.x == 0) lds[rp(R)] = ny;
+  }
   __syncthreads();
   const int F = g.F, L = g.L;
   const int OW = 2 * L - 1, OH = 2 * F - 1;
@@ -163,47 +203,46 @@ __global__ __launch_bounds__(NT) void k2d_rows_inv(const cf* __restrict__ T2, G2
   if (i >= P1) i -= P1;
   const bool row_ok = i < OH;
   auto in = [=](int k, int) -> cf {
-    const cf h = lds[k];
-    if (k == 0) { const float ny = lds[R].x; return make_float2(h.x + ny, h.x - ny); }
-    const cf hb = cconj(lds[R - k]);
+    const cf h = lds[rp(k)];
+    if (k == 0) { const float ny = lds[rp(R)].x; return make_float2(h.x + ny, h.x - ny); }
+    const cf hb = cconj(lds[rp(R - k)]);
     const cf sm = cadd(h, hb), df = csub(h, hb);
     const cf e = cmulc(df, tw_unt[k]);
     return make_float2(sm.x - e.y, sm.y + e.x);
   };
   float best = -INFINITY;
-  long long besti = 0x7fffffffffffffffLL;
-  float* __restrict__ frow = full ? full + ((size_t)q * OH + i) * OW : nullptr;
+  int bestj = 0x7fffffff;                      // column of the row maximum (first occurrence)
+  float* __restrict__ frow = (full && row_ok) ? full + ((size_t)q * OH + i) * OW : nullptr;
   auto out_f = [&](int m, int, cf u) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       int j = 2 * m + h + L - 1;             // shifted column
       if (j >= P2) j -= P2;
-      if (row_ok && j < OW) {
-        const float v = (h ? u.y : u.x) * inv_n;
-        if (frow) frow[j] = v;
-        const long long fi = (long long)i * OW + j;
-        if (v > best || (v == best && fi < besti)) { best = v; besti = fi; }
-      }
+      const bool ok = row_ok && j < OW;
+      const float v = (h ? u.y : u.x) * inv_n;
+      if (frow && ok) frow[j] = v;
+      const bool better = ok && (v > best || (v == best && j < bestj));
+      best = better ? v : best;
+      bestj = better ? j : bestj;
     }
   };
   // first stage reads the untangled spectrum from LDS (barrier before it is overwritten)
+  auto lds_st = [=](int p, int, cf v) { lds[rp(p)] = v; };
+  auto lds_ld = [=](int p, int) -> cf { return lds[rp(p)]; };
+  typename StageGeom<R, RX::R0, 1, 1, NT>::Base b0;
   if constexpr (RX::S == 2) {
-    auto lds_st = [=](int p, int, cf v) { lds[p] = v; };
-    auto lds_ld = [=](int p, int) -> cf { return lds[p]; };
-    fft_stage<R, RX::R0, 1, 1, NT, true, true>(tw_sub, in, lds_st);
+    fft_stage_c<R, RX::R0, 1, 1, NT, true, true, false>(b0, in, lds_st);
     __syncthreads();
-    fft_stage<R, RX::R1, RX::R0, 1, NT, true, false>(tw_sub, lds_ld, out_f);
+    fft_stage_c<R, RX::R1, RX::R0, 1, NT, true, false, false>(b1, lds_ld, out_f);
   } else {
-    auto lds_st = [=](int p, int, cf v) { lds[p] = v; };
-    auto lds_ld = [=](int p, int) -> cf { return lds[p]; };
-    fft_stage<R, RX::R0, 1, 1, NT, true, true>(tw_sub, in, lds_st);
+    fft_stage_c<R, RX::R0, 1, 1, NT, true, true, false>(b0, in, lds_st);
     __syncthreads();
-    fft_stage<R, RX::R1, RX::R0, 1, NT, true, true>(tw_sub, lds_ld, lds_st);
+    fft_stage_c<R, RX::R1, RX::R0, 1, NT, true, true, false>(b1, lds_ld, lds_st);
     __syncthreads();
-    fft_stage<R, RX::R2, RX::R0 * RX::R1, 1, NT, true, false>(tw_sub, lds_ld, out_f);
+    fft_stage_c<R, RX::R2, RX::R0 * RX::R1, 1, NT, true, false, false>(b2, lds_ld, out_f);
   }
   bv[threadIdx.x] = best;
-  bi[threadIdx.x] = besti;
+  bi[threadIdx.x] = bestj == 0x7fffffff ? 0x7fffffffffffffffLL : (long long)i * OW + bestj;
   __syncthreads();
   for (int o = NT / 2; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) {
@@ -274,31 +313,33 @@ int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const int2* dpa
   const size_t rowb = sizeof(cf) * (size_t)g.pitch;
   if ((rc = S1.ensure(ctx, rowb * g.F * T))) return rc;
   if ((rc = S2.ensure(ctx, rowb * P1 * T))) return rc;
+  // pairs per pass: 512 MiB of intermediate T2 (larger passes amortise the launch tails; keeping
+  // T2 inside the 256 MiB Infinity Cache measured 5-10% slower, not faster)
   const int PB = (int)std::max<size_t>(1, std::min<size_t>((size_t)P, ((size_t)512 << 20) / (rowb * P1)));
   if ((rc = T2.ensure(ctx, rowb * P1 * PB))) return rc;
-  if ((rc = misc.ensure(ctx, sizeof(float) * T + (sizeof(float) + sizeof(long long)) * (size_t)P1 * PB + 64))) return rc;
-  float* scale = (float*)misc.ptr;
-  long long* rowidx = (long long*)((char*)misc.ptr + ((sizeof(float) * T + 15) & ~(size_t)15));
+  if ((rc = misc.ensure(ctx, sizeof(double) * (size_t)T * g.F + (sizeof(float) + sizeof(long long)) * (size_t)P1 * PB + 64)))
+    return rc;
+  double* rowss = (double*)misc.ptr;
+  long long* rowidx = (long long*)(rowss + (size_t)T * g.F);
   float* rowbest = (float*)(rowidx + (size_t)P1 * PB);
   hipStream_t s = ctx->stream;
-  hipLaunchKernelGGL(k2d_norm, dim3(T), dim3(NT), 0, s, dtiles, (long)g.F * g.L, normalize, scale);
-  const size_t lds_r = sizeof(cf) * (R + 1);
+  const size_t lds_r = sizeof(cf) * (rp_c(R) + 1);
   HIP_TRY(big_lds(k2d_rows_fwd<RXR>, lds_r));
   HIP_TRY(big_lds(k2d_rows_inv<RXR>, lds_r));
-  hipLaunchKernelGGL(k2d_rows_fwd<RXR>, dim3(g.F, T), dim3(NT), lds_r, s, dtiles, g, (cf*)S1.ptr, tw_r, tw_u);
+  hipLaunchKernelGGL(k2d_rows_fwd<RXR>, dim3(g.F, T), dim3(NT), lds_r, s, dtiles, g, (cf*)S1.ptr, rowss, tw_r, tw_u);
   const size_t lds_c = (RXC::S > 1) ? sizeof(cf) * P1 * CB : 0;
   HIP_TRY(big_lds((k2d_cols<RXC, false>), lds_c));
   HIP_TRY(big_lds((k2d_cols<RXC, true>), lds_c));
   const int ncb = (g.R + 1 + CB - 1) / CB;
   hipLaunchKernelGGL((k2d_cols<RXC, false>), dim3(ncb, T), dim3(NT), lds_c, s, (const cf*)S1.ptr, (const cf*)nullptr, g,
-                     scale, (const int2*)nullptr, (cf*)S2.ptr, tw_c);
+                     (const double*)rowss, normalize, (const int2*)nullptr, (cf*)S2.ptr, tw_c);
   HIP_TRY(hipGetLastError());
   const float inv_n = 1.0f / ((float)P1 * (float)(2 * R));
   const size_t OH = 2 * (size_t)g.F - 1, OW = 2 * (size_t)g.L - 1;
   for (int p0 = 0; p0 < P; p0 += PB) {
     const int cnt = std::min(PB, P - p0);
     hipLaunchKernelGGL((k2d_cols<RXC, true>), dim3(ncb, cnt), dim3(NT), lds_c, s, (const cf*)S2.ptr, (const cf*)S2.ptr, g,
-                       (const float*)nullptr, dpairs + p0, (cf*)T2.ptr, tw_c);
+                       (const double*)nullptr, 0, dpairs + p0, (cf*)T2.ptr, tw_c);
     hipLaunchKernelGGL(k2d_rows_inv<RXR>, dim3(P1, cnt), dim3(NT), lds_r, s, (const cf*)T2.ptr, g, inv_n,
                        dfull ? dfull + (size_t)p0 * OH * OW : nullptr, rowbest, rowidx, tw_r, tw_u);
     hipLaunchKernelGGL(k2d_peak, dim3(cnt), dim3(NT), 0, s, rowbest, rowidx, P1, (int)OW, dpeak_val + p0,
