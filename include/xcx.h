@@ -197,6 +197,28 @@ int xcx_cc2d(xcx_ctx* ctx, const float* tiles, int T, int F, int L,
              const int* pairs, int P, int normalize, float* peak_val,
              int* peak_idx, float* full, int on_device);
 
+/* Discrete Fourier transforms of ARBITRARY length along the last axis with numpy.fft
+ * conventions -- the kernels of xcorr/signal/fft.py (fft :111-113, ifft :239-241,
+ * rfft :367-374, irfft :487-494; fftshift / coordinates stay with the caller).
+ * Complex data is interleaved float32 (re, im).
+ *   xcx_fft / xcx_ifft : in [batch][n] complex -> out [batch][n] complex (ifft scales 1/n)
+ *   xcx_rfft           : x [batch][size] real  -> out [batch][n/2+1] complex with
+ *                        n = size - (size & 1)  (fft.py:357 drops an odd last sample)
+ *   xcx_irfft          : in [batch][m] complex -> x [batch][2(m-1)] real  (fft.py:475)
+ * Bluestein's chirp convolution on the cross-correlation engine; supported while
+ * 2 (nin + nout - 1) - 1 <= 737280 (n <= 184320 complex, n <= 245760 real). */
+int xcx_fft(xcx_ctx* ctx, const float* in, float* out, long batch, long n, int on_device);
+int xcx_ifft(xcx_ctx* ctx, const float* in, float* out, long batch, long n, int on_device);
+int xcx_rfft(xcx_ctx* ctx, const float* x, float* out, long batch, long size, int on_device);
+int xcx_irfft(xcx_ctx* ctx, const float* in, float* x, long batch, long m, int on_device);
+
+/* Analytic signal of every row, scipy.signal.hilbert semantics (xcorr/signal/hilbert.py:69):
+ * x [batch][n] real -> out [batch][n] complex, or with envelope != 0 its modulus
+ * [batch][n] real (hilbert.py:120; the `envelope=True` branch of signal/snr.py:109).
+ * Any n >= 2 with 3n <= 737280. */
+int xcx_hilbert(xcx_ctx* ctx, const float* x, float* out, long batch, long n, int envelope,
+                int on_device);
+
 /* ---- multi-GPU time-stack reduction (RCCL over xGMI) --------------------
  * One communicator per process/GPU.  id_bytes is the 128-byte ncclUniqueId
  * created by rank 0 with xcx_comm_unique_id() and distributed by the host

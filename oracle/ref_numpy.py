@@ -513,3 +513,65 @@ def correlate2d_direct(f, g):
             v0, v1 = max(0, -dj), min(Ln, Ln - dj)
             out[i, j] = np.sum(f[u0 + di:u1 + di, v0 + dj:v1 + dj] * g[u0:u1, v0:v1])
     return out
+
+
+# -- a6: labelled FFT kernels (xcorr/signal/fft.py) ---------------------------
+def fft_kernel(f):
+    """`_fft` of signal/fft.py:111-113: fftshift(fft(f, n=size)) in complex128."""
+    f = np.asarray(f).astype(np.complex128)
+    return np.fft.fftshift(np.fft.fft(f, n=f.shape[-1], axis=-1), axes=-1)
+
+
+def ifft_kernel(F):
+    """`_ifft` of signal/fft.py:239-241: ifft(fftshift(F), n=size)."""
+    F = np.fft.fftshift(np.asarray(F).astype(np.complex128), axes=-1)
+    return np.fft.ifft(F, n=F.shape[-1], axis=-1)
+
+
+def rfft_kernel(x):
+    """signal/fft.py:357, 367-374: rfft over n = size - (size & 1) samples, float64."""
+    x = np.asarray(x, dtype=np.float64)
+    n = x.shape[-1] - 1 if x.shape[-1] & 1 else x.shape[-1]
+    return np.fft.rfft(x, n=n, axis=-1)
+
+
+def irfft_kernel(X):
+    """signal/fft.py:475, 487-494: irfft with n = 2 * size - 2."""
+    return np.fft.irfft(np.asarray(X).astype(np.complex128), n=None, axis=-1)
+
+
+def fft_freq(size, delta):
+    """frequency coordinate of `fft` (signal/fft.py:104-108)."""
+    return np.fft.fftshift(np.fft.fftfreq(size, d=np.round(abs(delta), decimals=10)))
+
+
+def rfft_freq(coord):
+    """frequency coordinate of `rfft` (signal/fft.py:357-359): integer-rounded Nyquist."""
+    coord = np.asarray(coord, dtype=np.float64)
+    n = coord.size - 1 if coord.size & 1 else coord.size
+    fN = np.round(n // 2 / (coord[n - 1] - coord[0]), decimals=0)
+    return np.linspace(0., fN, n // 2 + 1)
+
+
+def irfft_time(freq, zero=0.0):
+    """time coordinate of `irfft` (signal/fft.py:475-479)."""
+    n = 2 * len(freq) - 2
+    return np.linspace(0., (n - 1) / 2 / freq[-1], n) + zero
+
+
+def hilbert(x):
+    """scipy.signal.hilbert along the last axis (xcorr/signal/hilbert.py:69), float64."""
+    import scipy.signal
+    return scipy.signal.hilbert(np.asarray(x, dtype=np.float64), axis=-1)
+
+
+def envelope(x):
+    """|hilbert(x)| (xcorr/signal/hilbert.py:120)."""
+    return np.abs(hilbert(x))
+
+
+def snr_envelope(x, signal, noise):
+    """snr with envelope=True (signal/snr.py:107-113): noise rms of x, peak of |hilbert(x)|."""
+    _, _, n, _ = snr(x, signal, noise)
+    _, s, _, idx = snr(envelope(x), signal, noise)
+    return s / n, s, n, idx

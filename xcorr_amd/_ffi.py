@@ -73,6 +73,11 @@ SIGNATURES = {
     'xcx_snr': [_vp, _vp, _l, _l, _vp, _vp, _vp, _vp, _vp, _i],
     'xcx_timeshift': [_vp, _vp, _vp, _l, _l, _vp, C.c_double, _i],
     'xcx_cc2d': [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i],
+    'xcx_fft': [_vp, _vp, _vp, _l, _l, _i],
+    'xcx_ifft': [_vp, _vp, _vp, _l, _l, _i],
+    'xcx_rfft': [_vp, _vp, _vp, _l, _l, _i],
+    'xcx_irfft': [_vp, _vp, _vp, _l, _l, _i],
+    'xcx_hilbert': [_vp, _vp, _vp, _l, _l, _i, _i],
     'xcx_comm_unique_id': [C.c_char_p],
     'xcx_comm_init': [_vp, C.c_char_p, _i, _i],
     'xcx_comm_destroy': [_vp],

@@ -1,0 +1,221 @@
+// fftn.hip -- labelled-FFT kernels of xcorr/signal/fft.py (fft :111-113, ifft :239-241,
+// rfft :367-374, irfft :487-494) for ARBITRARY length n (the reference relies on
+// pocketfft's Bluestein path; lag axes such as 359 998 = 2 * 179 999 are the rule).
+//
+// Bluestein on the cross-correlation engine.  With the chirp c[m] = exp(s i pi m^2 / n),
+// s = -1 forward / +1 inverse, and mk = (m^2 + k^2 - (k-m)^2) / 2:
+//     out[k] = sum_{m < nin} in[m] exp(s 2 pi i m k / n)
+//            = c[k] * sum_m (in[m] c[m]) conj(c)[k - m],          k < nout
+// The inner sum is a linear convolution of a = in*c (complex, nin points) with conj(c)
+// over indices -(nout-1) .. nin-1, i.e. np = nin + nout - 1 points.  It is evaluated by the
+// time-stacking pair engine (xcx_cc1d_pairs with XCX_STACK, two "windows" per station):
+//     station A_b  = (Re a_b, Im a_b)           one per batch row
+//     station C1   = (Re conj c, -Im conj c),  C2 = (Im conj c, Re conj c)
+//     stack(A_b, C1) = Re(a (*) conj c),        stack(A_b, C2) = Im(a (*) conj c)
+// at lags nin-1 .. nin-1+nout (exactly the nout wanted outputs, in natural order), so one
+// inverse transform per real output row; the chirps are evaluated in float64 from the
+// exact integer m^2 mod 2n.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "../../include/xcx.h"
+#include "cc_kernels.h"
+#include "xcx_internal.h"
+
+using namespace xcx;
+
+#define HIP_TRY(expr)                                                     \
+  do {                                                                    \
+    hipError_t e_ = (expr);                                               \
+    if (e_ != hipSuccess)                                                 \
+      return set_err(e_ == hipErrorOutOfMemory ? XCX_ENOMEM : XCX_EHIP,   \
+                     "%s: %s (%s:%d)", #expr, hipGetErrorString(e_),      \
+                     __FILE__, __LINE__);                                 \
+  } while (0)
+
+namespace {
+
+struct BsGeom {
+  long nin, nout, n, np;   // np = nin + nout - 1
+  int sign;                // -1 forward, +1 inverse
+  int in_complex;          // input rows are interleaved complex (else real)
+  int half_weights;        // irfft: double every bin except DC and Nyquist (bin n/2)
+  long in_pitch;           // elements (floats or complex) between input rows
+};
+
+// c[m] = exp(sign i pi m^2 / n), exact argument reduction in integers
+__device__ __forceinline__ double2 chirp(long m, long n, int sign) {
+  const unsigned long long mm = (unsigned long long)(m < 0 ? -m : m);
+  const unsigned long long r = (mm * mm) % (unsigned long long)(2 * n);
+  double s, c;
+  sincospi((double)r / (double)n, &s, &c);
+  return make_double2(c, sign < 0 ? -s : s);
+}
+
+// traces [B + 2][2][np]
+__global__ void k_bs_pre(const float* __restrict__ in, BsGeom g, long B, float* __restrict__ tr) {
+  const long np = g.np;
+  const long total = (B + 1) * np;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / np, t = i % np;
+    if (b < B) {
+      float ar = 0.f, ai = 0.f;
+      if (t < g.nin) {
+        double vr, vi = 0.0;
+        if (g.in_complex) {
+          const float2 v = reinterpret_cast<const float2*>(in)[b * g.in_pitch + t];
+          vr = v.x; vi = v.y;
+        } else {
+          vr = in[b * g.in_pitch + t];
+        }
+        if (g.half_weights && t != 0 && 2 * t != g.n) { vr *= 2.0; vi *= 2.0; }
+        const double2 c = chirp(t, g.n, g.sign);
+        ar = (float)(vr * c.x - vi * c.y);
+        ai = (float)(vr * c.y + vi * c.x);
+      }
+      tr[(b * 2 + 0) * np + t] = ar;
+      tr[(b * 2 + 1) * np + t] = ai;
+    } else {                                    // the two chirp stations
+      const double2 c = chirp(t - (g.nout - 1), g.n, -g.sign);      // conj(c)[u], u = t - (nout-1)
+      tr[((B + 0) * 2 + 0) * np + t] = (float)c.x;
+      tr[((B + 0) * 2 + 1) * np + t] = (float)-c.y;
+      tr[((B + 1) * 2 + 0) * np + t] = (float)c.y;
+      tr[((B + 1) * 2 + 1) * np + t] = (float)c.x;
+    }
+  }
+}
+
+// out[b][k] = c[k] (R[2b][k] + i R[2b+1][k]) scale ; real_only keeps the real part
+// out_mode 0: complex, 1: real part, 2: modulus
+__global__ void k_bs_post(const float* __restrict__ R, long ld, BsGeom g, long B, double scale, int real_only,
+                          float* __restrict__ out) {
+  const long total = B * g.nout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / g.nout, k = i % g.nout;
+    const double re = R[(2 * b) * ld + k], im = R[(2 * b + 1) * ld + k];
+    const double2 c = chirp(k, g.n, g.sign);
+    const double orr = (re * c.x - im * c.y) * scale, oi = (re * c.y + im * c.x) * scale;
+    if (real_only == 1) out[i] = (float)orr;
+    else if (real_only == 2) out[i] = (float)sqrt(orr * orr + oi * oi);
+    else reinterpret_cast<float2*>(out)[i] = make_float2((float)orr, (float)oi);
+  }
+}
+
+int bluestein(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom g, double scale, int real_only,
+              int in_dev, int out_dev) {
+  if (!ctx || !in || !out) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || g.n < 2) return set_err(XCX_EINVAL, "batch >= 1 and n >= 2 required");
+  HIP_TRY(hipSetDevice(ctx->device));
+  g.np = g.nin + g.nout - 1;
+  if (2 * g.np - 1 > 737280) return set_err(XCX_EUNSUPPORTED, "transform length %ld too long for the Bluestein path", g.n);
+  int rc;
+  const long imin = g.nin - 1, imax = g.nin - 1 + g.nout;
+  int slot = -1;
+  for (int i = 0; i < 2; ++i)
+    if (ctx->bs_plan[i] && ctx->bs_key[i][0] == g.np && ctx->bs_key[i][1] == imin && ctx->bs_key[i][2] == imax) slot = i;
+  if (slot < 0) {                                   // two cached plans, replaced in turn
+    slot = ctx->bs_next;
+    ctx->bs_next ^= 1;
+    if (ctx->bs_plan[slot]) { xcx_plan_destroy(ctx->bs_plan[slot]); ctx->bs_plan[slot] = nullptr; }
+    if ((rc = xcx_plan_cc1d(ctx, (int)g.np, 0, (int)imin, (int)imax, XCX_STACK, &ctx->bs_plan[slot]))) return rc;
+    ctx->bs_key[slot][0] = g.np; ctx->bs_key[slot][1] = imin; ctx->bs_key[slot][2] = imax;
+  }
+  xcx_plan* plan = ctx->bs_plan[slot];
+  const long ld = (g.nout + 31) / 32 * 32;
+  // rows per pass: bounded workspace (traces + spectra scale with np)
+  const long chunk = std::max<long>(1, std::min<long>(std::min<long>(batch, 256), ((long)256 << 20) / (16 * g.np)));
+  DevBuf &tr = ctx->scratch[1], &lin = ctx->scratch[2], &din = ctx->scratch[4], &dout = ctx->scratch[5];
+  if ((rc = tr.ensure(ctx, sizeof(float) * 2 * g.np * (chunk + 2)))) return rc;
+  if ((rc = lin.ensure(ctx, sizeof(float) * ld * 2 * chunk))) return rc;
+  const size_t in_row = (size_t)g.in_pitch * (g.in_complex ? 8 : 4);
+  const size_t out_row = (size_t)g.nout * (real_only ? 4 : 8);
+  const bool stage_in = !in_dev, stage_out = !out_dev;
+  const float* ind = in;
+  float* outd = out;
+  if (stage_in) {
+    if ((rc = din.ensure(ctx, in_row * batch))) return rc;
+    HIP_TRY(hipMemcpyAsync(din.ptr, in, in_row * batch, hipMemcpyHostToDevice, ctx->stream));
+    ind = (const float*)din.ptr;
+  }
+  if (stage_out) {
+    if ((rc = dout.ensure(ctx, out_row * batch))) return rc;
+    outd = (float*)dout.ptr;
+  }
+  std::vector<int> pairs;
+  for (long r0 = 0; r0 < batch; r0 += chunk) {
+    const long cnt = std::min(chunk, batch - r0);
+    const long tot = (cnt + 1) * g.np;
+    const int grid = (int)std::min<long>((tot + 255) / 256, 256L * 16);
+    hipLaunchKernelGGL(k_bs_pre, dim3(grid), dim3(256), 0, ctx->stream,
+                       (const float*)((const char*)ind + in_row * r0), g, cnt, (float*)tr.ptr);
+    HIP_TRY(hipGetLastError());
+    pairs.resize(4 * cnt);
+    for (long b = 0; b < cnt; ++b) {
+      pairs[4 * b + 0] = (int)b; pairs[4 * b + 1] = (int)cnt;
+      pairs[4 * b + 2] = (int)b; pairs[4 * b + 3] = (int)cnt + 1;
+    }
+    if ((rc = xcx_cc1d_pairs(plan, (const float*)tr.ptr, (int)cnt + 2, 2, 2 * g.np, g.np, pairs.data(), (int)(2 * cnt),
+                             (float*)lin.ptr, ld, 1)))
+      return rc;
+    const long tot2 = cnt * g.nout;
+    const int grid2 = (int)std::min<long>((tot2 + 255) / 256, 256L * 16);
+    hipLaunchKernelGGL(k_bs_post, dim3(grid2), dim3(256), 0, ctx->stream, (const float*)lin.ptr, ld, g, cnt, scale,
+                       real_only, (float*)((char*)outd + out_row * r0));
+    HIP_TRY(hipGetLastError());
+  }
+  if (stage_out) {
+    HIP_TRY(hipMemcpyAsync(out, outd, out_row * batch, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return XCX_OK;
+}
+
+}  // namespace
+
+extern "C" int xcx_fft(xcx_ctx* ctx, const float* in, float* out, long batch, long n, int on_device) {
+  BsGeom g{n, n, n, 0, -1, 1, 0, n};
+  return bluestein(ctx, in, out, batch, g, 1.0, 0, on_device, on_device);
+}
+
+extern "C" int xcx_ifft(xcx_ctx* ctx, const float* in, float* out, long batch, long n, int on_device) {
+  BsGeom g{n, n, n, 0, +1, 1, 0, n};
+  return bluestein(ctx, in, out, batch, g, n > 0 ? 1.0 / (double)n : 0.0, 0, on_device, on_device);
+}
+
+extern "C" int xcx_rfft(xcx_ctx* ctx, const float* x, float* out, long batch, long size, int on_device) {
+  const long n = size - (size & 1);              // fft.py:357 drops the last sample of an odd axis
+  BsGeom g{n, n / 2 + 1, n, 0, -1, 0, 0, size};
+  return bluestein(ctx, x, out, batch, g, 1.0, 0, on_device, on_device);
+}
+
+extern "C" int xcx_irfft(xcx_ctx* ctx, const float* in, float* x, long batch, long m, int on_device) {
+  const long n = 2 * m - 2;                       // fft.py:475
+  BsGeom g{m, n, n, 0, +1, 1, 1, m};
+  return bluestein(ctx, in, x, batch, g, n > 0 ? 1.0 / (double)n : 0.0, 1, on_device, on_device);
+}
+
+// scipy.signal.hilbert along the last axis (xcorr/signal/hilbert.py:69, envelope :120):
+// one-sided spectrum (bins 0..n/2, doubled except DC and, for even n, Nyquist) transformed back
+extern "C" int xcx_hilbert(xcx_ctx* ctx, const float* x, float* out, long batch, long n, int envelope,
+                           int on_device) {
+  if (!ctx) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || n < 2) return set_err(XCX_EINVAL, "batch >= 1 and n >= 2 required");
+  const long nh = n / 2 + 1;
+  DevBuf& spec = ctx->scratch[6];
+  int rc;
+  const long rows = std::max<long>(1, std::min<long>(batch, ((long)512 << 20) / (8 * nh)));
+  if ((rc = spec.ensure(ctx, sizeof(float) * 2 * nh * rows))) return rc;
+  const size_t orow = (size_t)n * (envelope ? 4 : 8);
+  for (long r0 = 0; r0 < batch; r0 += rows) {
+    const long cnt = std::min(rows, batch - r0);
+    BsGeom f{n, nh, n, 0, -1, 0, 0, n};
+    if ((rc = bluestein(ctx, x + r0 * n, (float*)spec.ptr, cnt, f, 1.0, 0, on_device, 1))) return rc;
+    BsGeom b{nh, n, n, 0, +1, 1, 1, nh};
+    if ((rc = bluestein(ctx, (const float*)spec.ptr, (float*)((char*)out + orow * r0), cnt, b, 1.0 / (double)n,
+                        envelope ? 2 : 0, 1, on_device)))
+      return rc;
+  }
+  return XCX_OK;
+}

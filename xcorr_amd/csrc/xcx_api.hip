@@ -191,6 +191,7 @@ extern "C" int xcx_destroy(xcx_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   xcx_comm_destroy(ctx);
   if (ctx->ts_plan) xcx_plan_destroy(ctx->ts_plan);
+  for (auto* bp : ctx->bs_plan) if (bp) xcx_plan_destroy(bp);
   for (auto& b : ctx->scratch) b.release();
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);

@@ -25,4 +25,7 @@ struct xcx_ctx {
   xcx::DevBuf scratch[8];    // grow-only workspaces of the row ops / filters
   struct xcx_plan* ts_plan = nullptr;   // cached plan of xcx_timeshift
   long ts_n = 0;
+  struct xcx_plan* bs_plan[2] = {nullptr, nullptr};   // cached plans of the Bluestein FFTs (fftn.hip)
+  long bs_key[2][3] = {{0, 0, 0}, {0, 0, 0}};
+  int bs_next = 0;
 };

@@ -14,7 +14,8 @@ from ._ffi import check, ptr
 from .engine import DeviceArray, default_context
 
 __all__ = ['copy', 'norm1d', 'demean', 'detrend_linear', 'taper', 'unbias',
-           'onebit', 'sosfiltfilt', 'sosfilt', 'timeshift', 'snr']
+           'onebit', 'sosfiltfilt', 'sosfilt', 'timeshift', 'snr', 'correlate2d',
+           'fft', 'ifft', 'rfft', 'irfft', 'hilbert']
 
 
 def _prep(x):
@@ -201,3 +202,53 @@ def correlate2d(ctx, tiles, pairs, normalize=True, full=False):
     check(_ffi.lib().xcx_cc2d(ctx.handle, ptr(src), T, F, L, ptr(pr), P, int(bool(normalize)), ptr(peak), ptr(idx),
                               ptr(out) if out is not None else None, dev))
     return (peak, idx, out) if full else (peak, idx)
+
+
+def _fft_call(name, ctx, x, in_dtype, out_dtype, out_len):
+    ctx = ctx if ctx is not None else default_context()
+    a = np.ascontiguousarray(x, dtype=in_dtype)
+    if a.ndim == 0:
+        raise ValueError('array with at least one dimension required')
+    size = a.shape[-1]
+    lead = a.shape[:-1]
+    batch = int(np.prod(lead)) if lead else 1
+    out = np.empty(lead + (out_len(size),), dtype=out_dtype)
+    if batch and out.size:
+        check(getattr(_ffi.lib(), name)(ctx.handle, ptr(a), ptr(out), batch, size, 0))
+    return out
+
+
+def fft(ctx, x):
+    """numpy.fft.fft along the last axis, any length, complex64 (xcorr/signal/fft.py:111-113
+    without the fftshift)."""
+    return _fft_call('xcx_fft', ctx, x, np.complex64, np.complex64, lambda n: n)
+
+
+def ifft(ctx, x):
+    """numpy.fft.ifft along the last axis (signal/fft.py:239-241 without the fftshift)."""
+    return _fft_call('xcx_ifft', ctx, x, np.complex64, np.complex64, lambda n: n)
+
+
+def rfft(ctx, x):
+    """numpy.fft.rfft(x, n) with n = size - (size & 1) (signal/fft.py:357, 367-374)."""
+    return _fft_call('xcx_rfft', ctx, x, np.float32, np.complex64, lambda n: (n - (n & 1)) // 2 + 1)
+
+
+def irfft(ctx, x):
+    """numpy.fft.irfft(x) -> 2 (m - 1) real samples (signal/fft.py:475, 487-494)."""
+    return _fft_call('xcx_irfft', ctx, x, np.complex64, np.float32, lambda m: 2 * m - 2)
+
+
+def hilbert(ctx, x, envelope=False):
+    """Analytic signal (complex64) of every row, scipy.signal.hilbert semantics
+    (xcorr/signal/hilbert.py:69); ``envelope=True`` returns its modulus (float32, :120)."""
+    ctx = ctx if ctx is not None else default_context()
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    if a.ndim == 0:
+        raise ValueError('array with at least one dimension required')
+    n = a.shape[-1]
+    batch = int(np.prod(a.shape[:-1])) if a.ndim > 1 else 1
+    out = np.empty(a.shape, dtype=np.float32 if envelope else np.complex64)
+    if batch:
+        check(_ffi.lib().xcx_hilbert(ctx.handle, ptr(a), ptr(out), batch, n, int(bool(envelope)), 0))
+    return out

@@ -11,12 +11,14 @@ returned.  (xarray is not installed in the build container: the DataArray
 branch is exercised only where xarray exists.)
 """
 from .ops1d import (correlate1d, norm1d, norm, demean, detrend, window, taper,
-                    filter, unbias, unbias_weights, timeshift, snr)  # noqa: F401
+                    filter, unbias, unbias_weights, timeshift, snr, hilbert,
+                    envelope)  # noqa: F401
 from .ops2d import norm2d, correlate2d, correlate2d_peak  # noqa: F401
+from .fftops import fft, ifft, rfft, irfft  # noqa: F401
 
 __all__ = ['correlate1d', 'norm1d', 'norm', 'demean', 'detrend', 'window',
            'taper', 'filter', 'unbias', 'unbias_weights', 'timeshift', 'snr',
-           'norm2d', 'correlate2d', 'correlate2d_peak']
+           'norm2d', 'correlate2d', 'correlate2d_peak', 'fft', 'ifft', 'rfft', 'irfft', 'hilbert', 'envelope']
 
 try:                                    # B4 seam: DataArray.signal accessor
     from . import accessor  # noqa: F401

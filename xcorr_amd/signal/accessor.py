@@ -5,6 +5,8 @@ from functools import wraps
 import xarray as xr
 
 from . import ops1d as _f
+from . import ops2d as _f2
+from . import fftops as _ff
 
 
 @xr.register_dataarray_accessor('signal')
@@ -45,3 +47,35 @@ class SignalAccessor():
     @wraps(_f.timeshift)
     def timeshift(self, **kwargs):
         return _f.timeshift(self._da, **kwargs)
+
+    @wraps(_f.hilbert)
+    def hilbert(self, **kwargs):
+        return _f.hilbert(self._da, **kwargs)
+
+    @wraps(_f.envelope)
+    def envelope(self, **kwargs):
+        return _f.envelope(self._da, **kwargs)
+
+    @wraps(_f2.norm2d)
+    def norm2d(self, **kwargs):
+        return _f2.norm2d(self._da, **kwargs)
+
+    @wraps(_f2.correlate2d)
+    def correlate2d(self, in2, **kwargs):
+        return _f2.correlate2d(self._da, in2, **kwargs)
+
+    @wraps(_ff.fft)
+    def fft(self, **kwargs):
+        return _ff.fft(self._da, **kwargs)
+
+    @wraps(_ff.ifft)
+    def ifft(self, **kwargs):
+        return _ff.ifft(self._da, **kwargs)
+
+    @wraps(_ff.rfft)
+    def rfft(self, **kwargs):
+        return _ff.rfft(self._da, **kwargs)
+
+    @wraps(_ff.irfft)
+    def irfft(self, **kwargs):
+        return _ff.irfft(self._da, **kwargs)

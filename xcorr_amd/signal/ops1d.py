@@ -286,15 +286,37 @@ def timeshift(x, delay, dtype=None, dim=None, fast=True, sampling_rate=None):
     return out.astype(dtype or x.dtype)
 
 
-# -- signal/snr.py:27-168, signal/rms.py:23-68 (envelope=False) ------------------
+# -- signal/hilbert.py:29-120 ---------------------------------------------------
+def hilbert(x, dim=None, **kwargs):
+    """Analytic signal along the last axis / `dim` (scipy.signal.hilbert, hilbert.py:69)."""
+    if _is_da(x):
+        dim = _check_dim(x, dim)
+        xt = x.transpose(..., dim)
+        y = xt.copy(data=_ops.hilbert(None, xt.values).astype('complex128' if x.dtype == np.float64 else 'complex64'))
+        y = y.transpose(*x.dims)
+        y.attrs, y.name = x.attrs, x.name
+        return y
+    return _ops.hilbert(None, np.asarray(x))
+
+
+def envelope(x, dim=None, **kwargs):
+    """|hilbert(x)| (signal/hilbert.py:91-120)."""
+    if _is_da(x):
+        dim = _check_dim(x, dim)
+        return _apply_da(x, dim, lambda v: _ops.hilbert(None, v, envelope=True))
+    x = np.asarray(x)
+    return _ops.hilbert(None, x, envelope=True).astype(x.dtype if x.dtype.kind == 'f' else np.float32)
+
+
+# -- signal/snr.py:27-168, signal/rms.py:23-68 ------------------------------------
 def snr(x, signal, noise, dim=None, power=False, decibels=False, extend=False, envelope=False):
-    """Signal-to-noise ratio along the last axis: max|x| in the `signal` mask
-    over the rms of the `noise` mask (signal/snr.py:107-116).  ``extend=True``
-    returns (snr, s, n, argmax).  The Hilbert envelope variant is not built."""
-    if envelope:
-        raise NotImplementedError('envelope=True (Hilbert transform) is not built on the GPU path')
+    """Signal-to-noise ratio along the last axis: max|x| (or of the Hilbert envelope,
+    ``envelope=True``) in the `signal` mask over the rms of x in the `noise` mask
+    (signal/snr.py:107-116).  ``extend=True`` returns (snr, s, n, argmax)."""
     x = np.asarray(x)
     s, n, a = _ops.snr(None, x, np.asarray(signal), np.asarray(noise))
+    if envelope:
+        s, _, a = _ops.snr(None, _ops.hilbert(None, x, envelope=True), np.asarray(signal), np.asarray(noise))
     r = s / n
     if decibels:
         r = 20 * np.log10(r)
