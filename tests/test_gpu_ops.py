@@ -184,7 +184,9 @@ def test_snr_pieces(ctx):
     np.testing.assert_allclose(s, rs, rtol=1e-6)
     np.testing.assert_allclose(n, rn, rtol=1e-5)
     np.testing.assert_allclose(sig.snr(x, signal, noise, decibels=True), 20 * np.log10(rr), rtol=1e-5)
-    with pytest.raises(NotImplementedError):
-        sig.snr(x, signal, noise, envelope=True)
+    re_, rse, rne, _ = R.snr_envelope(x, signal, noise)
+    e, se, ne, _ = sig.snr(x, signal, noise, envelope=True, extend=True)
+    np.testing.assert_allclose(se, rse, rtol=1e-5)
+    np.testing.assert_allclose(e, re_, rtol=2e-5)
     with pytest.raises(ValueError):
         sig.snr(x, np.zeros(5000, bool), noise)

@@ -5,6 +5,7 @@ DeviceArray (caller-owned HBM buffer) and CCPlan (cross-correlation plan).
 This is plumbing only; all arithmetic happens in libxcx.so.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -25,11 +26,16 @@ class DeviceArray:
         p = C.c_void_p()
         check(_ffi.lib().xcx_malloc(ctx.handle, self.nbytes, C.byref(p)))
         self.ptr = p.value
+        ctx._children.add(self)
 
     def free(self):
-        if self.ptr:
+        # a context that is already closed has released everything it owned
+        # (finalisers may run in any order at interpreter exit)
+        if self.ptr and self.ctx.handle:
             check(_ffi.lib().xcx_free(self.ctx.handle, C.c_void_p(self.ptr)))
-            self.ptr = None
+        self.ptr = None
+
+    close = free
 
     def __del__(self):
         try:
@@ -73,9 +79,12 @@ class Context:
         check(_ffi.lib().xcx_init(int(device), C.byref(h)))
         self.handle = h
         self.device = int(device)
+        self._children = weakref.WeakSet()      # plans and arrays that must go first
 
     def close(self):
         if self.handle:
+            for child in list(self._children):
+                child.close()
             _ffi.lib().xcx_destroy(self.handle)
             self.handle = None
 
@@ -161,6 +170,7 @@ class CCPlan:
                                        int(index_min), int(index_max or 0),
                                        flags, C.byref(h)))
         self.handle = h
+        ctx._children.add(self)
         if whiten:
             fs, fmin, fmax, ftaper = whiten
             check(_ffi.lib().xcx_plan_set_whiten(h, fs, fmin, fmax, ftaper))
@@ -172,9 +182,9 @@ class CCPlan:
         self.stack = bool(stack)
 
     def close(self):
-        if self.handle:
+        if self.handle and self.ctx.handle:
             _ffi.lib().xcx_plan_destroy(self.handle)
-            self.handle = None
+        self.handle = None
 
     def __del__(self):
         try:
