@@ -219,6 +219,24 @@ int xcx_irfft(xcx_ctx* ctx, const float* in, float* x, long batch, long m, int o
 int xcx_hilbert(xcx_ctx* ctx, const float* x, float* out, long batch, long n, int envelope,
                 int on_device);
 
+/* Sample-rate changing preprocess ops of the stream registry
+ * (xcorr/stream/process.py:29-94; chain in scripts/cc.py:46-113).  Out of place:
+ * x [batch][n] -> y [batch][n_out].  decimate / interpolate are ObsPy methods in the
+ * reference (not vendored): documented behaviour restated, unverified vs obspy.
+ *   xcx_decimate : optional causal SOS low-pass (n_sections > 0: pass ObsPy's
+ *                  lowpass_cheby_2 design), then y[i] = x[i*factor], n_out = ceil(n/factor)
+ *   xcx_lanczos  : y[i] = sum_m x[m] K(offset + i*step - m), K(u) = sinc(u) sinc(u/a),
+ *                  |u| < a; offset and step in input samples
+ *                  (obspy lanczos_interpolation: step = new_dt/old_dt)
+ *   xcx_block_rms: y[i] = sqrt(mean(x[i*step : i*step+win]^2)), i < nwin
+ *                  (xcorr/stream/running_rms.py:104-111) */
+int xcx_decimate(xcx_ctx* ctx, const float* x, float* y, long batch, long n, long factor,
+                 const double* sos, int n_sections, int on_device);
+int xcx_lanczos(xcx_ctx* ctx, const float* x, float* y, long batch, long n, long n_out,
+                double offset, double step, int a, int on_device);
+int xcx_block_rms(xcx_ctx* ctx, const float* x, float* y, long batch, long n, long win,
+                  long step, long nwin, int on_device);
+
 /* ---- multi-GPU time-stack reduction (RCCL over xGMI) --------------------
  * One communicator per process/GPU.  id_bytes is the 128-byte ncclUniqueId
  * created by rank 0 with xcx_comm_unique_id() and distributed by the host

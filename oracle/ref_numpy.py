@@ -575,3 +575,52 @@ def snr_envelope(x, signal, noise):
     _, _, n, _ = snr(x, signal, noise)
     _, s, _, idx = snr(envelope(x), signal, noise)
     return s / n, s, n, idx
+
+
+# -- a13: ObsPy-backed stream ops, restated (unverified vs obspy) ------------------
+def cheby2_lowpass_sos(freq, sampling_rate, maxorder=12):
+    """ObsPy lowpass_cheby_2 design used by Trace.decimate (documented behaviour)."""
+    nyquist = sampling_rate * 0.5
+    rp, rs, order = 1, 96, 1e99
+    ws = min(freq / nyquist, 1.0)
+    wp = freq / nyquist
+    wn = ws
+    while order > maxorder:
+        wp = wp * 0.99
+        order, wn = scipy.signal.cheb2ord(wp, ws, rp, rs, analog=0)
+    z, p, k = scipy.signal.cheby2(order, rs, wn, btype='low', analog=0, output='zpk')
+    return scipy.signal.zpk2sos(z, p, k)
+
+
+def decimate(x, sampling_rate, factor, no_filter=False):
+    """Trace.decimate(factor): causal Chebyshev-II low-pass, then x[::factor]."""
+    x = np.asarray(x, dtype=np.float64)
+    if not no_filter:
+        x = scipy.signal.sosfilt(cheby2_lowpass_sos(0.5 * sampling_rate / factor, sampling_rate), x, axis=-1)
+    return x[..., ::factor]
+
+
+def lanczos_interpolation(x, offset, step, n_out, a):
+    """y[i] = sum_m x[m] sinc(p-m) sinc((p-m)/a), |p-m| < a, p = offset + i*step
+    (obspy.signal.interpolation.lanczos_interpolation, documented behaviour)."""
+    x = np.asarray(x, dtype=np.float64)
+    n = x.shape[-1]
+    p = offset + np.arange(n_out) * step
+    c = np.floor(p).astype(np.int64)
+    y = np.zeros(x.shape[:-1] + (n_out,))
+    for d in range(-a + 1, a + 1):
+        m = c + d
+        u = p - m
+        w = np.sinc(u) * np.sinc(u / a)
+        ok = (m >= 0) & (m < n) & (np.abs(u) < a)
+        y[..., ok] += x[..., m[ok]] * w[ok]
+    return y
+
+
+def running_rms(x, sampling_rate, window=1.):
+    """xcorr/stream/running_rms.py:104-111 with ObsPy's inclusive slide windows."""
+    x = np.asarray(x, dtype=np.float64)
+    step = int(round(window * sampling_rate))
+    win = step + 1
+    nwin = (x.shape[-1] - win) // step + 1
+    return np.stack([np.sqrt(np.sum(x[..., i * step:i * step + win] ** 2, axis=-1) / win) for i in range(nwin)], axis=-1)

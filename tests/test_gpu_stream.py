@@ -1,0 +1,115 @@
+"""GPU: sample-rate changing preprocess ops (decimate / lanczos interpolate /
+running rms) and the ObsPy-style operation list, against the numpy/scipy oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_numpy as R          # noqa: E402
+from xcorr_amd import ops, stream          # noqa: E402
+from xcorr_amd._ffi import XcxError        # noqa: E402
+
+TOL = 1e-5
+
+
+def relerr(got, ref):
+    ref = np.asarray(ref, np.float64)
+    return float(np.abs(np.asarray(got, np.float64) - ref).max() / np.abs(ref).max())
+
+
+@pytest.fixture(scope='module')
+def raw():
+    """250 Hz records (the reference's EDH hydrophone rate) with offset, trend and tones."""
+    rng = np.random.default_rng(21)
+    n = 250 * 400 + 3
+    t = np.arange(n) / 250.
+    x = rng.standard_normal((5, n)) + 2.0 + 1e-3 * t + np.sin(2 * np.pi * 3.1 * t) + 0.5 * np.sin(2 * np.pi * 60. * t)
+    return x.astype(np.float32)
+
+
+@pytest.mark.parametrize('factor', [1, 2, 5, 10, 16])
+def test_decimate(ctx, raw, factor):
+    y, fs = stream.decimate(raw, 250., factor, ctx=ctx)
+    ref = R.decimate(raw, 250., factor)
+    assert fs == 250. / factor and y.shape == ref.shape == (5, -(-raw.shape[1] // factor))
+    assert relerr(y, ref) < TOL
+    y2, _ = stream.decimate(raw, 250., factor, no_filter=True, ctx=ctx)
+    assert np.array_equal(y2, raw[:, ::factor])
+    # the design is ObsPy's: 96 dB stop band at the new Nyquist, order <= 12
+    sos = stream.cheby2_lowpass_sos(0.5 * 250. / factor, 250.)
+    assert sos.shape[0] <= 6 and np.allclose(sos, R.cheby2_lowpass_sos(0.5 * 250. / factor, 250.))
+    with pytest.raises(ArithmeticError):
+        stream.decimate(raw, 250., 17, ctx=ctx)
+
+
+@pytest.mark.parametrize('new_rate,a', [(50., 20), (100., 20), (40., 8), (250., 1), (333.3, 12)])
+def test_lanczos_interpolate(ctx, raw, new_rate, a):
+    x = raw[:, :50000]
+    y, fs = stream.interpolate(x, 250., new_rate, a=a, ctx=ctx)
+    n_out = int(np.floor((x.shape[1] - 1) / 250. * new_rate)) + 1
+    ref = R.lanczos_interpolation(x, 0.0, 250. / new_rate, n_out, a)
+    assert y.shape == ref.shape and fs == new_rate
+    assert relerr(y, ref) < TOL
+    if new_rate == 250.:
+        assert relerr(y, x) < TOL                      # identity at integer positions
+    # shifted start, explicit npts
+    y2, _ = stream.interpolate(x, 250., new_rate, a=a, starttime_offset=0.0137, npts=1000, ctx=ctx)
+    ref2 = R.lanczos_interpolation(x, 0.0137 * 250., 250. / new_rate, 1000, a)
+    assert relerr(y2, ref2) < TOL
+    with pytest.raises(ValueError):
+        stream.interpolate(x, 250., new_rate, a=a, npts=10 ** 9, ctx=ctx)
+
+
+def test_lanczos_bandlimited_signal_is_recovered(ctx):
+    t = np.arange(20000) / 250.
+    x = np.sin(2 * np.pi * 2.3 * t).astype(np.float32)[None]
+    y, _ = stream.interpolate(x, 250., 50., a=20, ctx=ctx)
+    tn = np.arange(y.shape[1]) / 50.
+    inner = slice(50, -50)
+    assert np.abs(y[0, inner] - np.sin(2 * np.pi * 2.3 * tn)[inner]).max() < 2e-3
+
+
+def test_running_rms(ctx, raw):
+    for window in (1.0, 10.0):
+        y, fs = stream.running_rms(raw, 250., window, ctx=ctx)
+        ref = R.running_rms(raw, 250., window)
+        assert y.shape == ref.shape and fs == 1.0 / window
+        assert relerr(y, ref) < TOL
+    assert relerr(ops.block_rms(ctx, raw, 1000), np.sqrt((raw[:, :100000].astype(np.float64).reshape(5, 100, 1000) ** 2).mean(-1))) < TOL
+    with pytest.raises(XcxError):
+        ops.block_rms(ctx, raw, 1000, 1000, 10 ** 6)
+
+
+def test_operation_list_like_scripts_cc(ctx, raw):
+    """scripts/cc.py:46-113 style chain on a 250 Hz record."""
+    chain = [
+        ('detrend', {'type': 'demean'}),
+        ('filter', {'type': 'highpass', 'freq': .05}),
+        ('decimate', {'factor': 5}),
+        ('filter', {'type': 'lowpass', 'freq': 20.}),
+        ('detrend', {'type': 'demean'}),
+        ('taper', {'type': 'cosine', 'max_percentage': 0.05, 'max_length': 30.}),
+    ]
+    y, fs = stream.apply_operations(raw, 250., chain, ctx=ctx)
+    r = R.demean(raw)
+    r = R.sosfilt(stream.butter_sos('highpass', 250., 4, freq=.05), r)
+    r = R.decimate(r, 250., 5)
+    r = R.sosfilt(stream.butter_sos('lowpass', 50., 4, freq=20.), r)
+    r = R.demean(r)
+    r = r * R.cosine_taper_obspy(r.shape[-1], 50., 0.05, 30.)
+    assert fs == 50. and y.shape == r.shape
+    assert relerr(y, r) < 5 * TOL                       # five chained float32 stages
+    chain2 = [('interpolate', {'sampling_rate': 50., 'method': 'lanczos', 'a': 20})]
+    y2, fs2 = stream.apply_operations(raw[:, :30000], 250., chain2, ctx=ctx)
+    assert fs2 == 50. and y2.shape[1] == 6000
+    with pytest.raises(NotImplementedError):
+        stream.apply_operations(raw, 250., [('remove_response', {})], ctx=ctx)
+
+
+def test_device_resident_rows(ctx, raw):
+    d = ctx.array(raw)
+    y = ops.decimate(ctx, d, 5, stream.cheby2_lowpass_sos(25., 250.))
+    assert relerr(y.to_host(), R.decimate(raw, 250., 5)) < TOL
+    assert np.array_equal(d.to_host(), raw)            # input untouched
+    z = ops.lanczos(ctx, d, 1000, 3.25, 5.0, 20)
+    assert relerr(z.to_host(), R.lanczos_interpolation(raw, 3.25, 5.0, 1000, 20)) < TOL

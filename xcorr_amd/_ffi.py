@@ -78,6 +78,9 @@ SIGNATURES = {
     'xcx_rfft': [_vp, _vp, _vp, _l, _l, _i],
     'xcx_irfft': [_vp, _vp, _vp, _l, _l, _i],
     'xcx_hilbert': [_vp, _vp, _vp, _l, _l, _i, _i],
+    'xcx_decimate': [_vp, _vp, _vp, _l, _l, _l, _vp, _i, _i],
+    'xcx_lanczos': [_vp, _vp, _vp, _l, _l, _l, C.c_double, C.c_double, _i, _i],
+    'xcx_block_rms': [_vp, _vp, _vp, _l, _l, _l, _l, _l, _i],
     'xcx_comm_unique_id': [C.c_char_p],
     'xcx_comm_init': [_vp, C.c_char_p, _i, _i],
     'xcx_comm_destroy': [_vp],

@@ -1,0 +1,170 @@
+// resample.hip -- sample-rate changing preprocess ops on [batch][n] float32 rows
+// (the decimate / interpolate / running_rms entries of xcorr/stream/process.py:29-94,
+// typical chain scripts/cc.py:46-113).  decimate and interpolate are ObsPy methods in
+// the reference (not vendored): restated from their documented behaviour, parity
+// unverified against obspy itself.  running_rms is the reference's own
+// xcorr/stream/running_rms.py:73-113.
+//
+//   xcx_decimate  : optional causal SOS low-pass (the caller passes ObsPy's
+//                   lowpass_cheby_2 design) on a work copy, then y[i] = x[i * factor]
+//   xcx_lanczos   : y[i] = sum_m x[m] K(p_i - m), p_i = offset + i * step (in input
+//                   samples), K(u) = sinc(u) sinc(u/a) for |u| < a, samples outside the
+//                   row skipped -- obspy.signal.interpolation.lanczos_interpolation
+//   xcx_block_rms : y[i] = sqrt(mean(x[i*step : i*step + win]^2))
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+
+#include "../../include/xcx.h"
+#include "xcx_internal.h"
+
+using namespace xcx;
+
+#define HIP_TRY(expr)                                                     \
+  do {                                                                    \
+    hipError_t e_ = (expr);                                               \
+    if (e_ != hipSuccess)                                                 \
+      return set_err(e_ == hipErrorOutOfMemory ? XCX_ENOMEM : XCX_EHIP,   \
+                     "%s: %s (%s:%d)", #expr, hipGetErrorString(e_),      \
+                     __FILE__, __LINE__);                                 \
+  } while (0)
+
+namespace {
+
+constexpr int NT = 256;
+inline unsigned grid_for(long total) { return (unsigned)std::min<long>((total + NT - 1) / NT, 256L * 32); }
+
+__global__ __launch_bounds__(NT) void k_stride_gather(const float* __restrict__ x, float* __restrict__ y, long batch,
+                                                      long n, long nout, long factor) {
+  const long total = batch * nout;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+    const long b = i / nout, k = i % nout;
+    y[i] = x[b * n + k * factor];
+  }
+}
+
+__global__ __launch_bounds__(NT) void k_lanczos(const float* __restrict__ x, float* __restrict__ y, long batch, long n,
+                                                long nout, double offset, double step, int a) {
+  const long total = batch * nout;
+  const double inv_a = 1.0 / (double)a;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+    const long b = i / nout, k = i % nout;
+    const double p = offset + (double)k * step;
+    const long c = (long)floor(p);
+    const float* __restrict__ row = x + b * n;
+    double acc = 0.0;
+    for (long m = c - a + 1; m <= c + a; ++m) {
+      if (m < 0 || m >= n) continue;
+      const double u = p - (double)m;
+      if (u <= -(double)a || u >= (double)a) continue;
+      double w;
+      if (u == 0.0) {
+        w = 1.0;
+      } else {
+        const double pu = M_PI * u;
+        w = sinpi(u) * sinpi(u * inv_a) / (pu * pu * inv_a);
+      }
+      acc += (double)row[m] * w;
+    }
+    y[i] = (float)acc;
+  }
+}
+
+// one wave per output block
+__global__ __launch_bounds__(NT) void k_block_rms(const float* __restrict__ x, float* __restrict__ y, long batch, long n,
+                                                  long nwin, long win, long step) {
+  const long total = batch * nwin;
+  const int lane = threadIdx.x & 63;
+  for (long w = (long)blockIdx.x * (NT / 64) + (threadIdx.x >> 6); w < total; w += (long)gridDim.x * (NT / 64)) {
+    const long b = w / nwin, k = w % nwin;
+    const float* __restrict__ src = x + b * n + k * step;
+    double acc = 0.0;
+    for (long t = lane; t < win; t += 64) { const double v = src[t]; acc += v * v; }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if (lane == 0) y[w] = (float)sqrt(acc / (double)win);
+  }
+}
+
+// host <-> device staging for out-of-place ops (device pointers pass through)
+struct IO {
+  xcx_ctx* ctx; const float* in_d = nullptr; float* out_d = nullptr; float* out_h = nullptr;
+  void *a = nullptr, *b = nullptr; size_t out_bytes = 0; int on_device;
+  int begin(xcx_ctx* c, const float* in, size_t in_bytes, float* out, size_t ob, int dev) {
+    ctx = c; on_device = dev; out_bytes = ob;
+    if (dev) { in_d = in; out_d = out; return XCX_OK; }
+    HIP_TRY(hipMalloc(&a, in_bytes));
+    HIP_TRY(hipMalloc(&b, ob));
+    HIP_TRY(hipMemcpyAsync(a, in, in_bytes, hipMemcpyHostToDevice, c->stream));
+    in_d = (const float*)a; out_d = (float*)b; out_h = out;
+    return XCX_OK;
+  }
+  int end(int rc) {
+    if (!on_device) {
+      if (rc == XCX_OK && hipMemcpyAsync(out_h, out_d, out_bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        rc = set_err(XCX_EHIP, "copy back failed");
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == XCX_OK) rc = set_err(XCX_EHIP, "stream sync failed");
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    a = b = nullptr;
+    return rc;
+  }
+};
+
+}  // namespace
+
+extern "C" int xcx_decimate(xcx_ctx* ctx, const float* x, float* y, long batch, long n, long factor,
+                            const double* sos, int n_sections, int on_device) {
+  if (!ctx || !x || !y) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || n < 1 || factor < 1) return set_err(XCX_EINVAL, "batch, n and factor must be >= 1");
+  if (n_sections < 0 || (n_sections > 0 && !sos)) return set_err(XCX_EINVAL, "bad sos argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const long nout = (n + factor - 1) / factor;            // len(x[::factor])
+  const size_t in_bytes = sizeof(float) * (size_t)batch * n;
+  IO io;
+  int rc = io.begin(ctx, x, in_bytes, y, sizeof(float) * (size_t)batch * nout, on_device);
+  if (rc) return io.end(rc);
+  const float* src = io.in_d;
+  if (n_sections > 0) {
+    DevBuf& work = ctx->scratch[7];                        // the filter runs in place on a copy
+    if ((rc = work.ensure(ctx, in_bytes))) return io.end(rc);
+    if (hipMemcpyAsync(work.ptr, io.in_d, in_bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+      return io.end(set_err(XCX_EHIP, "work copy failed"));
+    if ((rc = xcx_sosfilt(ctx, (float*)work.ptr, batch, n, sos, n_sections, 1))) return io.end(rc);
+    src = (const float*)work.ptr;
+  }
+  hipLaunchKernelGGL(k_stride_gather, dim3(grid_for(batch * nout)), dim3(NT), 0, ctx->stream, src, io.out_d, batch, n,
+                     nout, factor);
+  if (hipGetLastError() != hipSuccess) rc = set_err(XCX_EHIP, "k_stride_gather launch failed");
+  return io.end(rc);
+}
+
+extern "C" int xcx_lanczos(xcx_ctx* ctx, const float* x, float* y, long batch, long n, long n_out, double offset,
+                           double step, int a, int on_device) {
+  if (!ctx || !x || !y) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || n < 1 || n_out < 1) return set_err(XCX_EINVAL, "batch, n and n_out must be >= 1");
+  if (a < 1 || a > 1024 || !(step > 0.0)) return set_err(XCX_EINVAL, "a must be in [1,1024] and step > 0");
+  HIP_TRY(hipSetDevice(ctx->device));
+  IO io;
+  int rc = io.begin(ctx, x, sizeof(float) * (size_t)batch * n, y, sizeof(float) * (size_t)batch * n_out, on_device);
+  if (rc) return io.end(rc);
+  hipLaunchKernelGGL(k_lanczos, dim3(grid_for(batch * n_out)), dim3(NT), 0, ctx->stream, io.in_d, io.out_d, batch, n,
+                     n_out, offset, step, a);
+  if (hipGetLastError() != hipSuccess) rc = set_err(XCX_EHIP, "k_lanczos launch failed");
+  return io.end(rc);
+}
+
+extern "C" int xcx_block_rms(xcx_ctx* ctx, const float* x, float* y, long batch, long n, long win, long step,
+                             long nwin, int on_device) {
+  if (!ctx || !x || !y) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || n < 1 || win < 1 || step < 1 || nwin < 1) return set_err(XCX_EINVAL, "sizes must be >= 1");
+  if ((nwin - 1) * step + win > n) return set_err(XCX_EINVAL, "windows exceed the row: (%ld-1)*%ld+%ld > %ld", nwin, step, win, n);
+  HIP_TRY(hipSetDevice(ctx->device));
+  IO io;
+  int rc = io.begin(ctx, x, sizeof(float) * (size_t)batch * n, y, sizeof(float) * (size_t)batch * nwin, on_device);
+  if (rc) return io.end(rc);
+  hipLaunchKernelGGL(k_block_rms, dim3((unsigned)std::min<long>((batch * nwin + 3) / 4, 256L * 32)), dim3(NT), 0,
+                     ctx->stream, io.in_d, io.out_d, batch, n, nwin, win, step);
+  if (hipGetLastError() != hipSuccess) rc = set_err(XCX_EHIP, "k_block_rms launch failed");
+  return io.end(rc);
+}

@@ -15,7 +15,7 @@ from .engine import DeviceArray, default_context
 
 __all__ = ['copy', 'norm1d', 'demean', 'detrend_linear', 'taper', 'unbias',
            'onebit', 'sosfiltfilt', 'sosfilt', 'timeshift', 'snr', 'correlate2d',
-           'fft', 'ifft', 'rfft', 'irfft', 'hilbert']
+           'fft', 'ifft', 'rfft', 'irfft', 'hilbert', 'decimate', 'lanczos', 'block_rms']
 
 
 def _prep(x):
@@ -252,3 +252,57 @@ def hilbert(ctx, x, envelope=False):
     if batch:
         check(_ffi.lib().xcx_hilbert(ctx.handle, ptr(a), ptr(out), batch, n, int(bool(envelope)), 0))
     return out
+
+
+def _rows(x):
+    if isinstance(x, DeviceArray):
+        return x, 1, x.shape[:-1], int(x.shape[-1])
+    a = np.ascontiguousarray(x, dtype=np.float32)
+    if a.ndim == 0:
+        raise ValueError('array with at least one dimension required')
+    return a, 0, a.shape[:-1], int(a.shape[-1])
+
+
+def _out(ctx, src, dev, shape):
+    return ctx.empty(shape) if dev else np.empty(shape, np.float32)
+
+
+def decimate(ctx, x, factor, sos=None):
+    """y = lowpass(x)[..., ::factor]; `sos` (scipy layout) is the causal anti-alias
+    filter (ObsPy decimate: lowpass_cheby_2), None = no filter."""
+    ctx = _ctx(ctx, x)
+    src, dev, lead, n = _rows(x)
+    batch = int(np.prod(lead)) if lead else 1
+    y = _out(ctx, src, dev, tuple(lead) + ((n + factor - 1) // factor,))
+    if sos is None:
+        s2, K = None, 0
+    else:
+        s2 = _sos(sos)
+        K = s2.shape[0]
+    check(_ffi.lib().xcx_decimate(ctx.handle, ptr(src), ptr(y), batch, n, int(factor), ptr(s2), K, dev))
+    return y
+
+
+def lanczos(ctx, x, n_out, offset, step, a=20):
+    """Lanczos (windowed sinc, half-width `a`) interpolation at positions
+    offset + i * step (input samples), i < n_out."""
+    ctx = _ctx(ctx, x)
+    src, dev, lead, n = _rows(x)
+    batch = int(np.prod(lead)) if lead else 1
+    y = _out(ctx, src, dev, tuple(lead) + (int(n_out),))
+    check(_ffi.lib().xcx_lanczos(ctx.handle, ptr(src), ptr(y), batch, n, int(n_out), float(offset), float(step),
+                                 int(a), dev))
+    return y
+
+
+def block_rms(ctx, x, win, step=None, nwin=None):
+    """rms of blocks x[..., i*step : i*step + win] (xcorr/stream/running_rms.py:104-111)."""
+    ctx = _ctx(ctx, x)
+    src, dev, lead, n = _rows(x)
+    step = int(step or win)
+    if nwin is None:
+        nwin = (n - int(win)) // step + 1
+    batch = int(np.prod(lead)) if lead else 1
+    y = _out(ctx, src, dev, tuple(lead) + (int(nwin),))
+    check(_ffi.lib().xcx_block_rms(ctx.handle, ptr(src), ptr(y), batch, n, int(win), step, int(nwin), dev))
+    return y

@@ -1,0 +1,148 @@
+"""Array-level preprocess ops with ObsPy's parameter names (see package docstring)."""
+import numpy as np
+import scipy.signal
+
+from .. import ops as _ops
+
+
+# -- filter design (host side, scipy) -----------------------------------------
+def butter_sos(ftype, sampling_rate, corners=4, freq=None, freqmin=None, freqmax=None):
+    """ObsPy ``Trace.filter('highpass'|'lowpass'|'bandpass', ...)`` design: Butterworth
+    ``iirfilter(corners, Wn, btype, ftype='butter', output='zpk')`` -> ``zpk2sos``."""
+    fe = 0.5 * sampling_rate
+    if ftype == 'bandpass':
+        wn, btype = [freqmin / fe, freqmax / fe], 'band'
+    elif ftype in ('highpass', 'lowpass'):
+        wn, btype = freq / fe, ftype[:-4]
+    else:
+        raise NotImplementedError(f'filter type "{ftype}" is not built')
+    z, p, k = scipy.signal.iirfilter(corners, wn, btype=btype, ftype='butter', output='zpk')
+    return scipy.signal.zpk2sos(z, p, k)
+
+
+def cheby2_lowpass_sos(freq, sampling_rate, maxorder=12):
+    """ObsPy ``lowpass_cheby_2`` design (the anti-alias filter of ``Trace.decimate``):
+    stop band at `freq` with 96 dB attenuation, pass band lowered by 1 % steps until the
+    order given by ``cheb2ord`` is <= maxorder."""
+    nyquist = sampling_rate * 0.5
+    rp, rs, order = 1, 96, 1e99
+    ws = freq / nyquist
+    wp = ws
+    if ws > 1:
+        ws = 1.0
+    wn = ws
+    while order > maxorder:
+        wp = wp * 0.99
+        order, wn = scipy.signal.cheb2ord(wp, ws, rp, rs, analog=0)
+    z, p, k = scipy.signal.cheby2(order, rs, wn, btype='low', analog=0, output='zpk')
+    return scipy.signal.zpk2sos(z, p, k)
+
+
+def cosine_taper_length(npts, sampling_rate, max_percentage=0.05, max_length=None):
+    """Flank length of ObsPy ``Trace.taper(type='cosine', max_percentage, max_length)``."""
+    wlen = int(max_percentage * npts) if max_percentage is not None else npts // 2
+    if max_length is not None:
+        wlen = min(wlen, int(max_length * sampling_rate))
+    return min(wlen, npts // 2)
+
+
+# -- operations -----------------------------------------------------------------
+def detrend(x, type='demean', ctx=None):
+    """``Trace.detrend('demean' | 'constant' | 'linear')``."""
+    if type in ('demean', 'constant'):
+        return _ops.demean(ctx, x)
+    if type in ('linear', 'simple'):
+        if type == 'simple':
+            raise NotImplementedError('detrend type "simple" is not built')
+        return _ops.detrend_linear(ctx, x)
+    raise NotImplementedError(f'detrend type "{type}" is not built')
+
+
+def filter(x, sampling_rate, type, corners=4, zerophase=False, ctx=None, **options):
+    """``Trace.filter(type, freq= | freqmin=, freqmax=, corners=4, zerophase=False)``."""
+    sos = butter_sos(type, sampling_rate, corners, **options)
+    return _ops.sosfiltfilt(ctx, x, sos) if zerophase else _ops.sosfilt(ctx, x, sos)
+
+
+def taper(x, sampling_rate, max_percentage=0.05, type='cosine', max_length=None, ctx=None):
+    """``Trace.taper(max_percentage, type='cosine'|'hann', max_length)``, both sides."""
+    if type not in ('cosine', 'hann'):
+        raise NotImplementedError(f'taper type "{type}" is not built')
+    n = x.shape[-1]
+    wlen = cosine_taper_length(n, sampling_rate, max_percentage, max_length)
+    if wlen < 1:
+        return x
+    return _ops.taper(ctx, x, wlen, wtype=type)
+
+
+def decimate(x, sampling_rate, factor, no_filter=False, ctx=None):
+    """``Trace.decimate(factor, no_filter=False)``: Chebyshev-II low-pass at
+    0.5 * sampling_rate / factor (``lowpass_cheby_2``, maxorder 12, causal), then every
+    factor-th sample.  Returns (y, new_sampling_rate)."""
+    factor = int(factor)
+    if factor > 16 and not no_filter:
+        raise ArithmeticError('Automatic filter design is unstable for decimation factors above 16. '
+                              'Manual decimation is necessary.')
+    sos = None if no_filter else cheby2_lowpass_sos(0.5 * sampling_rate / factor, sampling_rate)
+    return _ops.decimate(ctx, x, factor, sos), sampling_rate / float(factor)
+
+
+def interpolate(x, sampling_rate, new_sampling_rate, method='lanczos', a=20, starttime_offset=0.0, npts=None,
+                ctx=None):
+    """``Trace.interpolate(sampling_rate, method='lanczos', a=...)``: new sample i sits at
+    ``starttime_offset + i / new_sampling_rate`` seconds after the first old sample;
+    default npts covers the old time span.  Returns (y, new_sampling_rate)."""
+    if method != 'lanczos':
+        raise NotImplementedError(f'interpolation method "{method}" is not built')
+    n = x.shape[-1]
+    dt_old, dt_new = 1.0 / sampling_rate, 1.0 / float(new_sampling_rate)
+    if npts is None:
+        span = (n - 1) * dt_old - starttime_offset
+        npts = int(np.floor(span / dt_new)) + 1
+    if starttime_offset < 0 or starttime_offset + (npts - 1) * dt_new > (n - 1) * dt_old + 1e-9 * dt_old:
+        raise ValueError('The time span of the new samples must lie within the old one')
+    y = _ops.lanczos(ctx, x, npts, starttime_offset / dt_old, dt_new / dt_old, a)
+    return y, float(new_sampling_rate)
+
+
+def running_rms(x, sampling_rate, window=1., ctx=None):
+    """xcorr/stream/running_rms.py:73-113: rms over consecutive windows of `window`
+    seconds.  ObsPy's ``Trace.slide(window, window)`` windows include both end points
+    (window*fs + 1 samples, neighbours share one sample).  Returns (rms, 1/window)."""
+    n = x.shape[-1]
+    step = int(round(window * sampling_rate))
+    win = step + 1
+    nwin = (n - win) // step + 1 if n >= win else 0
+    if nwin < 1:
+        raise ValueError('trace shorter than one window')
+    return _ops.block_rms(ctx, x, win, step, nwin), 1.0 / window
+
+
+_OPS = {'detrend': detrend, 'filter': filter, 'taper': taper, 'decimate': decimate,
+        'interpolate': interpolate, 'running_rms': running_rms}
+
+
+def apply_operations(x, sampling_rate, operations, ctx=None):
+    """Run a reference-style operation list ``[(name, params), ...]``
+    (xcorr/stream/process.py:300-412) on an array.  Returns (y, sampling_rate)."""
+    for name, params in operations:
+        if callable(name):
+            x = name(x, **params)
+            continue
+        if name not in _OPS:
+            raise NotImplementedError(f'"{name}" is not an implemented operation or callable.')
+        p = dict(params)
+        if name == 'detrend':
+            x = detrend(x, ctx=ctx, **p)
+        elif name == 'taper':
+            x = taper(x, sampling_rate, ctx=ctx, **p)
+        elif name == 'filter':
+            x = filter(x, sampling_rate, ctx=ctx, **p)
+        elif name == 'decimate':
+            x, sampling_rate = decimate(x, sampling_rate, ctx=ctx, **p)
+        elif name == 'interpolate':
+            new_rate = p.pop('sampling_rate')
+            x, sampling_rate = interpolate(x, sampling_rate, new_rate, ctx=ctx, **p)
+        elif name == 'running_rms':
+            x, sampling_rate = running_rms(x, sampling_rate, ctx=ctx, **p)
+    return x, sampling_rate
