@@ -237,6 +237,19 @@ int xcx_lanczos(xcx_ctx* ctx, const float* x, float* y, long batch, long n, long
 int xcx_block_rms(xcx_ctx* ctx, const float* x, float* y, long batch, long n, long win,
                   long step, long nwin, int on_device);
 
+/* Hop-1 spectrogram of every row: scipy.signal.spectrogram(x, nperseg=win_len,
+ * noverlap=win_len-1, nfft, window, detrend, mode='psd', return_onesided=True) as used
+ * by xcorr/signal/spectrogram.py:124-141, including its zero columns at the outer
+ * edges: x [batch][n] -> S [batch][nfft/2+1][n], column edge + t (edge = rint(win_len/2))
+ * holds the segment starting at sample t, t <= n - win_len; other columns are 0.
+ * window: win_len float64 values (host); scale: 1/(fs sum w^2) ('density') or
+ * 1/(sum w)^2 ('spectrum') -- the one-sided doubling of all bins but DC / Nyquist is
+ * applied here; detrend: 0 none, 1 'constant' (scipy default).
+ * Sliding-window DFT as a Hankel GEMM on fp32 MFMA; 2 <= win_len <= 256, nfft <= 8192. */
+int xcx_spectrogram(xcx_ctx* ctx, const float* x, float* S, long batch, long n,
+                    int win_len, int nfft, const double* window, double scale,
+                    int detrend, int on_device);
+
 /* ---- multi-GPU time-stack reduction (RCCL over xGMI) --------------------
  * One communicator per process/GPU.  id_bytes is the 128-byte ncclUniqueId
  * created by rank 0 with xcx_comm_unique_id() and distributed by the host

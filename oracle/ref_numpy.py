@@ -624,3 +624,20 @@ def running_rms(x, sampling_rate, window=1.):
     win = step + 1
     nwin = (x.shape[-1] - win) // step + 1
     return np.stack([np.sqrt(np.sum(x[..., i * step:i * step + win] ** 2, axis=-1) / win) for i in range(nwin)], axis=-1)
+
+
+# -- f2: spectrogram (xcorr/signal/spectrogram.py:112-141) --------------------------
+def spectrogram(x, sampling_rate, duration, padding_factor=2, scaling='density', **kwargs):
+    """`_spectrogram` of signal/spectrogram.py:124-141: scipy.signal.spectrogram with
+    nperseg = int(duration*fs), noverlap = nperseg-1, nfft = nperseg*padding_factor,
+    mode 'psd', zero-padded to the input length (edge = rint(nperseg/2) on the left).
+    Returns (freq, Sxx[..., nfreq, n]); float64."""
+    x = np.asarray(x, dtype=np.float64)
+    win_len = int(duration * sampling_rate)
+    nfft = int(win_len * padding_factor)
+    edge = int(np.rint(win_len / 2))
+    _f, _t, Sxx = scipy.signal.spectrogram(x=x, fs=sampling_rate, nperseg=win_len, noverlap=win_len - 1, nfft=nfft,
+                                           scaling=scaling, mode='psd', axis=-1, return_onesided=True, **kwargs)
+    npad = [(0, 0)] * (Sxx.ndim - 1) + [(edge, x.shape[-1] - Sxx.shape[-1] - edge)]
+    freq = np.linspace(0., sampling_rate / 2, int(nfft / 2 + 1))
+    return freq, np.pad(Sxx, pad_width=npad, mode='constant', constant_values=0)

@@ -1,0 +1,221 @@
+// spectrogram.hip -- hop-1 spectrogram of [batch][n] float32 rows, the kernel of
+// xcorr/signal/spectrogram.py:124-141 (scipy.signal.spectrogram with nperseg = win_len,
+// noverlap = win_len-1, nfft = win_len * padding_factor, mode 'psd', one-sided; zero
+// columns at the outer edges) -- the producer of the tiles that correlate2d consumes
+// (scripts/timelapse.py:207-208: duration 2.5 s -> win_len 125, nfft 500, 251 bins).
+//
+// With one segment per sample every output column is a short DFT of a sliding window:
+//     Y[f][t] = sum_{m < win_len} D[f][m] x[t + m],  D[f][m] = w[m] exp(-2 pi i f m / nfft)
+// i.e. the product of the constant (2 nfreq x win_len) matrix D with the Hankel matrix of
+// the row: dense GEMM work -> fp32 MFMA (v_mfma_f32_32x32x2_f32, exact f32 accumulate).
+//   * M: 32-row tiles = 16 frequencies x (re, im), rows ordered so that re and im of one
+//     frequency land in the SAME lane of the 32x32 accumulator (rows r and r+8)
+//   * K: win_len padded to 2*KS; the A tile (32 x 2KS of D) lives in KS registers per lane
+//     for the whole workgroup lifetime
+//   * N: 32 consecutive window starts t; the B operand is read straight from an LDS copy of
+//     the row chunk (Hankel structure: B[k][j] = x[t0 + j + k]), no matrix is materialised
+// 'constant' detrend (scipy default) is applied algebraically: Y - mean_t * sum_m D[f][m],
+// after the chunk mean has been removed from the LDS copy so nothing large cancels.
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "../../include/xcx.h"
+#include "xcx_internal.h"
+
+using namespace xcx;
+
+#define HIP_TRY(expr)                                                     \
+  do {                                                                    \
+    hipError_t e_ = (expr);                                               \
+    if (e_ != hipSuccess)                                                 \
+      return set_err(e_ == hipErrorOutOfMemory ? XCX_ENOMEM : XCX_EHIP,   \
+                     "%s: %s (%s:%d)", #expr, hipGetErrorString(e_),      \
+                     __FILE__, __LINE__);                                 \
+  } while (0)
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int TC = 256;          // window starts (output columns) per workgroup
+constexpr int NT = 256;          // 4 waves, one M tile each
+
+struct SgArgs {
+  const float* x; float* S;
+  const float* D;                // [tiles][KS][64] A-operand image of the DFT matrix
+  const float2* Wsum;            // [tiles*16] sum_m D[f][m]
+  const float* sc;               // [tiles*16] per-frequency scale (one-sided doubling included)
+  long n, nseg; int nfreq, tiles, win_len, edge, detrend;
+};
+
+template <int KS>
+__global__ __launch_bounds__(NT) void k_spectrogram(SgArgs a) {
+  __shared__ float xs[TC + 2 * KS];
+  __shared__ float mu[TC];
+  __shared__ float red[NT / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long b = blockIdx.z;
+  const long t0 = (long)blockIdx.x * TC;
+  const float* __restrict__ xr = a.x + b * a.n;
+  // ---- stage the row chunk, remove its mean, running means of every window ----
+  float part = 0.f;
+  for (int i = tid; i < TC + 2 * KS; i += NT) {
+    const long g = t0 + i;
+    const float v = g < a.n ? xr[g] : 0.f;
+    xs[i] = v;
+    part += v;
+  }
+  if (a.detrend) {
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
+    if (lane == 0) red[wave] = part;
+    __syncthreads();
+    const long valid = std::min<long>(TC + 2 * KS, a.n - t0);
+    const float cm = (red[0] + red[1] + red[2] + red[3]) / (float)valid;
+    for (int i = tid; i < TC + 2 * KS; i += NT)
+      if (t0 + i < a.n) xs[i] -= cm;
+    __syncthreads();
+    float s = 0.f;
+    for (int k = 0; k < a.win_len; ++k) s += xs[tid + k];          // TC == NT
+    mu[tid] = s / (float)a.win_len;
+  } else {
+    mu[tid] = 0.f;
+  }
+  __syncthreads();
+  const int tile = blockIdx.y * 4 + wave;
+  if (tile >= a.tiles) return;
+  // ---- A tile of the DFT matrix: KS registers -----------------------------------
+  float A[KS];
+  const float* __restrict__ Dt = a.D + ((size_t)tile * KS) * 64 + lane;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) A[ks] = Dt[(size_t)ks * 64];
+  const int g = lane >> 5, col = lane & 31;
+  float2 W[8]; float scl[8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int f = tile * 16 + 8 * h + s + 4 * g;
+      W[4 * h + s] = a.Wsum[f];
+      scl[4 * h + s] = a.sc[f];
+    }
+  float* __restrict__ Sb = a.S + (size_t)b * a.nfreq * a.n;
+  for (int nt = 0; nt < TC / 32; ++nt) {
+    const long t = t0 + nt * 32 + col;
+    if (t0 + nt * 32 >= a.nseg) break;                              // wave-uniform
+    f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float* __restrict__ xb = xs + nt * 32 + col + g;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[ks], xb[2 * ks], acc, 0, 0, 0);
+    if (t < a.nseg) {
+      const float m = mu[nt * 32 + col];
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const int f = tile * 16 + 8 * h + s + 4 * g;
+          if (f < a.nfreq) {
+            const float re = acc[8 * h + s] - m * W[4 * h + s].x;
+            const float im = acc[8 * h + 4 + s] - m * W[4 * h + s].y;
+            Sb[(size_t)f * a.n + a.edge + t] = (re * re + im * im) * scl[4 * h + s];
+          }
+        }
+    }
+  }
+}
+
+// zero columns outside [edge, edge + nseg)
+__global__ void k_sg_edges(float* __restrict__ S, long rows, long n, long edge, long nseg) {
+  const long nz = n - nseg;
+  const long total = rows * nz;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / nz, c = i % nz;
+    S[r * n + (c < edge ? c : c + nseg)] = 0.f;
+  }
+}
+
+}  // namespace
+
+extern "C" int xcx_spectrogram(xcx_ctx* ctx, const float* x, float* S, long batch, long n, int win_len, int nfft,
+                               const double* window, double scale, int detrend, int on_device) {
+  if (!ctx || !x || !S || !window) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || n < 1) return set_err(XCX_EINVAL, "batch and n must be >= 1");
+  if (win_len < 2 || win_len > 256) return set_err(XCX_EUNSUPPORTED, "win_len %d outside [2, 256]", win_len);
+  if (nfft < win_len || nfft > 8192) return set_err(XCX_EINVAL, "nfft %d outside [win_len, 8192]", nfft);
+  if (n < win_len) return set_err(XCX_EINVAL, "row shorter than one segment (%ld < %d)", n, win_len);
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int nfreq = nfft / 2 + 1;
+  const int tiles = (nfreq + 15) / 16;
+  const int KS = win_len <= 64 ? 32 : win_len <= 128 ? 64 : win_len <= 192 ? 96 : 128;
+  const long nseg = n - win_len + 1;
+  const long edge = (long)std::rint(win_len / 2.0);                 // spectrogram.py:121 (np.rint: half to even)
+  // ---- tables (float64 on the host) ----
+  std::vector<float> D((size_t)tiles * KS * 64, 0.f), sc((size_t)tiles * 16, 0.f);
+  std::vector<float2> Ws((size_t)tiles * 16, make_float2(0.f, 0.f));
+  for (int tile = 0; tile < tiles; ++tile) {
+    for (int fi = 0; fi < 16; ++fi) {
+      const int f = tile * 16 + fi;
+      if (f >= nfreq) continue;
+      double sr = 0.0, si = 0.0;
+      for (int m = 0; m < win_len; ++m) {
+        const double th = -2.0 * M_PI * (double)(((long)f * m) % nfft) / (double)nfft;
+        sr += window[m] * cos(th); si += window[m] * sin(th);
+      }
+      Ws[(size_t)tile * 16 + fi] = make_float2((float)sr, (float)si);
+      const bool single = f == 0 || (nfft % 2 == 0 && f == nfft / 2);
+      sc[(size_t)tile * 16 + fi] = (float)(scale * (single ? 1.0 : 2.0));
+    }
+    for (int ks = 0; ks < KS; ++ks)
+      for (int l = 0; l < 64; ++l) {
+        const int i = l & 31, k = 2 * ks + (l >> 5);
+        const int fi = (i & 7) + 8 * (i >> 4), im = (i >> 3) & 1;
+        const int f = tile * 16 + fi;
+        if (f >= nfreq || k >= win_len) continue;
+        const double th = -2.0 * M_PI * (double)(((long)f * k) % nfft) / (double)nfft;
+        D[((size_t)tile * KS + ks) * 64 + l] = (float)(window[k] * (im ? sin(th) : cos(th)));
+      }
+  }
+  int rc;
+  DevBuf& tab = ctx->scratch[3];
+  const size_t bD = sizeof(float) * D.size(), bW = sizeof(float2) * Ws.size(), bS = sizeof(float) * sc.size();
+  if ((rc = tab.ensure(ctx, bD + bW + bS))) return rc;
+  char* tp = (char*)tab.ptr;
+  HIP_TRY(hipMemcpyAsync(tp, D.data(), bD, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(tp + bD, Ws.data(), bW, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(tp + bD + bW, sc.data(), bS, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));                       // host vectors go out of scope
+  const size_t in_b = sizeof(float) * (size_t)batch * n, out_b = in_b * nfreq;
+  const float* xd = x; float* Sd = S;
+  void *ha = nullptr, *hb = nullptr;
+  if (!on_device) {
+    HIP_TRY(hipMalloc(&ha, in_b));
+    if (hipMalloc(&hb, out_b) != hipSuccess) { (void)hipFree(ha); return set_err(XCX_ENOMEM, "spectrogram output (%zu bytes)", out_b); }
+    (void)hipMemcpyAsync(ha, x, in_b, hipMemcpyHostToDevice, ctx->stream);
+    xd = (const float*)ha; Sd = (float*)hb;
+  }
+  SgArgs a{xd, Sd, (const float*)tp, (const float2*)(tp + bD), (const float*)(tp + bD + bW),
+           n, nseg, nfreq, tiles, win_len, (int)edge, detrend ? 1 : 0};
+  const dim3 grid((unsigned)((nseg + TC - 1) / TC), (unsigned)((tiles + 3) / 4), (unsigned)batch);
+  switch (KS) {
+    case 32: hipLaunchKernelGGL(k_spectrogram<32>, grid, dim3(NT), 0, ctx->stream, a); break;
+    case 64: hipLaunchKernelGGL(k_spectrogram<64>, grid, dim3(NT), 0, ctx->stream, a); break;
+    case 96: hipLaunchKernelGGL(k_spectrogram<96>, grid, dim3(NT), 0, ctx->stream, a); break;
+    default: hipLaunchKernelGGL(k_spectrogram<128>, grid, dim3(NT), 0, ctx->stream, a); break;
+  }
+  rc = XCX_OK;
+  if (hipGetLastError() != hipSuccess) rc = set_err(XCX_EHIP, "k_spectrogram launch failed");
+  if (rc == XCX_OK && n > nseg) {
+    const long rows = batch * nfreq;
+    hipLaunchKernelGGL(k_sg_edges, dim3((unsigned)std::min<long>((rows * (n - nseg) + 255) / 256, 8192)), dim3(256), 0,
+                       ctx->stream, Sd, rows, n, edge, nseg);
+  }
+  if (!on_device) {
+    if (rc == XCX_OK && hipMemcpyAsync(S, Sd, out_b, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+      rc = set_err(XCX_EHIP, "copy back failed");
+  }
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == XCX_OK) rc = set_err(XCX_EHIP, "stream sync failed");
+  if (ha) (void)hipFree(ha);
+  if (hb) (void)hipFree(hb);
+  return rc;
+}

@@ -15,7 +15,7 @@ from .engine import DeviceArray, default_context
 
 __all__ = ['copy', 'norm1d', 'demean', 'detrend_linear', 'taper', 'unbias',
            'onebit', 'sosfiltfilt', 'sosfilt', 'timeshift', 'snr', 'correlate2d',
-           'fft', 'ifft', 'rfft', 'irfft', 'hilbert', 'decimate', 'lanczos', 'block_rms']
+           'fft', 'ifft', 'rfft', 'irfft', 'hilbert', 'decimate', 'lanczos', 'block_rms', 'spectrogram']
 
 
 def _prep(x):
@@ -305,4 +305,20 @@ def block_rms(ctx, x, win, step=None, nwin=None):
     batch = int(np.prod(lead)) if lead else 1
     y = _out(ctx, src, dev, tuple(lead) + (int(nwin),))
     check(_ffi.lib().xcx_block_rms(ctx.handle, ptr(src), ptr(y), batch, n, int(win), step, int(nwin), dev))
+    return y
+
+
+def spectrogram(ctx, x, win_len, nfft, window, scale, detrend=True):
+    """Hop-1 one-sided PSD of every row (xcorr/signal/spectrogram.py:124-141):
+    [..., n] -> [..., nfft//2+1, n] with zero columns at the outer edges.  `window`:
+    win_len samples; `scale`: 1/(fs*sum(w**2)) or 1/sum(w)**2."""
+    ctx = _ctx(ctx, x)
+    src, dev, lead, n = _rows(x)
+    batch = int(np.prod(lead)) if lead else 1
+    w = np.ascontiguousarray(window, dtype=np.float64)
+    if w.shape != (int(win_len),):
+        raise ValueError('window must have win_len samples')
+    y = _out(ctx, src, dev, tuple(lead) + (int(nfft) // 2 + 1, n))
+    check(_ffi.lib().xcx_spectrogram(ctx.handle, ptr(src), ptr(y), batch, n, int(win_len), int(nfft), ptr(w),
+                                     float(scale), int(bool(detrend)), dev))
     return y

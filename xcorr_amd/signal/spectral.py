@@ -1,0 +1,68 @@
+"""``xcorr/signal/spectrogram.py`` (spectrogram / psd) on the GPU."""
+import numpy as np
+import scipy.signal
+
+from .. import ops as _ops
+from .ops1d import _is_da, _check_dim, xr
+
+
+def _design(sampling_rate, duration, padding_factor, scaling, window):
+    """win_len, nfft, window samples and scale exactly as scipy's `_spectral_helper`
+    derives them from the reference's arguments (spectrogram.py:112-133)."""
+    delta = 1.0 / sampling_rate
+    duration = duration if (duration and duration > delta) else delta
+    padding_factor = padding_factor if (padding_factor and padding_factor >= 1) else 1
+    scaling = scaling or 'density'
+    if scaling not in ['density', 'spectrum']:
+        raise ValueError('Scaling should be either "density" or "spectrum"!')
+    win_len = int(duration * sampling_rate)
+    if win_len < 16:
+        raise ValueError('Change duration to have at least 16 sample points!')
+    nfft = int(win_len * padding_factor)
+    if isinstance(window, (str, tuple)):
+        win = scipy.signal.get_window(window, win_len)
+    else:
+        win = np.asarray(window, dtype=np.float64)
+        if win.shape != (win_len,):
+            raise ValueError('window must have length of nperseg')
+    scale = 1.0 / (sampling_rate * (win * win).sum()) if scaling == 'density' else 1.0 / win.sum() ** 2
+    return win_len, nfft, win, scale, scaling, duration, padding_factor
+
+
+def spectrogram(x, duration=None, padding_factor=2, scaling=None, dim=None, sampling_rate=None,
+                window=('tukey', .25), detrend='constant', **kwargs):
+    """Spectrogram with one segment per sample (signal/spectrogram.py:27-196).
+
+    numpy input ``[..., n]`` needs ``sampling_rate``; returns ``(freq, Sxx[..., nfreq, n])``.
+    DataArray input follows the reference: new dimension ``freq`` before `dim`."""
+    if kwargs:
+        raise NotImplementedError(f'scipy.signal.spectrogram arguments {sorted(kwargs)} are not built')
+    if detrend not in ('constant', False, None):
+        raise NotImplementedError('only detrend="constant" or False is built')
+    if _is_da(x):
+        dim = _check_dim(x, dim)
+        if 'sampling_rate' not in x[dim].attrs:
+            raise ValueError('Dimension has no attribute "{sampling_rate}"!')
+        if 'delta' not in x[dim].attrs:
+            raise ValueError('Dimension has no attribute "{delta}"!')
+        fs = x[dim].attrs['sampling_rate']
+        xt = x.transpose(..., dim)
+        freq, S = spectrogram(xt.values, duration, padding_factor, scaling, sampling_rate=fs, window=window,
+                              detrend=detrend)
+        y = xr.DataArray(S.astype(x.dtype), dims=xt.dims[:-1] + ('freq', dim),
+                         coords={**{d: xt[d] for d in xt.dims if d in xt.coords}, 'freq': freq}, name='psd')
+        y.freq.attrs = {'name': 'freq', 'long_name': 'Frequency', 'standard_name': 'frequency',
+                        'units': f"{x[dim].attrs.get('units', 's')}-1"}
+        y.attrs = {**x.attrs, 'scaling': scaling or 'density', 'mode': 'psd', 'duration': duration,
+                   'padding_factor': padding_factor, 'centered': np.byte(True)}
+        return y
+    if sampling_rate is None:
+        raise ValueError('sampling_rate is required for array input')
+    win_len, nfft, win, scale, *_ = _design(sampling_rate, duration, padding_factor, scaling, window)
+    x = np.asarray(x)
+    S = _ops.spectrogram(None, x, win_len, nfft, win, scale, detrend == 'constant')
+    freq = np.linspace(0., sampling_rate / 2, int(nfft / 2 + 1))
+    return freq, S.astype(x.dtype if x.dtype.kind == 'f' else np.float32)
+
+
+psd = spectrogram
