@@ -2,6 +2,7 @@
 // build: hipcc -O3 --offload-arch=gfx950 tools/micro/pkrate.hip -o /tmp/pkrate
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 typedef float v2f __attribute__((ext_vector_type(2)));
 constexpr int ITER = 4096;
 
@@ -50,8 +51,15 @@ template <int MODE> void run(const char* name, float* d, int wavesPerSimd) {
          ms * 1e6 / (instr * wavesPerSimd));
 }
 
-int main() {
+int main(int argc, char** argv) {
   float* d; hipMalloc(&d, 256 * 8 * 256 * 4);
+  if (argc > 1) {           // single configuration (for counter runs): pkrate <waves/SIMD>
+    const int w = atoi(argv[1]);
+    run<6>("v_add_f32 x1", d, w);
+    run<1>("v_pk_add_f32", d, w);
+    run<2>("v_fma_f32 x2", d, w);
+    return 0;
+  }
   for (int w : {1, 2, 4}) {
     run<6>("v_add_f32 x1", d, w);
     run<0>("v_add_f32 x2", d, w);

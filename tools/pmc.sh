@@ -14,7 +14,7 @@ acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(int)
 for f in glob.glob(os.path.join(out, 'run', '**', '*counter_collection.csv'), recursive=True):
     for r in csv.DictReader(open(f)):
         k = r['Kernel_Name']
-        for s in ('k_wpair_rows', 'k_wpair_cols', 'k_wfwd_rows', 'k_wfwd_cols', 'k_pair_rows', 'k_pair_cols'):
+        for s in ('k_wpair_dual', 'k_gram', 'k_wpair_rows', 'k_wpair_cols', 'k_wfwd_rows', 'k_wfwd_cols', 'k_pair_rows', 'k_pair_cols'):
             if s in k: k = s
         if not k.startswith('k_'): continue
         acc[k][r['Counter_Name']] += float(r['Counter_Value'])

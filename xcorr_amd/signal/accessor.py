@@ -7,6 +7,7 @@ import xarray as xr
 from . import ops1d as _f
 from . import ops2d as _f2
 from . import fftops as _ff
+from . import spectral as _fs
 
 
 @xr.register_dataarray_accessor('signal')
@@ -79,3 +80,9 @@ class SignalAccessor():
     @wraps(_ff.irfft)
     def irfft(self, **kwargs):
         return _ff.irfft(self._da, **kwargs)
+
+    @wraps(_fs.spectrogram)
+    def spectrogram(self, **kwargs):
+        return _fs.spectrogram(self._da, **kwargs)
+
+    psd = spectrogram
