@@ -100,3 +100,46 @@ def test_synthetic_generator_matches_oracle_copy():
     b = R.synthetic_traces(3, 500, day=2)
     np.testing.assert_array_equal(a, b)
     assert a.dtype == np.float32 and a.shape == (3, 500)
+
+
+def test_stream_filter_designs_and_lengths():
+    """Host-side designs of the ObsPy-style ops (no GPU): Butterworth via iirfilter/zpk2sos,
+    lowpass_cheby_2 order search, cosine taper flank length."""
+    import scipy.signal
+    from xcorr_amd import stream
+    from oracle import ref_numpy as R
+    sos = stream.butter_sos('bandpass', 50., 4, freqmin=0.1, freqmax=10.)
+    assert sos.shape == (4, 6)
+    assert np.allclose(sos, scipy.signal.butter(4, [0.1, 10.], 'bandpass', output='sos', fs=50.))
+    assert np.allclose(stream.butter_sos('highpass', 250., 4, freq=.05),
+                       scipy.signal.butter(4, .05, 'highpass', output='sos', fs=250.))
+    with pytest.raises(NotImplementedError):
+        stream.butter_sos('bandstop', 50., 4, freqmin=1., freqmax=2.)
+    for factor in (2, 5, 10, 16):
+        s = stream.cheby2_lowpass_sos(0.5 * 250. / factor, 250.)
+        assert s.shape[0] <= 6 and np.allclose(s, R.cheby2_lowpass_sos(0.5 * 250. / factor, 250.))
+        w, h = scipy.signal.sosfreqz(s, worN=4096, fs=250.)
+        assert np.all(20 * np.log10(np.abs(h[w >= 0.5 * 250. / factor]) + 1e-300) <= -95.9)   # 96 dB stop band
+    assert stream.cosine_taper_length(4320000, 50., 0.05, 30.) == 1500
+    assert stream.cosine_taper_length(1000, 50., 0.05, 30.) == 50
+    assert stream.cosine_taper_length(10, 50., None, None) == 5
+
+
+def test_fft_axes_and_spectrogram_design():
+    """Coordinate rules of signal/fft.py and the scipy-equivalent spectrogram design."""
+    import scipy.signal
+    from xcorr_amd.signal import fftops, spectral
+    from oracle import ref_numpy as R
+    t = np.arange(6001) * 0.02 - 60.
+    assert np.array_equal(fftops.rfft_freq(t), R.rfft_freq(t)) and fftops.rfft_freq(t).size == 3001
+    assert np.allclose(fftops.fft_freq(9, 0.02), np.fft.fftshift(np.fft.fftfreq(9, 0.02)))
+    f = fftops.rfft_freq(t)
+    assert np.allclose(fftops.irfft_time(f, -60.)[:3], [-60., -59.98, -59.96])
+    win_len, nfft, win, scale, scaling, *_ = spectral._design(50., 2.5, 4, None, ('tukey', .25))
+    assert (win_len, nfft, scaling) == (125, 500, 'density')
+    assert np.allclose(win, scipy.signal.get_window(('tukey', .25), 125))
+    assert scale == pytest.approx(1.0 / (50. * (win ** 2).sum()))
+    with pytest.raises(ValueError):
+        spectral._design(50., 0.2, 2, None, 'hann')
+    with pytest.raises(ValueError):
+        spectral._design(50., 2.5, 2, 'power', 'hann')
