@@ -150,41 +150,54 @@ extern "C" int xcx_spectrogram(xcx_ctx* ctx, const float* x, float* S, long batc
   const int KS = win_len <= 64 ? 32 : win_len <= 128 ? 64 : win_len <= 192 ? 96 : 128;
   const long nseg = n - win_len + 1;
   const long edge = (long)std::rint(win_len / 2.0);                 // spectrogram.py:121 (np.rint: half to even)
-  // ---- tables (float64 on the host) ----
-  std::vector<float> D((size_t)tiles * KS * 64, 0.f), sc((size_t)tiles * 16, 0.f);
-  std::vector<float2> Ws((size_t)tiles * 16, make_float2(0.f, 0.f));
-  for (int tile = 0; tile < tiles; ++tile) {
-    for (int fi = 0; fi < 16; ++fi) {
-      const int f = tile * 16 + fi;
-      if (f >= nfreq) continue;
-      double sr = 0.0, si = 0.0;
-      for (int m = 0; m < win_len; ++m) {
-        const double th = -2.0 * M_PI * (double)(((long)f * m) % nfft) / (double)nfft;
-        sr += window[m] * cos(th); si += window[m] * sin(th);
-      }
-      Ws[(size_t)tile * 16 + fi] = make_float2((float)sr, (float)si);
-      const bool single = f == 0 || (nfft % 2 == 0 && f == nfft / 2);
-      sc[(size_t)tile * 16 + fi] = (float)(scale * (single ? 1.0 : 2.0));
-    }
-    for (int ks = 0; ks < KS; ++ks)
-      for (int l = 0; l < 64; ++l) {
-        const int i = l & 31, k = 2 * ks + (l >> 5);
-        const int fi = (i & 7) + 8 * (i >> 4), im = (i >> 3) & 1;
-        const int f = tile * 16 + fi;
-        if (f >= nfreq || k >= win_len) continue;
-        const double th = -2.0 * M_PI * (double)(((long)f * k) % nfft) / (double)nfft;
-        D[((size_t)tile * KS + ks) * 64 + l] = (float)(window[k] * (im ? sin(th) : cos(th)));
-      }
-  }
+  // ---- tables (float64 on the host), cached per (win_len, nfft, window, scale) ----
+  const size_t nD = (size_t)tiles * KS * 64, nW = (size_t)tiles * 16;
+  const size_t bD = sizeof(float) * nD, bW = sizeof(float2) * nW, bS = sizeof(float) * nW;
+  unsigned long long key = 1469598103934665603ULL;
+  auto mix = [&](const void* p, size_t bytes) {
+    const unsigned char* c = (const unsigned char*)p;
+    for (size_t i = 0; i < bytes; ++i) { key ^= c[i]; key *= 1099511628211ULL; }
+  };
+  mix(&win_len, sizeof win_len); mix(&nfft, sizeof nfft); mix(&scale, sizeof scale);
+  mix(window, sizeof(double) * win_len);
   int rc;
-  DevBuf& tab = ctx->scratch[3];
-  const size_t bD = sizeof(float) * D.size(), bW = sizeof(float2) * Ws.size(), bS = sizeof(float) * sc.size();
-  if ((rc = tab.ensure(ctx, bD + bW + bS))) return rc;
+  DevBuf& tab = ctx->sg_tab;
+  if (key != ctx->sg_key || !tab.ptr) {
+    std::vector<float> D(nD, 0.f), sc(nW, 0.f);
+    std::vector<float2> Ws(nW, make_float2(0.f, 0.f));
+    for (int tile = 0; tile < tiles; ++tile) {
+      for (int fi = 0; fi < 16; ++fi) {
+        const int f = tile * 16 + fi;
+        if (f >= nfreq) continue;
+        double sr = 0.0, si = 0.0;
+        for (int m = 0; m < win_len; ++m) {
+          const double th = -2.0 * M_PI * (double)(((long)f * m) % nfft) / (double)nfft;
+          sr += window[m] * cos(th); si += window[m] * sin(th);
+        }
+        Ws[(size_t)tile * 16 + fi] = make_float2((float)sr, (float)si);
+        const bool single = f == 0 || (nfft % 2 == 0 && f == nfft / 2);
+        sc[(size_t)tile * 16 + fi] = (float)(scale * (single ? 1.0 : 2.0));
+      }
+      for (int ks = 0; ks < KS; ++ks)
+        for (int l = 0; l < 64; ++l) {
+          const int i = l & 31, k = 2 * ks + (l >> 5);
+          const int fi = (i & 7) + 8 * (i >> 4), im = (i >> 3) & 1;
+          const int f = tile * 16 + fi;
+          if (f >= nfreq || k >= win_len) continue;
+          const double th = -2.0 * M_PI * (double)(((long)f * k) % nfft) / (double)nfft;
+          D[((size_t)tile * KS + ks) * 64 + l] = (float)(window[k] * (im ? sin(th) : cos(th)));
+        }
+    }
+    ctx->sg_key = 0;
+    if ((rc = tab.ensure(ctx, bD + bW + bS))) return rc;
+    char* up = (char*)tab.ptr;
+    HIP_TRY(hipMemcpyAsync(up, D.data(), bD, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(up + bD, Ws.data(), bW, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(up + bD + bW, sc.data(), bS, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));                     // host vectors go out of scope
+    ctx->sg_key = key;
+  }
   char* tp = (char*)tab.ptr;
-  HIP_TRY(hipMemcpyAsync(tp, D.data(), bD, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(tp + bD, Ws.data(), bW, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(tp + bD + bW, sc.data(), bS, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));                       // host vectors go out of scope
   const size_t in_b = sizeof(float) * (size_t)batch * n, out_b = in_b * nfreq;
   const float* xd = x; float* Sd = S;
   void *ha = nullptr, *hb = nullptr;

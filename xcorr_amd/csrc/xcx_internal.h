@@ -28,4 +28,6 @@ struct xcx_ctx {
   struct xcx_plan* bs_plan[2] = {nullptr, nullptr};   // cached plans of the Bluestein FFTs (fftn.hip)
   long bs_key[2][3] = {{0, 0, 0}, {0, 0, 0}};
   int bs_next = 0;
+  xcx::DevBuf sg_tab;                    // cached DFT-matrix tables of xcx_spectrogram
+  unsigned long long sg_key = 0;
 };
