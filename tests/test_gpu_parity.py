@@ -329,3 +329,16 @@ def test_stack_gram_many_stations_and_odd_pairs(ctx, monkeypatch):
     per = X.CCPlan(ctx, n, **kw).pairs(tr, pairs, W, hop).astype(np.float64).sum(axis=1)
     st = X.CCPlan(ctx, n, stack=True, **kw).pairs(tr, pairs, W, hop)
     assert relerr(st, per) < TOL
+
+
+def test_randomised_sweep(ctx):
+    """tools/fuzz_cc.py: random n / hop / lag slices / flags / pair subsets / stacking for a
+    few seconds (a 90 s run covers ~5700 cases; worst error seen 1.2e-6)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        'fuzz_cc', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fuzz_cc.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cases, worst = mod.run(budget=6.0, seed=123, ctx=ctx)
+    assert cases > 50 and worst < 1e-5
