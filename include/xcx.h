@@ -155,6 +155,11 @@ int xcx_taper(xcx_ctx* ctx, float* x, long batch, long n, long nmax,
 int xcx_unbias(xcx_ctx* ctx, float* x, long batch, long npts, long idx_min,
                long idx_max, int on_device);
 int xcx_onebit(xcx_ctx* ctx, float* x, long batch, long n, int on_device);
+/* Running-absolute-mean temporal normalisation (Bensen et al. 2007 eq. 1; self-defined,
+ * the reference has none): x[t] /= mean(|x[t-h .. t+h]|), the window truncated at the
+ * row ends and averaged over the samples it holds; 0 where the mean is 0.  h <= 3072. */
+int xcx_ram_normalize(xcx_ctx* ctx, float* x, long batch, long n, long half_width,
+                      int on_device);
 int xcx_sosfiltfilt(xcx_ctx* ctx, float* x, long batch, long n,
                     const double* sos, int n_sections, int on_device);
 int xcx_sosfilt(xcx_ctx* ctx, float* x, long batch, long n, const double* sos,

@@ -325,6 +325,20 @@ def onebit(x):
     return np.sign(x).astype(x.dtype)
 
 
+def ram_normalize(x, half_width):
+    """Running-absolute-mean normalisation (Bensen et al. 2007 eq. 1): x / mean(|x|) over
+    a centred window of 2h+1 samples, truncated (and re-counted) at the ends."""
+    x = np.asarray(x, dtype=np.float64)
+    n = x.shape[-1]
+    c = np.concatenate([np.zeros(x.shape[:-1] + (1,)), np.cumsum(np.abs(x), axis=-1)], axis=-1)
+    t = np.arange(n)
+    lo = np.maximum(t - half_width, 0)
+    hi = np.minimum(t + half_width, n - 1)
+    w = (c[..., hi + 1] - c[..., lo]) / (hi - lo + 1)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        return np.where(w > 0, x / w, 0.0)
+
+
 def whiten_weights(nfft, sampling_rate, fmin, fmax, ftaper):
     """Band weight g(f) on the rfft grid of length nfft: 1 inside
     [fmin, fmax], raised-cosine ramps of width ``ftaper`` Hz outside, 0

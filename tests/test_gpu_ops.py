@@ -190,3 +190,24 @@ def test_snr_pieces(ctx):
     np.testing.assert_allclose(e, re_, rtol=2e-5)
     with pytest.raises(ValueError):
         sig.snr(x, np.zeros(5000, bool), noise)
+
+
+@pytest.mark.parametrize('h', [0, 1, 7, 250, 2500, 3072])
+def test_running_absolute_mean_normalisation(ctx, h):
+    """Self-defined op named by the north star (Bensen et al. 2007 eq. 1)."""
+    rng = np.random.default_rng(h)
+    x = (rng.standard_normal((3, 20011)) * (1 + 5 * (rng.random((3, 20011)) > 0.999))).astype(np.float32)
+    x[1, 5000:5010] *= 100.                      # an "earthquake"
+    x[2, :4000] = 0.                             # dead channel start: w = 0 -> y = 0
+    y = ops.ram_normalize(ctx, x, h)
+    ref = R.ram_normalize(x, h)
+    assert relerr(y, ref) < TOL
+    if h == 0:
+        assert np.all(np.abs(y[0]) == 1)
+    if h >= 250:
+        assert np.all(y[2, :4000 - h] == 0)
+    short = x[:, :37]
+    assert relerr(ops.ram_normalize(ctx, short, h), R.ram_normalize(short, h)) < TOL
+    from xcorr_amd._ffi import XcxError
+    with pytest.raises(XcxError):
+        ops.ram_normalize(ctx, x, 3073)

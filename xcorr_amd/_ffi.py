@@ -82,6 +82,7 @@ SIGNATURES = {
     'xcx_lanczos': [_vp, _vp, _vp, _l, _l, _l, C.c_double, C.c_double, _i, _i],
     'xcx_block_rms': [_vp, _vp, _vp, _l, _l, _l, _l, _l, _i],
     'xcx_spectrogram': [_vp, _vp, _vp, _l, _l, _i, _i, _vp, C.c_double, _i, _i],
+    'xcx_ram_normalize': [_vp, _vp, _l, _l, _l, _i],
     'xcx_comm_unique_id': [C.c_char_p],
     'xcx_comm_init': [_vp, C.c_char_p, _i, _i],
     'xcx_comm_destroy': [_vp],

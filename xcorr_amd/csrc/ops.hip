@@ -317,6 +317,89 @@ extern "C" int xcx_onebit(xcx_ctx* ctx, float* x, long batch, long n, int on_dev
   return st.end();
 }
 
+// ---------------------------------------------------------------------------
+// Running-absolute-mean temporal normalisation (Bensen et al. 2007, eq. 1; named by the
+// north star, not present in the reference -> self-defined):
+//     w[t] = mean_{|tau| <= h, 0 <= t+tau < n} |x[t+tau]|,   y[t] = x[t] / w[t]  (0 where w = 0)
+// One workgroup per chunk of kRamChunk samples: |x| of the chunk and its 2h halo goes to
+// LDS in float64, an inclusive prefix sum is built with wavefront shuffles (thread-local
+// run -> __shfl_up scan across the 64 lanes -> 4 wave totals through LDS), and each
+// output takes the difference of two prefix values.
+// ---------------------------------------------------------------------------
+constexpr int kRamChunk = 2048;
+constexpr int kRamMaxHalf = 3072;
+
+__global__ __launch_bounds__(NT) void k_ram(const float* __restrict__ src, float* __restrict__ dst, long n, int h) {
+  extern __shared__ double pre[];                 // kRamChunk + 2h prefix sums
+  __shared__ double wtot[NT / 64];
+  const long b = blockIdx.y;
+  const long c0 = (long)blockIdx.x * kRamChunk;
+  const long g0 = c0 - h;
+  const int span = kRamChunk + 2 * h;
+  const float* __restrict__ x = src + b * n;
+  const int E = (span + NT - 1) / NT;             // contiguous elements per thread
+  const int i0 = threadIdx.x * E;
+  double run = 0.0;
+  for (int e = 0; e < E; ++e) {
+    const int i = i0 + e;
+    if (i < span) {
+      const long g = g0 + i;
+      run += (g >= 0 && g < n) ? (double)fabsf(x[g]) : 0.0;
+      pre[i] = run;                               // thread-local inclusive prefix
+    }
+  }
+  // exclusive scan of the per-thread totals: across lanes, then across waves
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double inc = run;
+  for (int o = 1; o < 64; o <<= 1) {
+    const double up = __shfl_up(inc, o);
+    if (lane >= o) inc += up;
+  }
+  if (lane == 63) wtot[wave] = inc;
+  __syncthreads();
+  double off = inc - run;
+  for (int w = 0; w < wave; ++w) off += wtot[w];
+  for (int e = 0; e < E; ++e) {
+    const int i = i0 + e;
+    if (i < span) pre[i] += off;
+  }
+  __syncthreads();
+  float* __restrict__ y = dst + b * n;
+  for (int k = threadIdx.x; k < kRamChunk; k += NT) {
+    const long t = c0 + k;
+    if (t >= n) break;
+    const long lo = t - h < 0 ? 0 : t - h, hi = t + h > n - 1 ? n - 1 : t + h;
+    const int il = (int)(lo - g0) - 1, ih = (int)(hi - g0);
+    const double sum = pre[ih] - (il >= 0 ? pre[il] : 0.0);
+    const double w = sum / (double)(hi - lo + 1);
+    y[t] = w > 0.0 ? (float)((double)x[t] / w) : 0.f;
+  }
+}
+
+extern "C" int xcx_ram_normalize(xcx_ctx* ctx, float* x, long batch, long n, long half_width, int on_device) {
+  if (!ctx || !x) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || n < 1) return set_err(XCX_EINVAL, "batch and n must be >= 1");
+  if (half_width < 0 || half_width > kRamMaxHalf)
+    return set_err(XCX_EUNSUPPORTED, "half_width %ld outside [0, %d]", half_width, kRamMaxHalf);
+  HIP_TRY(hipSetDevice(ctx->device));
+  Staged st;
+  int rc = st.begin(ctx, x, (size_t)batch * n * sizeof(float), on_device);
+  if (rc) return rc;
+  // the window reaches into neighbouring chunks: read from a copy, write in place
+  const size_t bytes = (size_t)batch * n * sizeof(float);
+  if ((rc = ctx->scratch[1].ensure(ctx, bytes))) { (void)st.end(); return rc; }
+  HIP_TRY(hipMemcpyAsync(ctx->scratch[1].ptr, st.dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  const size_t lds = sizeof(double) * (size_t)(kRamChunk + 2 * half_width);
+  static hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(k_ram),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)(sizeof(double) * (kRamChunk + 2 * kRamMaxHalf)));
+  HIP_TRY(attr);
+  hipLaunchKernelGGL(k_ram, dim3((unsigned)((n + kRamChunk - 1) / kRamChunk), (unsigned)batch), dim3(NT), lds, ctx->stream,
+                     (const float*)ctx->scratch[1].ptr, st.dev, n, (int)half_width);
+  HIP_TRY(hipGetLastError());
+  return st.end();
+}
+
 extern "C" int xcx_snr(xcx_ctx* ctx, const float* x, long batch, long n, const unsigned char* signal_mask,
                        const unsigned char* noise_mask, float* s, float* noise_rms, int* argmax, int on_device) {
   if (!ctx || !x || !signal_mask || !noise_mask || !s || !noise_rms || !argmax)

@@ -15,7 +15,7 @@ from .engine import DeviceArray, default_context
 
 __all__ = ['copy', 'norm1d', 'demean', 'detrend_linear', 'taper', 'unbias',
            'onebit', 'sosfiltfilt', 'sosfilt', 'timeshift', 'snr', 'correlate2d',
-           'fft', 'ifft', 'rfft', 'irfft', 'hilbert', 'decimate', 'lanczos', 'block_rms', 'spectrogram']
+           'fft', 'ifft', 'rfft', 'irfft', 'hilbert', 'decimate', 'lanczos', 'block_rms', 'spectrogram', 'ram_normalize']
 
 
 def _prep(x):
@@ -322,3 +322,13 @@ def spectrogram(ctx, x, win_len, nfft, window, scale, detrend=True):
     check(_ffi.lib().xcx_spectrogram(ctx.handle, ptr(src), ptr(y), batch, n, int(win_len), int(nfft), ptr(w),
                                      float(scale), int(bool(detrend)), dev))
     return y
+
+
+
+def ram_normalize(ctx, x, half_width):
+    """Running-absolute-mean normalisation: x / mean(|x|) over a centred window of
+    2*half_width+1 samples (truncated at the ends).  Self-defined (Bensen et al. 2007)."""
+    ctx = _ctx(ctx, x)
+    buf, batch, n, dev, ret = _prep(x)
+    check(_ffi.lib().xcx_ram_normalize(ctx.handle, ptr(buf), batch, n, int(half_width), dev))
+    return buf
