@@ -56,6 +56,10 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--overlap', action='store_true',
+                    help='overlap the next step\'s preprocess + forward transforms with the pair phase '
+                         '(xcx_cc1d_prepare; measured 20-25 %% SLOWER: the streaming front end evicts the '
+                         'cache-resident T ring of the pair pipelines -- kept for A/B)')
     return ap.parse_args()
 
 
@@ -191,18 +195,44 @@ def main():
         if rccl is True:
             ctx.stack_reduce(out, count=nrows * ld)
 
+    # Optional software pipelining across steps (--overlap): while the pair phase of step k
+    # runs, step k+1 is preprocessed on a second context (own stream) and its windows are
+    # transformed on the plan's side stream (xcx_cc1d_prepare).  Every step's full work stays
+    # inside the timed region.  Off by default: it measures slower (see --help).
+    pipelined = preprocess and not a.stack and a.overlap and W >= 2
+    ctx2 = X.Context(local % max(ndev.value, 1)) if pipelined else None
+
+    def front():
+        plan.prepare_sync()                 # the previous prepare no longer reads `work`
+        ops.copy(ctx2, work, raw)
+        ops.demean(ctx2, work)
+        ops.taper(ctx2, work, taper_n, wtype='cosine')
+        ops.sosfilt(ctx2, work, sos)
+        ctx2.sync()
+        plan.prepare(work, W, hop)
+
+    def run(K):
+        if not pipelined:
+            for _ in range(K):
+                step()
+            return
+        if K > 0:
+            front()
+        for k in range(K):
+            plan.pairs(work, pairs, W, hop, out=out, ld_out=ld)      # consumes the prepared spectra
+            if k + 1 < K:
+                front()
+
     def barrier():
         ctx.sync()
         if dist is not None:
             dist.barrier()
 
-    for _ in range(a.warmup):
-        step()
+    run(a.warmup)
     barrier()
     t0 = time.perf_counter()
     ctx.timer_start()
-    for _ in range(a.steps):
-        step()
+    run(a.steps)
     ev_ms = ctx.timer_stop()
     ctx.sync()
     wall = time.perf_counter() - t0
@@ -246,7 +276,8 @@ def main():
                             'one-bit+whitening per window' if preprocess else 'no preprocess')
                          + (', time-stack' if a.stack else '')),
             'fft_length': plan.N, 'pair_batch': plan.batch,
-            'shard': a.shard, 'per_rank_pair_windows_per_step': P * W,
+            'shard': a.shard,
+            'overlap_next_step_front_end': bool(pipelined), 'per_rank_pair_windows_per_step': P * W,
         },
         'cc_samples_per_s': value * L,
         'event_ms_per_step_rank0': ev_ms / a.steps,

@@ -107,6 +107,17 @@ int xcx_cc1d_pairs(xcx_plan* plan, const float* traces, int S, int W,
                    long stride_s, long stride_w, const int* pairs, int P,
                    float* out, long ld_out, int on_device);
 
+/* Software pipelining across batches (station-days): compute the spectra of ALL S x W
+ * windows of `traces` (device pointer) on a side stream, into a second spectra buffer,
+ * while the pair phase of the previous xcx_cc1d_pairs call is still running.  The next
+ * xcx_cc1d_pairs call with the same (traces, S, W, strides, on_device = 1) consumes them
+ * instead of transforming again; any other call discards them.  The caller must not
+ * modify `traces` until xcx_cc1d_prepare_sync() returns (or the consuming call is issued
+ * and the context synchronised).  Needs W >= 2 and S*W spectra <= 24 GB; not for XCX_STACK. */
+int xcx_cc1d_prepare(xcx_plan* plan, const float* traces, int S, int W, long stride_s,
+                     long stride_w);
+int xcx_cc1d_prepare_sync(xcx_plan* plan);
+
 /* Batched two-input form (util/cc.py:22 cc(x, y) / correlate1d(in1, in2)):
  * x, y : [batch][n]; out : [batch][L]. */
 int xcx_cc1d(xcx_plan* plan, const float* x, const float* y, int batch,

@@ -174,3 +174,45 @@ def test_bench_contract_small(ctx):
     for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert k in r, k
     assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and 0 < r['frac'] < 1
+
+
+def test_prepare_pipelines_the_forward_transforms(ctx):
+    """xcx_cc1d_prepare: spectra computed ahead on a side stream are consumed by the
+    matching pairs() call (bit-identical results); a non-matching call discards them."""
+    import numpy as np
+    from xcorr_amd.engine import CCPlan
+    from xcorr_amd._ffi import XcxError
+    rng = np.random.default_rng(77)
+    S, n, hop, W = 6, 3000, 1500, 5
+    T = (W - 1) * hop + n
+    pairs = np.array([(i, j) for i in range(S) for j in range(i + 1, S)], np.int32)
+    a = rng.standard_normal((S, T)).astype(np.float32)
+    b = rng.standard_normal((S, T)).astype(np.float32)
+    plan = CCPlan(ctx, n, normalize=True, demean=True)
+    da, db = ctx.array(a), ctx.array(b)
+    ld = (plan.L + 31) // 32 * 32
+    out = ctx.empty((len(pairs) * W, ld))
+    ref_a = plan.pairs(da, pairs, W, hop, out=out, ld_out=ld).to_host().copy()
+    ref_b = plan.pairs(db, pairs, W, hop, out=out, ld_out=ld).to_host().copy()
+    # pipelined: prepare b while a's pair phase runs, and so on
+    plan.prepare(da, W, hop)
+    got_a = plan.pairs(da, pairs, W, hop, out=out, ld_out=ld)
+    plan.prepare(db, W, hop)                       # overlaps with the pair phase of a
+    got_a = got_a.to_host().copy()
+    got_b = plan.pairs(db, pairs, W, hop, out=out, ld_out=ld).to_host().copy()
+    assert np.array_equal(got_a[:, :plan.L], ref_a[:, :plan.L])
+    assert np.array_equal(got_b[:, :plan.L], ref_b[:, :plan.L])
+    # stale preparation (other traces) is dropped, the result is that of the call's own traces
+    plan.prepare(da, W, hop)
+    got = plan.pairs(db, pairs, W, hop, out=out, ld_out=ld).to_host()
+    assert np.array_equal(got[:, :plan.L], ref_b[:, :plan.L])
+    # overwrite the traces only after prepare_sync
+    plan.prepare(da, W, hop)
+    plan.prepare_sync()
+    da.copy_from(b)
+    got = plan.pairs(da, pairs, W, hop, out=out, ld_out=ld).to_host()
+    assert np.array_equal(got[:, :plan.L], ref_a[:, :plan.L])      # spectra of the OLD contents were prepared
+    with pytest.raises(XcxError):
+        CCPlan(ctx, n, stack=True).prepare(da, W, hop)
+    with pytest.raises(ValueError):
+        plan.prepare(a, W, hop)                    # host array

@@ -83,6 +83,8 @@ SIGNATURES = {
     'xcx_block_rms': [_vp, _vp, _vp, _l, _l, _l, _l, _l, _i],
     'xcx_spectrogram': [_vp, _vp, _vp, _l, _l, _i, _i, _vp, C.c_double, _i, _i],
     'xcx_ram_normalize': [_vp, _vp, _l, _l, _l, _i],
+    'xcx_cc1d_prepare': [_vp, _vp, _i, _i, _l, _l],
+    'xcx_cc1d_prepare_sync': [_vp],
     'xcx_comm_unique_id': [C.c_char_p],
     'xcx_comm_init': [_vp, C.c_char_p, _i, _i],
     'xcx_comm_destroy': [_vp],

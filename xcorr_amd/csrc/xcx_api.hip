@@ -326,6 +326,13 @@ struct xcx_plan {
   Chain chains[kMaxChains];
   int nchains = 2;
   hipEvent_t ev_fwd = nullptr;
+  // xcx_cc1d_prepare: spectra of the NEXT batch computed on a side stream while
+  // the pair phase of the current one runs; consumed by a matching xcx_cc1d_pairs
+  DevBuf spectra_next;
+  hipStream_t prep_stream = nullptr;
+  hipEvent_t prep_done = nullptr, pairs_done[2] = {nullptr, nullptr};
+  bool prep_valid = false; unsigned long long pairs_count = 0;   // pair phases recorded in pairs_done[count & 1]
+  const float* prep_traces = nullptr; int prep_S = 0, prep_W = 0; long prep_ss = 0, prep_sw = 0;
   size_t fused_err_off = 0;  // index of the error flag inside fsync
   unsigned long long gram_key = 0; int gram_ntiles = 0;
   bool fused_ran = false;
@@ -507,6 +514,10 @@ extern "C" int xcx_plan_destroy(xcx_plan* p) {
     if (ch.done) (void)hipEventDestroy(ch.done);
   }
   if (p->ev_fwd) (void)hipEventDestroy(p->ev_fwd);
+  if (p->prep_stream) { (void)hipStreamSynchronize(p->prep_stream); (void)hipStreamDestroy(p->prep_stream); }
+  if (p->prep_done) (void)hipEventDestroy(p->prep_done);
+  for (auto& e : p->pairs_done) if (e) (void)hipEventDestroy(e);
+  p->spectra_next.release();
   DevBuf* bufs[] = {&p->tw_N1, &p->tw_N2h, &p->tw_unt, &p->tw_N, &p->stats,
                     &p->Tm_f, &p->Tn_f, &p->spectra, &p->T, &p->descs,
                     &p->dtraces, &p->dout, &p->dpairs, &p->psum, &p->psq, &p->Tring, &p->fsync, &p->trash, &p->gramC, &p->gramTiles, &p->gramPidx};
@@ -973,6 +984,13 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
   const int B = p->batch;
   const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
   if ((rc = p->T.ensure(ctx, sizeof(cf) * tm_per * B * 2 * (p->dual ? p->nchains : 1)))) return rc;
+  // spectra prepared ahead by xcx_cc1d_prepare for exactly this call?
+  const bool prepared = p->prep_valid && allw && on_device && p->prep_traces == traces && p->prep_S == S &&
+                        p->prep_W == W && p->prep_ss == stride_s && p->prep_sw == stride_w;
+  if (p->prep_valid && !prepared) {                   // stale preparation: let it finish, drop it
+    HIP_TRY(hipStreamWaitEvent(ctx->stream, p->prep_done, 0));
+    p->prep_valid = false;
+  }
   if (stack) {
     if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)S * W))) return rc;
     if ((rc = forward(p, dtr, stride_s, stride_w, W, 0, 0, S * W, 0))) return rc;
@@ -1040,8 +1058,14 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
     }
   } else if (allw) {
     // every window's station spectra first (few large launches), then the pairs
-    if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)S * W))) return rc;
-    if ((rc = forward(p, dtr, stride_s, stride_w, W, 0, 0, S * W, 0))) return rc;
+    if (prepared) {
+      std::swap(p->spectra, p->spectra_next);
+      HIP_TRY(hipStreamWaitEvent(ctx->stream, p->prep_done, 0));
+      p->prep_valid = false;
+    } else {
+      if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)S * W))) return rc;
+      if ((rc = forward(p, dtr, stride_s, stride_w, W, 0, 0, S * W, 0))) return rc;
+    }
     if (p->fused) {
       for (int w = 0; w < W; ++w)
         if ((rc = pair_fused(p, (size_t)w * P, P, dout, 1))) return rc;
@@ -1069,11 +1093,59 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
   if (p->fused && (!on_device || getenv("XCX_CHECK"))) {
     if ((rc = fused_check(p))) return rc;
   }
+  if (p->pairs_done[0]) {                             // a later xcx_cc1d_prepare must not overwrite these spectra early
+    HIP_TRY(hipEventRecord(p->pairs_done[p->pairs_count & 1], ctx->stream));
+    p->pairs_count += 1;
+  }
   if (!on_device) {
     HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld_out * sizeof(float), dout, (size_t)ld_out * sizeof(float),
                              (size_t)L * sizeof(float), nrows, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
+  return XCX_OK;
+}
+
+extern "C" int xcx_cc1d_prepare(xcx_plan* p, const float* traces, int S, int W, long stride_s, long stride_w) {
+  if (!p || !traces) return set_err(XCX_EINVAL, "null argument");
+  if (S < 1 || W < 1 || stride_s < 0 || stride_w < 0) return set_err(XCX_EINVAL, "bad shape");
+  xcx_ctx* ctx = p->ctx;
+  const Geom& g = p->g;
+  if (g.flags & XCX_F_STACK) return set_err(XCX_EUNSUPPORTED, "xcx_cc1d_prepare does not apply to stacking plans");
+  if (!p->wave) return set_err(XCX_EUNSUPPORTED, "xcx_cc1d_prepare needs the wave engine");
+  if ((long long)S * W > 0x7fffffffLL / 2) return set_err(XCX_EINVAL, "S*W too large");
+  const size_t bytes = sizeof(cf) * p->spec_pitch * (size_t)S * W;
+  if (W < 2 || bytes > ((size_t)24 << 30))
+    return set_err(XCX_EUNSUPPORTED, "xcx_cc1d_prepare needs 2 <= W and all spectra resident (<= 24 GB)");
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc;
+  if (!p->prep_stream) {
+    HIP_TRY(hipStreamCreateWithFlags(&p->prep_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&p->prep_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p->pairs_done[0], hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&p->pairs_done[1], hipEventDisableTiming));
+  }
+  if ((rc = p->spectra_next.ensure(ctx, bytes))) return rc;
+  // the buffer being filled was last read by the pair phase BEFORE the most recent one (the
+  // most recent one reads p->spectra and is what this preparation overlaps with): wait for
+  // that one on the GPU, not on the host
+  if (p->pairs_count >= 2) HIP_TRY(hipStreamWaitEvent(p->prep_stream, p->pairs_done[p->pairs_count & 1], 0));
+  // forward() launches on the context's main stream and writes p->spectra: redirect both
+  hipStream_t main_stream = ctx->stream;
+  ctx->stream = p->prep_stream;
+  std::swap(p->spectra, p->spectra_next);
+  rc = forward(p, traces, stride_s, stride_w, W, 0, 0, S * W, 0);
+  std::swap(p->spectra, p->spectra_next);
+  ctx->stream = main_stream;
+  if (rc) return rc;
+  HIP_TRY(hipEventRecord(p->prep_done, p->prep_stream));
+  p->prep_valid = true;
+  p->prep_traces = traces; p->prep_S = S; p->prep_W = W; p->prep_ss = stride_s; p->prep_sw = stride_w;
+  return XCX_OK;
+}
+
+extern "C" int xcx_cc1d_prepare_sync(xcx_plan* p) {
+  if (!p) return set_err(XCX_EINVAL, "null plan");
+  if (p->prep_done) HIP_TRY(hipEventSynchronize(p->prep_done));
   return XCX_OK;
 }
 

@@ -220,6 +220,21 @@ class CCPlan:
         check(L.xcx_plan_profile(self.handle, 0))
         return out
 
+    def prepare(self, traces, W, stride_w, stride_s=None):
+        """Start transforming all windows of the device-resident `traces` [S, T] on a side
+        stream; the next matching pairs() call uses the result (xcx_cc1d_prepare)."""
+        if not isinstance(traces, DeviceArray):
+            raise ValueError('prepare() needs device-resident traces')
+        S, T = traces.shape
+        stride_s = T if stride_s is None else stride_s
+        if (W - 1) * stride_w + self.n > T:
+            raise ValueError('windows exceed the trace length')
+        check(_ffi.lib().xcx_cc1d_prepare(self.handle, ptr(traces), S, int(W), int(stride_s), int(stride_w)))
+
+    def prepare_sync(self):
+        """Block until the last prepare() has finished reading its traces."""
+        check(_ffi.lib().xcx_cc1d_prepare_sync(self.handle))
+
     def pairs(self, traces, pairs, W, stride_w, out=None, ld_out=0,
               stride_s=None):
         """All pairs x W windows.  `traces`: numpy [S, T] or DeviceArray [S, T];
