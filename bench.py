@@ -56,7 +56,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--overlap', action='store_true',
+    ap.add_argument('--pipeline-front-end', action='store_true',
                     help='overlap the next step\'s preprocess + forward transforms with the pair phase '
                          '(xcx_cc1d_prepare; measured 20-25 %% SLOWER: the streaming front end evicts the '
                          'cache-resident T ring of the pair pipelines -- kept for A/B)')
@@ -195,11 +195,11 @@ def main():
         if rccl is True:
             ctx.stack_reduce(out, count=nrows * ld)
 
-    # Optional software pipelining across steps (--overlap): while the pair phase of step k
+    # Optional software pipelining across steps (--pipeline-front-end): while the pair phase of step k
     # runs, step k+1 is preprocessed on a second context (own stream) and its windows are
     # transformed on the plan's side stream (xcx_cc1d_prepare).  Every step's full work stays
     # inside the timed region.  Off by default: it measures slower (see --help).
-    pipelined = preprocess and not a.stack and a.overlap and W >= 2
+    pipelined = preprocess and not a.stack and a.pipeline_front_end and W >= 2
     ctx2 = X.Context(local % max(ndev.value, 1)) if pipelined else None
 
     def front():
