@@ -1,0 +1,85 @@
+"""Randomised parity sweep of the row ops / filters / FFT helpers against the oracle (GPU box)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import ref_numpy as R
+from xcorr_amd import ops
+from xcorr_amd.engine import default_context
+
+
+def rel(got, ref):
+    ref = np.asarray(ref)
+    d = np.abs(ref).max()
+    return float(np.abs(np.asarray(got) - ref).max() / (d if d > 0 else 1.0))
+
+
+def run(budget=60.0, seed=0, ctx=None):
+    rng = np.random.default_rng(seed)
+    ctx = ctx or default_context()
+    t_end = time.time() + budget
+    worst, cases = {}, 0
+    while time.time() < t_end:
+        kind = rng.choice(['sos', 'rowops', 'fft', 'hilbert', 'ram', 'cc2d', 'lanczos', 'timeshift'])
+        if kind == 'sos':
+            n = int(rng.choice([rng.integers(40, 300), rng.integers(300, 20000), rng.integers(20000, 400000)]))
+            b = int(rng.integers(1, 5)) if n > 20000 else int(rng.integers(1, 200))
+            order = int(rng.integers(1, 9))
+            btype = rng.choice(['lowpass', 'highpass', 'bandpass'])
+            if btype == 'bandpass':
+                order = min(order, 4)
+                f = tuple(sorted(rng.uniform(0.05, 20., 2)));
+                if f[1] - f[0] < 0.5: f = (f[0], f[0] + 0.5)
+            else:
+                f = float(rng.uniform(0.05, 20.))
+            sos = R.butter_sos(order, f, btype, 50.)
+            x = (rng.standard_normal((b, n)) + rng.uniform(-2, 2)).astype(np.float32)
+            e = rel(ops.sosfilt(ctx, x, sos), R.sosfilt(sos, x))
+            if n > 3 * (2 * sos.shape[0] + 1):
+                e = max(e, rel(ops.sosfiltfilt(ctx, x, sos), R.sosfiltfilt(sos, x)))
+            tol = 2e-5 if order > 4 else 1e-5
+        elif kind == 'rowops':
+            n = int(rng.integers(2, 300000)); b = int(rng.integers(1, 6))
+            x = (rng.standard_normal((b, n)) + 3.0 + 1e-4 * np.arange(n)).astype(np.float32)
+            e = max(rel(ops.demean(ctx, x), R.demean(x)), rel(ops.norm1d(ctx, x), R.norm1d(x)),
+                    rel(ops.detrend_linear(ctx, x), R.detrend_linear(x)) / 2)
+            tol = 1e-5
+        elif kind == 'fft':
+            n = int(rng.integers(2, 30000)); b = int(rng.integers(1, 4))
+            x = rng.standard_normal((b, n)).astype(np.float32)
+            e = rel(ops.rfft(ctx, x), R.rfft_kernel(x))
+            z = (x + 1j * rng.standard_normal((b, n))).astype(np.complex64)
+            e = max(e, rel(ops.fft(ctx, z), np.fft.fft(z.astype(np.complex128), axis=-1)))
+            tol = 1e-5
+        elif kind == 'hilbert':
+            n = int(rng.integers(2, 20000)); x = rng.standard_normal((2, n)).astype(np.float32)
+            e = rel(ops.hilbert(ctx, x), R.hilbert(x)); tol = 1e-5
+        elif kind == 'ram':
+            n = int(rng.integers(1, 50000)); h = int(rng.integers(0, 3073))
+            x = rng.standard_normal((3, n)).astype(np.float32)
+            e = rel(ops.ram_normalize(ctx, x, h), R.ram_normalize(x, h)); tol = 1e-5
+        elif kind == 'cc2d':
+            F = int(rng.integers(1, 65)); L = int(rng.integers(1, 600)); T = int(rng.integers(2, 5))
+            t = np.abs(rng.standard_normal((T, F, L))).astype(np.float32)
+            a, b2 = int(rng.integers(0, T)), int(rng.integers(0, T))
+            nrm = bool(rng.random() < 0.5)
+            pk, ix, full = ops.correlate2d(ctx, t, [(a, b2)], normalize=nrm, full=True)
+            e = rel(full[0], R.correlate2d(t[a], t[b2], normalize=nrm)); tol = 1e-5
+        elif kind == 'lanczos':
+            n = int(rng.integers(50, 50000)); a_ = int(rng.integers(1, 25)); step = float(rng.uniform(0.2, 7.))
+            off = float(rng.uniform(0, 3)); nout = max(1, int((n - 1 - off) / step))
+            x = rng.standard_normal((2, n)).astype(np.float32)
+            e = rel(ops.lanczos(ctx, x, nout, off, step, a_), R.lanczos_interpolation(x, off, step, nout, a_)); tol = 1e-5
+        else:
+            n = int(rng.integers(16, 60000)); x = (rng.standard_normal((3, n)) * np.hanning(n)).astype(np.float32)
+            d = rng.uniform(-1, 1, 3)
+            e = rel(ops.timeshift(ctx, x, d, 50.), R.timeshift(x, d, 50.)); tol = 1e-5
+        cases += 1
+        worst[kind] = max(worst.get(kind, 0.0), e)
+        if not e < tol:
+            raise AssertionError(f'{kind}: error {e} (seed {seed}, case {cases})')
+    return cases, worst
+
+
+if __name__ == '__main__':
+    c, w = run(float(sys.argv[1]) if len(sys.argv) > 1 else 60.0, int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    print(f'fuzz_ops: {c} cases, worst relative errors', {k: f'{v:.1e}' for k, v in w.items()})
