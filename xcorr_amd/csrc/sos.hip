@@ -87,19 +87,26 @@ __global__ __launch_bounds__(64) void k_sos_tiles(
     }
   }
   const int nact = (int)std::min((long)64, nseq - q0);
+  // every lane knows where ITS sequence starts; the cooperative tile loads below fetch
+  // sequence i's address and length from lane i (no 64-bit divisions in the loop)
+  long mybase = 0;
+  if (live) mybase = (q / nchunks) * row_stride + (q % nchunks) * Lc;
   for (long t0 = 0; t0 < Lc; t0 += kTile) {
     // coalesced load: 64 consecutive samples of sequence i per instruction
-    for (int i = 0; i < nact; ++i) {
-      const long qi = q0 + i;
-      const long row = qi / nchunks, chunk = qi % nchunks;
-      const long len = std::min(Lc, n - chunk * Lc);
-      const long u = t0 + lane;                 // step index within the sequence
-      float v = 0.f;
-      if (u < len) {
+    // 16 loads in flight at a time (a rolled load -> LDS-store loop would wait out one
+    // memory round trip per sequence); lanes beyond nact hold mylen = 0 and load nothing
+    for (int i0 = 0; i0 < 64; i0 += 16) {
+      float v[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const long base = __shfl(mybase, i0 + k, 64);
+        const long len = __shfl(mylen, i0 + k, 64);
+        const long u = t0 + lane;               // step index within the sequence
         const long t = REVERSE ? (len - 1 - u) : u;
-        v = x[row * row_stride + chunk * Lc + t];
+        v[k] = (u < len) ? x[base + t] : 0.f;
       }
-      tile[i][lane] = v;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) tile[i0 + k][lane] = v[k];
     }
     __syncthreads();
     if (live) {
@@ -112,13 +119,12 @@ __global__ __launch_bounds__(64) void k_sos_tiles(
     __syncthreads();
     if (WRITE) {
       for (int i = 0; i < nact; ++i) {
-        const long qi = q0 + i;
-        const long row = qi / nchunks, chunk = qi % nchunks;
-        const long len = std::min(Lc, n - chunk * Lc);
+        const long base = __shfl(mybase, i, 64);
+        const long len = __shfl(mylen, i, 64);
         const long u = t0 + lane;
         if (u < len) {
           const long t = REVERSE ? (len - 1 - u) : u;
-          x[row * row_stride + chunk * Lc + t] = tile[i][lane];
+          x[base + t] = tile[i][lane];
         }
       }
       __syncthreads();
@@ -172,6 +178,81 @@ __global__ __launch_bounds__(64) void k_sos_scan(double* __restrict__ Z, const d
     if (live) zr[(size_t)c * D + d] = s;
     s = acc;
     c = cn;
+  }
+}
+
+// ---- two-level scan over the chunks of long rows ------------------------------
+// The start-state recurrence S0[i+1] = Z[i] + M_i S0[i] (i = processing order) is affine
+// and all M_i are powers of one matrix, so it splits into groups of kScanG chunks:
+//   A  k_sos_scan_local : per (row, group) the recurrence from a zero start; Z[i] <- local
+//                         prefix T[i], E[row][group] <- group end value
+//   B  k_sos_scan       : the same sequential kernel over the G group values (66 steps
+//                         instead of 4219 for a day at Lc = 1024)
+//   C  k_sos_scan_apply : S0[i] = T[i] + A^(samples before i inside its group) * group start
+// Processing order i <-> chunk c = i (forward) or C-1-i (reverse); groups are formed in
+// processing order and stored in chunk order (group index gc = reverse ? G-1-grp : grp), so
+// the short last chunk sits in the last stored group in both directions.
+constexpr int kScanG = 64;
+
+__global__ __launch_bounds__(64) void k_sos_scan_local(double* __restrict__ Z, double* __restrict__ E,
+                                                       const double* __restrict__ Mfull,
+                                                       const double* __restrict__ Mlast, int D, int nchunks,
+                                                       int G, long rows, int reverse) {
+  const int lane = threadIdx.x;
+  const int d = lane & 15;
+  const long vr = (long)blockIdx.x * 4 + (lane >> 4);          // virtual row = (row, group in processing order)
+  const long nvr = rows * G;
+  const long vrc = vr < nvr ? vr : nvr - 1;                      // keep every lane in the shuffles
+  const long row = vrc / G;
+  const int grp = (int)(vrc % G);
+  const bool live = vr < nvr && d < D;
+  double mf[2 * kMaxK], ml[2 * kMaxK];
+#pragma unroll
+  for (int e = 0; e < 2 * kMaxK; ++e) {
+    mf[e] = (d < D && e < D) ? Mfull[d * D + e] : 0.0;
+    ml[e] = (d < D && e < D) ? Mlast[d * D + e] : 0.0;
+  }
+  double* zr = Z + (size_t)row * nchunks * D;
+  const int i0 = grp * kScanG;
+  const int cnt = min(kScanG, nchunks - i0);
+  double t = 0.0;
+  for (int j = 0; j < cnt; ++j) {
+    const int i = i0 + j;
+    const int c = reverse ? nchunks - 1 - i : i;
+    const double zc = live ? zr[(size_t)c * D + d] : 0.0;
+    double acc = zc;
+    const bool last = c == nchunks - 1;
+#pragma unroll
+    for (int e = 0; e < 2 * kMaxK; ++e) {
+      const double te = __shfl(t, (lane & 48) | e, 64);
+      acc += (last ? ml[e] : mf[e]) * te;
+    }
+    if (live) zr[(size_t)c * D + d] = t;
+    t = acc;
+  }
+  const int gc = reverse ? G - 1 - grp : grp;
+  if (live) E[((size_t)row * G + gc) * D + d] = t;
+}
+
+// PW: [kScanG+1][D][D] powers A^(j*Lc); PWs: the same for the group that starts with the
+// short chunk (reverse passes): PWs[0] = I, PWs[j] = A^(last_len + (j-1) Lc)
+__global__ void k_sos_scan_apply(double* __restrict__ Z, const double* __restrict__ E,
+                                 const double* __restrict__ PW, const double* __restrict__ PWs, int D,
+                                 int nchunks, int G, long rows, int reverse) {
+  const long total = rows * nchunks * D;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+    const int d = (int)(q % D);
+    const long rc = q / D;
+    const int c = (int)(rc % nchunks);
+    const long row = rc / nchunks;
+    const int i = reverse ? nchunks - 1 - c : c;
+    const int grp = i / kScanG, j = i % kScanG;
+    const int gc = reverse ? G - 1 - grp : grp;
+    const double* __restrict__ sg = E + ((size_t)row * G + gc) * D;
+    const double* __restrict__ Pj = ((reverse && grp == 0) ? PWs : PW) + (size_t)j * D * D + (size_t)d * D;
+    double acc = Z[q];
+    for (int e = 0; e < D; ++e) acc += Pj[e] * sg[e];
+    Z[q] = acc;
   }
 }
 
@@ -320,17 +401,47 @@ int run_pass(xcx_ctx* ctx, float* x, long rows, long n, const SosParams& P,
     return XCX_OK;
   }
   int rc;
-  if ((rc = zbuf.ensure(ctx, sizeof(double) * D * (size_t)nseq))) return rc;
-  if ((rc = mbuf.ensure(ctx, sizeof(double) * D * D * 2))) return rc;
+  const int G = (nchunks + kScanG - 1) / kScanG;
+  if ((rc = zbuf.ensure(ctx, sizeof(double) * D * ((size_t)nseq + (size_t)rows * G)))) return rc;
   const long last_len = n - (long)(nchunks - 1) * Lc;
-  std::vector<double> Mf = transition_power(P, Lc), Ml = transition_power(P, last_len);
-  Mf.insert(Mf.end(), Ml.begin(), Ml.end());
-  HIP_TRY(hipMemcpyAsync(mbuf.ptr, Mf.data(), sizeof(double) * Mf.size(), hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  // transition-matrix powers (float64 from long double on the host), cached per filter/geometry
+  const size_t nmat = 2 * (size_t)(kScanG + 1);
+  unsigned long long key = 1469598103934665603ULL;
+  auto mix = [&](const void* p, size_t bytes) {
+    const unsigned char* c = (const unsigned char*)p;
+    for (size_t i = 0; i < bytes; ++i) { key ^= c[i]; key *= 1099511628211ULL; }
+  };
+  mix(&P.K, sizeof P.K); mix(P.c, sizeof(SosCoef) * P.K); mix(&Lc, sizeof Lc); mix(&last_len, sizeof last_len);
+  if (key != ctx->sos_key || !ctx->sos_tab.ptr) {
+    std::vector<double> tab(nmat * D * D);
+    for (int j = 0; j <= kScanG; ++j) {
+      const std::vector<double> a = transition_power(P, (long)j * Lc);
+      const std::vector<double> b = transition_power(P, j == 0 ? 0 : last_len + (long)(j - 1) * Lc);
+      std::copy(a.begin(), a.end(), tab.begin() + (size_t)j * D * D);
+      std::copy(b.begin(), b.end(), tab.begin() + ((size_t)(kScanG + 1) + j) * D * D);
+    }
+    ctx->sos_key = 0;
+    if ((rc = ctx->sos_tab.ensure(ctx, sizeof(double) * tab.size()))) return rc;
+    HIP_TRY(hipMemcpyAsync(ctx->sos_tab.ptr, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->sos_key = key;
+  }
+  (void)mbuf;
+  const double* PW = (const double*)ctx->sos_tab.ptr;
+  const double* PWs = PW + (size_t)(kScanG + 1) * D * D;
+  const double* Mfull = PW + (size_t)D * D;                  // A^Lc
+  const double* Mlast = PWs + (size_t)D * D;                 // A^last_len
   double* Z = (double*)zbuf.ptr;
+  double* E = Z + (size_t)D * nseq;
   HIP_TRY((launch_tiles<K, REV, false>(ctx, x, n, n, Lc, nchunks, nseq, P, nullptr, Z)));
-  hipLaunchKernelGGL(k_sos_scan, dim3((unsigned)((rows + 3) / 4)), dim3(64), 0, ctx->stream, Z, init,
-                     (const double*)mbuf.ptr, (const double*)mbuf.ptr + D * D, D, nchunks, rows, (int)REV);
+  hipLaunchKernelGGL(k_sos_scan_local, dim3((unsigned)((rows * G + 3) / 4)), dim3(64), 0, ctx->stream, Z, E, Mfull, Mlast,
+                     D, nchunks, G, rows, (int)REV);
+  // group start states: the sequential kernel over G values; a full group advances by
+  // A^(kScanG Lc), the stored-last group (which holds the short chunk) by PWs[kScanG]
+  hipLaunchKernelGGL(k_sos_scan, dim3((unsigned)((rows + 3) / 4)), dim3(64), 0, ctx->stream, E, init,
+                     PW + (size_t)kScanG * D * D, PWs + (size_t)kScanG * D * D, D, G, rows, (int)REV);
+  hipLaunchKernelGGL(k_sos_scan_apply, dim3((unsigned)std::min<long>((rows * nchunks * D + 255) / 256, 8192)), dim3(256), 0,
+                     ctx->stream, Z, (const double*)E, PW, PWs, D, nchunks, G, rows, (int)REV);
   HIP_TRY(hipGetLastError());
   // re-run from the true start states; end states land back in Z
   HIP_TRY((launch_tiles<K, REV, true>(ctx, x, n, n, Lc, nchunks, nseq, P, Z, fend ? Z : nullptr)));

@@ -193,6 +193,7 @@ extern "C" int xcx_destroy(xcx_ctx* ctx) {
   if (ctx->ts_plan) xcx_plan_destroy(ctx->ts_plan);
   for (auto* bp : ctx->bs_plan) if (bp) xcx_plan_destroy(bp);
   ctx->sg_tab.release();
+  ctx->sos_tab.release();
   for (auto& b : ctx->scratch) b.release();
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);

@@ -30,4 +30,6 @@ struct xcx_ctx {
   int bs_next = 0;
   xcx::DevBuf sg_tab;                    // cached DFT-matrix tables of xcx_spectrogram
   unsigned long long sg_key = 0;
+  xcx::DevBuf sos_tab;                   // cached transition-matrix powers of the chunked SOS scan
+  unsigned long long sos_key = 0;
 };
