@@ -34,13 +34,13 @@ hipError_t XCX_CAT(launch_wpair_cols_, XCX_INST_L)(const WI1Args& a, dim3 grid, 
   return hipGetLastError();
 }
 #else
-constexpr size_t kLdsF = sizeof(float) * lds_frow_floats(RX::L) * kWPB;   // forward rows keep full complex LDS
+constexpr size_t kLdsF = sizeof(float) * lds_frow_floats(RX::L) * kF1WPB;   // forward rows keep full complex LDS
 constexpr size_t kLds = sizeof(float) * lds_row_floats(RX::L) * kWPB;
 hipError_t XCX_CAT(launch_wfwd_rows_, XCX_INST_L)(const WF1Args& a, dim3 grid, hipStream_t s) {
-  grid.x = (grid.x + kWPB - 1) / kWPB;
+  grid.x = (grid.x + kF1WPB - 1) / kF1WPB;
   static hipError_t once = ensure_lds(k_wfwd_rows<RX>, kLdsF);
   if (once != hipSuccess) return once;
-  hipLaunchKernelGGL(k_wfwd_rows<RX>, grid, dim3(kWNT * kWPB), kLdsF, s, a);
+  hipLaunchKernelGGL(k_wfwd_rows<RX>, grid, dim3(kWNT * kF1WPB), kLdsF, s, a);
   return hipGetLastError();
 }
 hipError_t XCX_CAT(launch_wpair_rows_, XCX_INST_L)(const WI2Args& a, dim3 grid, hipStream_t s) {

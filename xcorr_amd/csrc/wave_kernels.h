@@ -156,8 +156,14 @@ struct WF1Args {
   Geom g;
 };
 
+// waves per workgroup of the forward row kernel: its full-complex LDS slice (15 KB per wave at
+// N2h = 120) limits residency, and smaller workgroups pack the 160 KB better
+#ifndef XCX_F1_WPB
+#define XCX_F1_WPB 2
+#endif
+constexpr int kF1WPB = XCX_F1_WPB;
 template <class RX>
-__global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
+__global__ __launch_bounds__(kWNT * kF1WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_wfwd_rows(WF1Args a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   constexpr int N2h = RX::L;
@@ -166,7 +172,7 @@ void k_wfwd_rows(WF1Args a) {
   const int sw = blockIdx.y;
   const int swg = a.sw0 + sw;
   const int s = swg / a.W, wl = swg % a.W;
-  const int row0 = (blockIdx.x * kWPB + wave_in_group()) * kWRB;
+  const int row0 = (blockIdx.x * kF1WPB + wave_in_group()) * kWRB;
   const float* __restrict__ x = a.traces + (long)s * a.stride_s + (long)(a.w0 + wl) * a.stride_w;
   const int n = g.n, N1 = g.N1;
   const bool onebit = g.flags & XCX_F_ONEBIT;
