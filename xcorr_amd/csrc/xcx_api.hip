@@ -617,7 +617,8 @@ static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_
   xcx_ctx* ctx = p->ctx;
   const Geom& g = p->g;
   // station-windows per forward launch: large launches fill the chip
-  const int kChunk = std::max(64, std::min(512, sw_end - sw_begin));
+  static const int chunk_cap = getenv("XCX_FWD_CHUNK") ? std::max(1, atoi(getenv("XCX_FWD_CHUNK"))) : 512;
+  const int kChunk = std::max(std::min(64, chunk_cap), std::min(chunk_cap, sw_end - sw_begin));
   const size_t tm_per = (size_t)g.N1 * g.N2h;
   int rc;
   if ((g.flags & XCX_F_WHITEN) && !p->whiten_set)
