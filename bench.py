@@ -256,6 +256,37 @@ def main():
         if 'pair_phase' in phase:
             kern['pair_phase'] = phase['pair_phase']
 
+    # ---- context numbers (rank 0, outside the timed region) -----------------
+    extras = {}
+    if not a.no_kernel_timing and rank == 0:
+        # measured device-copy ceiling next to the nominal HBM peak
+        src_b = raw
+        dst_b = work if work is not raw else ctx.empty(raw.shape)
+        ops.copy(ctx, dst_b, src_b); ctx.sync()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            ops.copy(ctx, dst_b, src_b)
+        ctx.sync()
+        extras['copy_GBps_measured'] = 5 * 2 * src_b.nbytes / (time.perf_counter() - t1) / 1e9
+        # PCIe-inclusive rate of the host-pointer form of the same call (bounded sample):
+        # traces in pageable host memory, CCFs copied back
+        try:
+            S_h, W_h = min(S, 8), min(W, 3)
+            host_tr = raw.rows_to_host(0, S_h, (W_h - 1) * hop + n)
+            prs = np.array([(i, j) for i in range(S_h) for j in range(i + 1, S_h)], np.int32)
+            hplan = X.CCPlan(ctx, n, normalize=True)
+            hplan.pairs(host_tr, prs[:2], W_h, hop)
+            t1 = time.perf_counter()
+            hplan.pairs(host_tr, prs, W_h, hop)
+            dt_h = time.perf_counter() - t1
+            extras['pcie_inclusive'] = {
+                'value': len(prs) * W_h / dt_h, 'unit': 'pair-windows/s',
+                'sample': f'{len(prs) * W_h} pair-windows, host traces in ({host_tr.nbytes / 1e6:.0f} MB) and '
+                          f'full-lag CCFs out ({len(prs) * W_h * L * 4 / 1e6:.0f} MB) through pageable memory'}
+            hplan.close()
+        except Exception as e:          # context number only
+            extras['pcie_inclusive'] = {'error': str(e)}
+
     res = {
         'metric': 'pair-windows/s' if not a.stack else 'pair-windows/s (stacked: windows summed per pair)',
         'value': value,
@@ -329,7 +360,11 @@ def main():
                 'algorithmic_bytes_per_launch': alg_dom,
                 'pair_windows_per_launch': B,
                 'kernels_us': {k: v['avg_us'] for k, v in kern.items()},
+                'copy_GBps_measured': extras.get('copy_GBps_measured'),
+                'frac_of_measured_copy': (ach / extras['copy_GBps_measured']) if extras.get('copy_GBps_measured') else None,
             }
+            if 'pcie_inclusive' in extras:
+                res['pcie_inclusive'] = extras['pcie_inclusive']
             if not whole_pass:
                 pass_us = sum(kern[k]['avg_us'] * kern[k]['launches'] for k in names) / kern[dom]['launches']
                 res['roofline']['pass'] = {'kernels': names, 'us_per_launch_set': pass_us,
