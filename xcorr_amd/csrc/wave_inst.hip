@@ -38,9 +38,14 @@ constexpr size_t kLdsF = sizeof(float) * lds_frow_floats(RX::L) * kF1WPB;   // f
 constexpr size_t kLds = sizeof(float) * lds_row_floats(RX::L) * kWPB;
 hipError_t XCX_CAT(launch_wfwd_rows_, XCX_INST_L)(const WF1Args& a, dim3 grid, hipStream_t s) {
   grid.x = (grid.x + kF1WPB - 1) / kF1WPB;
-  static hipError_t once = ensure_lds(k_wfwd_rows<RX>, kLdsF);
+  static hipError_t once = ensure_lds((k_wfwd_rows<RX, false>), kLdsF);
+  static hipError_t once1 = ensure_lds((k_wfwd_rows<RX, true>), kLdsF);
   if (once != hipSuccess) return once;
-  hipLaunchKernelGGL(k_wfwd_rows<RX>, grid, dim3(kWNT * kF1WPB), kLdsF, s, a);
+  if (once1 != hipSuccess) return once1;
+  if (a.g.flags & XCX_F_ONEBIT)
+    hipLaunchKernelGGL((k_wfwd_rows<RX, true>), grid, dim3(kWNT * kF1WPB), kLdsF, s, a);
+  else
+    hipLaunchKernelGGL((k_wfwd_rows<RX, false>), grid, dim3(kWNT * kF1WPB), kLdsF, s, a);
   return hipGetLastError();
 }
 hipError_t XCX_CAT(launch_wpair_rows_, XCX_INST_L)(const WI2Args& a, dim3 grid, hipStream_t s) {

@@ -162,7 +162,10 @@ struct WF1Args {
 #define XCX_F1_WPB 2
 #endif
 constexpr int kF1WPB = XCX_F1_WPB;
-template <class RX>
+// ONEBIT is a template parameter: as a run-time flag the sign() branch sat between every
+// pair of loads and its s_waitcnt vmcnt(0) serialised the whole gather (30 memory round
+// trips per lane; the kernel ran at 1 TB/s)
+template <class RX, bool ONEBIT>
 __global__ __launch_bounds__(kWNT * kF1WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_wfwd_rows(WF1Args a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
@@ -175,7 +178,6 @@ void k_wfwd_rows(WF1Args a) {
   const int row0 = (blockIdx.x * kF1WPB + wave_in_group()) * kWRB;
   const float* __restrict__ x = a.traces + (long)s * a.stride_s + (long)(a.w0 + wl) * a.stride_w;
   const int n = g.n, N1 = g.N1;
-  const bool onebit = g.flags & XCX_F_ONEBIT;
   const float mean = sw_mean(a.psum, sw, n, g.flags & XCX_F_DEMEAN);
   // branch-free gather of the zero-padded window: indices beyond the window
   // are clamped (the load hits the cached last sample) and the value zeroed,
@@ -185,7 +187,7 @@ void k_wfwd_rows(WF1Args a) {
     const int i1 = i0 + N1;
     float v0 = x[i0 < n ? i0 : n - 1] - mean;
     float v1 = x[i1 < n ? i1 : n - 1] - mean;
-    if (onebit) {
+    if constexpr (ONEBIT) {
       v0 = (v0 > 0.f) ? 1.f : ((v0 < 0.f) ? -1.f : 0.f);
       v1 = (v1 > 0.f) ? 1.f : ((v1 < 0.f) ? -1.f : 0.f);
     }
