@@ -391,6 +391,9 @@ template <bool SC1> XCX_DEV cf load_t(const cf* p) {
 
 // row body shared by k_wpair_rows and the fused kernel: tile `Tt` (16 rows,
 // N2h+1 slots), output row `out`, block index blk
+#ifndef XCX_BUFSTORE
+#define XCX_BUFSTORE 1
+#endif
 template <class RX, bool SC1, bool UNBIAS>
 XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, float* __restrict__ out, int blk,
                            const cf* __restrict__ tw_sub, const cf* __restrict__ twu, float* __restrict__ trash,
@@ -501,7 +504,20 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
   int m1 = blk * kWRB + (lane & 15) - shift;
   if (m1 < 0) m1 += N1;
   const int base = m1 + (n - 1) - idx_min;        // output index of (m = 0, h = 0) before the wrap
+#if XCX_BUFSTORE
+  // Buffer stores through a resource that spans exactly the retained lags of this output
+  // row: the hardware range check drops every out-of-range lag (negative indices wrap to
+  // huge unsigned offsets), so a store needs a 32-bit offset and no compare / select /
+  // 64-bit address arithmetic (10 -> 4 VALU instructions per stored lag).
+  (void)trash;
+  const unsigned long long ob = reinterpret_cast<unsigned long long>(out);
+  const unsigned ob_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(ob >> 32));
+  const unsigned ob_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ob);   // unsigned: no sign extension
+  float* out_u = reinterpret_cast<float*>(((unsigned long long)ob_hi << 32) | (unsigned long long)ob_lo);
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out_u, 0, (int)(Lout * 4u), 0x00020000);
+#else
   float* __restrict__ trash_l = trash + lane;
+#endif
   auto out_f = [=](int m, int, cf u) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -513,10 +529,14 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
         lag = lag < 0 ? -lag : lag;
         v *= (float)n / (float)(n - lag);
       }
-      float* dst = ((unsigned)o < Lout) ? out + o : trash_l;
       // streaming (nt) stores: the CCFs are written once and never re-read, so they
       // must not displace the T ring from L2 / the Infinity Cache (+8 % measured)
+#if XCX_BUFSTORE
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, o * 4, 0, /*nt*/ 2);
+#else
+      float* dst = ((unsigned)o < Lout) ? out + o : trash_l;
       __builtin_nontemporal_store(v, dst);
+#endif
     }
   };
 #pragma unroll
