@@ -360,6 +360,9 @@ def main():
                 'algorithmic_bytes_per_launch': alg_dom,
                 'pair_windows_per_launch': B,
                 'kernels_us': {k: v['avg_us'] for k, v in kern.items()},
+                # what the kernel actually moves between L2 and the fabric (Infinity Cache + HBM),
+                # from the PMC passes, at the effective launch time: the quantity that saturates
+                'traffic_GBps': (tr / (eff_us * 1e-6) / 1e9) if (tr and eff_us) else None,
                 'copy_GBps_measured': extras.get('copy_GBps_measured'),
                 'frac_of_measured_copy': (ach / extras['copy_GBps_measured']) if extras.get('copy_GBps_measured') else None,
             }
