@@ -50,6 +50,8 @@ def parse():
     ap.add_argument('--overlap', type=float, default=0.5)
     ap.add_argument('--batch', type=int, default=0, help='pair-windows per launch batch')
     ap.add_argument('--shard', choices=['days', 'pairs'], default='days')
+    ap.add_argument('--clip-lag', type=float, default=0.0,
+                    help='retain only lags within +-SECONDS (the reference\'s clip_lag); 0 = full lag')
     ap.add_argument('--no-preprocess', action='store_true',
                     help='configs[1]-style: raw traces, L2 normalisation only')
     ap.add_argument('--stack', action='store_true', help='time-stack mode (configs[3])')
@@ -144,6 +146,11 @@ def main():
     hop = int(round(n * (1.0 - a.overlap)))
     W = (T - n) // hop + 1
     L = 2 * n - 1
+    imin, imax = 0, L
+    if a.clip_lag > 0:
+        half = min(n - 1, int(round(a.clip_lag * FS)))
+        imin, imax = n - 1 - half, n + half
+        L = imax - imin
     pairs_all = np.array([(i, j) for i in range(S) for j in range(i + 1, S)], np.int32)
     if a.shard == 'pairs' and world > 1:
         pairs = np.ascontiguousarray(pairs_all[rank::world])     # cyclic over the triangle
@@ -156,7 +163,7 @@ def main():
 
     preprocess = not a.no_preprocess
     whiten = (FS, 0.1, 10.0, 0.05) if preprocess else None
-    plan = X.CCPlan(ctx, n, normalize=True, onebit=preprocess, whiten=whiten,
+    plan = X.CCPlan(ctx, n, imin, imax, normalize=True, onebit=preprocess, whiten=whiten,
                     stack=a.stack, batch=a.batch or None)
 
     # ---- synthetic inputs, resident in HBM before the clock starts ---------
@@ -302,7 +309,7 @@ def main():
         'data': 'synthetic',
         'config': {
             'workload': (f'{S} stations x {a.seconds:.0f} s @ {FS:.0f} Hz, {P} pairs x {W} windows '
-                         f'(n={n}, {a.overlap:.0%} overlap), full lag L={L}, '
+                         f'(n={n}, {a.overlap:.0%} overlap), ' + (f'lags +-{a.clip_lag:g} s L={L}, ' if a.clip_lag > 0 else f'full lag L={L}, ')
                          + ('demean+cosine-taper+bandpass(0.1-10 Hz, 4 corners) per station-day, '
                             'one-bit+whitening per window' if preprocess else 'no preprocess')
                          + (', time-stack' if a.stack else '')),

@@ -342,3 +342,26 @@ def test_randomised_sweep(ctx):
     spec.loader.exec_module(mod)
     cases, worst = mod.run(budget=6.0, seed=123, ctx=ctx)
     assert cases > 50 and worst < 1e-5
+
+
+def test_clipped_plans_use_shorter_transforms(ctx):
+    """N >= n + max|lag| is enough for exact retained lags (clip_lag of core/init.py:176-209):
+    a +-600 s slice of a 3600 s window runs at N = 245760 instead of 368640."""
+    from xcorr_amd.engine import CCPlan
+    n = 180000
+    full = CCPlan(ctx, n)
+    assert full.N == 368640
+    clip = CCPlan(ctx, n, n - 1 - 30000, n + 30000)
+    assert clip.N == 245760 and clip.L == 60001
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((2, n)).astype(np.float32)
+    y = (np.roll(x, 12345, axis=-1) + 0.3 * rng.standard_normal((2, n))).astype(np.float32)
+    got = clip.cc(x, y)
+    ref = full.cc(x, y)[:, n - 1 - 30000:n + 30000]
+    assert np.abs(got - ref).max() <= 2e-6 * np.abs(ref).max()
+    one_sided = CCPlan(ctx, n, n - 1, n + 5000)            # lags 0 .. 5000
+    assert one_sided.N < 245760
+    got1 = one_sided.cc(x, y)
+    assert np.abs(got1 - full.cc(x, y)[:, n - 1:n + 5000]).max() <= 2e-6 * np.abs(ref).max()
+    for p in (full, clip, one_sided):
+        p.close()

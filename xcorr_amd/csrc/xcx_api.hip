@@ -405,7 +405,13 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
   if (idx_min < 0 || idx_max > full || idx_min >= idx_max)
     return set_err(XCX_EINVAL, "lag slice [%d,%d) outside [0,%lld)", idx_min,
                    idx_max, full);
-  // choose N = 2*N1*N2h: smallest supported >= 2n-1 (or == nfft)
+  // A circular correlation of length N aliases lag m with m +- N, and the linear correlation
+  // vanishes beyond |m| = n-1: the retained lags [idx_min, idx_max) - (n-1) are exact as soon
+  // as N >= n + max|lag|.  Full-lag plans need 2n-1 as ever; clipped plans (the reference's
+  // clip_lag) get a proportionally shorter transform.
+  const long long maxlag = std::max<long long>((long long)n - 1 - idx_min, (long long)idx_max - n);
+  const long long need = (long long)n + maxlag;
+  // choose N = 2*N1*N2h: smallest supported >= need (or == nfft)
   const char* eng = getenv("XCX_ENGINE");
   const bool wave = !(eng && strcmp(eng, "wg") == 0);
   long long best = -1;
@@ -416,7 +422,7 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
       const int L1 = wave ? kWCols[i].L : kCols[i].L;
       const int L2 = wave ? kWRows[j].L : kRows[j].L;
       long long N = 2LL * L1 * L2;
-      if (N < full) continue;
+      if (N < need) continue;
       if (nfft > 0 && N != nfft) continue;
       // among equal N: wave engine prefers long columns (one column per
       // wave), the workgroup engine the most balanced split
