@@ -76,9 +76,11 @@ int xcx_timer_stop(xcx_ctx* ctx, float* ms);
 /* ---- cross-correlation plan (replaces util/cc.py:22-79 cc(), and the
  *      _correlate1d closure of signal/correlate.py:108-113) ---------------
  * n        : window length in samples (len(x) == len(y), util/cc.py:60-62)
- * nfft     : transform length, 0 = smallest supported N >= 2n-1.  The
- *            reference uses exactly 2n-1 (util/cc.py:67); any N >= 2n-1
- *            yields the identical linear cross-correlation.
+ * nfft     : transform length, 0 = smallest supported N >= n + max|lag| of the
+ *            retained slice (2n-1 for the full lag axis).  The reference uses
+ *            exactly 2n-1 (util/cc.py:67); any such N yields the identical
+ *            linear cross-correlation on the retained lags (aliases m +- N of a
+ *            correlation that vanishes beyond |m| = n-1 cannot reach them).
  * idx_min, idx_max : retained slice of the 2n-1 lags, end exclusive
  *            (core/process.py:155-162 `[index_min:index_max]`,
  *            util/time.py:104-108); idx_max = 0 means 2n-1.
