@@ -28,7 +28,23 @@ class DeviceArray:
         self.ptr = p.value
         ctx._children.add(self)
 
+    def columns_from(self, col0):
+        """Non-owning view of a 2-D buffer starting at column `col0`: shape [rows, cols-col0],
+        same row pitch (pass ``stride_s=self.shape[-1]`` to the consumer)."""
+        if len(self.shape) != 2 or not 0 <= col0 < self.shape[1]:
+            raise ValueError('columns_from needs a 2-D buffer and a column inside it')
+        v = DeviceArray.__new__(DeviceArray)
+        v.ctx, v.dtype = self.ctx, self.dtype
+        v.shape = (self.shape[0], self.shape[1] - int(col0))
+        v.nbytes = 0
+        v.ptr = self.ptr + int(col0) * self.dtype.itemsize
+        v._owner = self                      # keeps the allocation alive; the view frees nothing
+        return v
+
     def free(self):
+        if getattr(self, '_owner', None) is not None:
+            self.ptr = None
+            return
         # a context that is already closed has released everything it owned
         # (finalisers may run in any order at interpreter exit)
         if self.ptr and self.ctx.handle:
