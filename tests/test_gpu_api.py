@@ -216,3 +216,28 @@ def test_prepare_pipelines_the_forward_transforms(ctx):
         CCPlan(ctx, n, stack=True).prepare(da, W, hop)
     with pytest.raises(ValueError):
         plan.prepare(a, W, hop)                    # host array
+
+
+def test_column_views_select_window_blocks(ctx):
+    """DeviceArray.columns_from: a rank that owns windows [w0, w1) of a day passes a view that
+    starts at its first window (bench.py --shard windows)."""
+    import numpy as np
+    from xcorr_amd.engine import CCPlan
+    rng = np.random.default_rng(5)
+    S, n, hop, W = 4, 2000, 1000, 7
+    T = (W - 1) * hop + n
+    a = rng.standard_normal((S, T)).astype(np.float32)
+    pairs = np.array([(0, 1), (2, 3), (1, 3)], np.int32)
+    plan = CCPlan(ctx, n)
+    d = ctx.array(a)
+    ld = (plan.L + 31) // 32 * 32
+    full = plan.pairs(d, pairs, W, hop, out=ctx.empty((3 * W, ld)), ld_out=ld).to_host().reshape(3, W, ld)
+    w0, Wr = 2, 3
+    v = d.columns_from(w0 * hop)
+    assert v.shape == (S, T - w0 * hop)
+    part = plan.pairs(v, pairs, Wr, hop, out=ctx.empty((3 * Wr, ld)), ld_out=ld, stride_s=T).to_host().reshape(3, Wr, ld)
+    assert np.array_equal(part[..., :plan.L], full[:, w0:w0 + Wr, :plan.L])
+    v.free()
+    assert d.ptr                                   # the view frees nothing
+    with pytest.raises(ValueError):
+        d.columns_from(T)
