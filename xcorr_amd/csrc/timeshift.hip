@@ -39,33 +39,41 @@ namespace {
 
 // hr[r][t] = h_r[(-t) mod n]: the correlation engine computes
 // R[lag] = sum_t x[t+lag] hr[t], so R folded over the period is x (*) h
+// With n u = m - n alpha:  sin((n-1) pi u) = sin(n pi u) cos(pi u) - cos(n pi u) sin(pi u) and
+// sin(n pi u) = -(-1)^m sin(pi n alpha), cos(n pi u) = (-1)^m cos(pi n alpha), so the two
+// cosine terms cancel and   h[m] = -(-1)^m sin(pi n alpha) cot(pi u) / n   -- one sincospi
+// per sample (float64: u is a small difference near the peak) instead of three circular
+// functions; the removable singularity u -> 0 takes the limit (n-1 + cos(pi n alpha)(-1)^m)/n.
 __global__ void k_dirichlet(float* __restrict__ hr, long n, long rows, const double* __restrict__ alpha) {
-  const long total = rows * n;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / n, t = i % n;
-    const long m = (t == 0) ? 0 : n - t;
-    const double al = alpha[r];
-    double u = (double)m / (double)n - al;
-    u -= rint(u);                                   // [-1/2, 1/2]
-    const double s = sin(M_PI * u);
-    double ratio;
-    if (fabs(s) < 1e-12) ratio = (double)(n - 1);
-    else ratio = sin((double)(n - 1) * M_PI * u) / s;
-    const double nyq = cos(M_PI * (double)n * al) * ((m & 1) ? -1.0 : 1.0);
-    hr[i] = (float)((ratio + nyq) / (double)n);
-  }
+  // grid (ceil(n / 256), rows): no 64-bit division per sample
+  const long r = blockIdx.y;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n || r >= rows) return;
+  const long m = (t == 0) ? 0 : n - t;
+  const double al = alpha[r];
+  const double inv_n = 1.0 / (double)n;
+  double u = (double)m * inv_n - al;
+  u -= rint(u);                                     // [-1/2, 1/2]
+  double su, cu;
+  sincospi(u, &su, &cu);
+  double sa, ca;
+  sincospi(fmod((double)n * al, 2.0), &sa, &ca);    // row constants
+  const double sgn = (m & 1) ? -1.0 : 1.0;
+  double h;
+  if (fabs(su) < 1e-12) h = ((double)(n - 1) + ca * sgn) * inv_n;
+  else h = -sgn * sa * (cu / su) * inv_n;
+  hr[r * n + t] = (float)h;
 }
 
 // y[r][m] = R[r][m + n - 1] + (m >= 1 ? R[r][m - 1] : 0)
 __global__ void k_fold(const float* __restrict__ lin, long ld, float* __restrict__ y, long n, long rows) {
-  const long total = rows * n;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long r = i / n, m = i % n;
-    const float* R = lin + r * ld;
-    float v = R[m + n - 1];
-    if (m >= 1) v += R[m - 1];
-    y[i] = v;
-  }
+  const long r = blockIdx.y;
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n || r >= rows) return;
+  const float* R = lin + r * ld;
+  float v = R[m + n - 1];
+  if (m >= 1) v += R[m - 1];
+  y[r * n + m] = v;
 }
 
 }  // namespace
@@ -114,16 +122,15 @@ extern "C" int xcx_timeshift(xcx_ctx* ctx, const float* x, float* y, long batch,
   std::vector<PwDesc> d(chunk);
   for (long r0 = 0; r0 < batch; r0 += chunk) {
     const int cnt = (int)std::min<long>(chunk, batch - r0);
-    const long tot = (long)cnt * n;
-    const int grid = (int)std::min<long>((tot + 255) / 256, 256L * 16);
-    hipLaunchKernelGGL(k_dirichlet, dim3(grid), dim3(256), 0, ctx->stream, (float*)hr.ptr, n, (long)cnt,
+    const dim3 grid((unsigned)((n + 255) / 256), (unsigned)cnt);
+    hipLaunchKernelGGL(k_dirichlet, grid, dim3(256), 0, ctx->stream, (float*)hr.ptr, n, (long)cnt,
                        (const double*)dal.ptr + r0);
     HIP_TRY(hipGetLastError());
     if ((rc = xcx_internal_forward(plan, xd + r0 * size, size, 0, 1, 0, 0, cnt, 0))) return rc;
     if ((rc = xcx_internal_forward(plan, (const float*)hr.ptr, n, 0, 1, 0, 0, cnt, cnt))) return rc;
     for (int i = 0; i < cnt; ++i) d[i] = PwDesc{i, cnt + i, (long long)i * ld};
     if ((rc = xcx_internal_pairs(plan, d.data(), cnt, (float*)lin.ptr))) return rc;
-    hipLaunchKernelGGL(k_fold, dim3(grid), dim3(256), 0, ctx->stream, (const float*)lin.ptr, ld, yd + r0 * n, n,
+    hipLaunchKernelGGL(k_fold, grid, dim3(256), 0, ctx->stream, (const float*)lin.ptr, ld, yd + r0 * n, n,
                        (long)cnt);
     HIP_TRY(hipGetLastError());
   }
