@@ -386,7 +386,7 @@ hipError_t launch_tiles(xcx_ctx* ctx, float* x, long row_stride, long n, long Lc
 // non-null.
 template <int K, bool REV>
 int run_pass(xcx_ctx* ctx, float* x, long rows, long n, const SosParams& P,
-             const double* init, double* fend, DevBuf& zbuf, DevBuf& mbuf) {
+             const double* init, double* fend, DevBuf& zbuf, DevBuf& /*unused: matrices live in ctx->sos_tab*/) {
   const int D = 2 * K;
   long Lc = n;
   int nchunks = 1;
@@ -426,7 +426,6 @@ int run_pass(xcx_ctx* ctx, float* x, long rows, long n, const SosParams& P,
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->sos_key = key;
   }
-  (void)mbuf;
   const double* PW = (const double*)ctx->sos_tab.ptr;
   const double* PWs = PW + (size_t)(kScanG + 1) * D * D;
   const double* Mfull = PW + (size_t)D * D;                  // A^Lc

@@ -1026,15 +1026,12 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
         p->gram_ntiles = (int)tiles.size();
         p->gram_key = key;
         // duplicate pairs share a row of C: point their descriptors at it
-        bool dup = false;
         for (size_t q = 0; q < (size_t)P; ++q) {
           const int pi = (int)(p->hdescs[q].out_off / ld_out);
           const int row = pidx[(size_t)pairs[2 * pi] * S + pairs[2 * pi + 1]];
           p->hdescs[q].slot_a = row;
           p->hdescs[q].slot_b = row;
-          dup |= row != (int)q;
         }
-        (void)dup;
         if ((rc = upload(ctx, p->descs, p->hdescs.data(), ndesc * sizeof(PwDesc)))) return rc;
       }
       if ((rc = p->gramC.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)P))) return rc;
