@@ -42,9 +42,7 @@ def run(budget=60.0, seed=0, ctx=None):
         scale *= W
     err = float(np.abs(got - ref).max() / max(scale, 1e-30))
     worst = max(worst, err); cases += 1
-    # sign(x - mean) is discontinuous: a sample within float rounding of the window mean may
-    # flip, which moves a normalised one-bit CCF by 2/n -- allow a couple of such flips
-    tol = 1e-5 + (4.5 / n if (flags['onebit'] and flags['demean']) else 0.0)
+    tol = 1e-5          # one-bit after demean decides its signs in float64 on the GPU, like the oracle
     if not (err < tol):
         raise AssertionError(f'{dict(n=n, W=W, hop=hop, S=S, imin=imin, imax=imax, stack=stack, P=len(pairs), **flags)}: {err}')
     plan.close()

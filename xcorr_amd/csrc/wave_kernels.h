@@ -122,12 +122,21 @@ XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in
 // part[sw][p] (p < kStatParts): phase 0 sum(x), phase 1 sum(x'^2)
 constexpr int kStatParts = 16;
 
-XCX_DEV float sw_mean(const double* __restrict__ psum, int sw, int n, bool demean) {
-  if (!demean) return 0.f;
+XCX_DEV double sw_mean_d(const double* __restrict__ psum, int sw, int n, bool demean) {
+  if (!demean) return 0.0;
   double s = 0.0;
 #pragma unroll
   for (int p = 0; p < kStatParts; ++p) s += psum[sw * kStatParts + p];
-  return (float)(s / (double)n);
+  return s / (double)n;
+}
+XCX_DEV float sw_mean(const double* __restrict__ psum, int sw, int n, bool demean) {
+  return (float)sw_mean_d(psum, sw, n, demean);
+}
+// one-bit after demeaning: the sign is decided in float64 (x - mean rounded to float32 can
+// flip the sign of a sample that sits within an ulp of the window mean)
+XCX_DEV float onebit_of(float x, double mean_d) {
+  const double d = (double)x - mean_d;
+  return (d > 0.0) ? 1.f : ((d < 0.0) ? -1.f : 0.f);
 }
 XCX_DEV float sw_scale(const double* __restrict__ psq, int sw, int N, int flags, float fixed_norm) {
   double nrm = 1.0;
@@ -178,18 +187,22 @@ void k_wfwd_rows(WF1Args a) {
   const int row0 = (blockIdx.x * kF1WPB + wave_in_group()) * kWRB;
   const float* __restrict__ x = a.traces + (long)s * a.stride_s + (long)(a.w0 + wl) * a.stride_w;
   const int n = g.n, N1 = g.N1;
-  const float mean = sw_mean(a.psum, sw, n, g.flags & XCX_F_DEMEAN);
+  const double mean_d = sw_mean_d(a.psum, sw, n, g.flags & XCX_F_DEMEAN);
+  const float mean = (float)mean_d;
   // branch-free gather of the zero-padded window: indices beyond the window
   // are clamped (the load hits the cached last sample) and the value zeroed,
   // so all loads of a lane are in flight together
   auto in = [=](int m, int r) -> cf {
     const int i0 = row0 + r + N1 * (2 * m);
     const int i1 = i0 + N1;
-    float v0 = x[i0 < n ? i0 : n - 1] - mean;
-    float v1 = x[i1 < n ? i1 : n - 1] - mean;
+    const float x0 = x[i0 < n ? i0 : n - 1], x1 = x[i1 < n ? i1 : n - 1];
+    float v0, v1;
     if constexpr (ONEBIT) {
-      v0 = (v0 > 0.f) ? 1.f : ((v0 < 0.f) ? -1.f : 0.f);
-      v1 = (v1 > 0.f) ? 1.f : ((v1 < 0.f) ? -1.f : 0.f);
+      v0 = onebit_of(x0, mean_d);
+      v1 = onebit_of(x1, mean_d);
+    } else {
+      v0 = x0 - mean;
+      v1 = x1 - mean;
     }
     return make_float2(i0 < n ? v0 : 0.f, i1 < n ? v1 : 0.f);
   };

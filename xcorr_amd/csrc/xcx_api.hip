@@ -86,10 +86,10 @@ __global__ __launch_bounds__(kNT) void k_wstats(
   if (PHASE == 0) {
     for (int i = lo + tid; i < hi; i += kNT) acc += (double)x[i];
   } else {
-    const float mean = sw_mean(psum, swl, n, flags & XCX_F_DEMEAN);
+    const double mean_d = sw_mean_d(psum, swl, n, flags & XCX_F_DEMEAN);
+    const float mean = (float)mean_d;
     for (int i = lo + tid; i < hi; i += kNT) {
-      float v = x[i] - mean;
-      if (flags & XCX_F_ONEBIT) v = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
+      const float v = (flags & XCX_F_ONEBIT) ? onebit_of(x[i], mean_d) : x[i] - mean;
       acc += (double)v * (double)v;
     }
   }
