@@ -211,3 +211,13 @@ def test_running_absolute_mean_normalisation(ctx, h):
     from xcorr_amd._ffi import XcxError
     with pytest.raises(XcxError):
         ops.ram_normalize(ctx, x, 3073)
+
+
+def test_rms_along_last_axis(ctx):
+    import xcorr_amd.signal as sig
+    rng = np.random.default_rng(12)
+    x = (rng.standard_normal((3, 4, 7001)) + 0.5).astype(np.float32)
+    got = sig.rms(x)
+    assert got.shape == (3, 4)
+    assert relerr(got, np.sqrt(np.mean(np.square(x.astype(np.float64)), axis=-1))) < TOL
+    assert np.array_equal(sig.absolute(x), np.abs(x))

@@ -86,3 +86,10 @@ class SignalAccessor():
         return _fs.spectrogram(self._da, **kwargs)
 
     psd = spectrogram
+
+    @wraps(_f.rms)
+    def rms(self, **kwargs):
+        return _f.rms(self._da, **kwargs)
+
+    def abs(self):
+        return _f.absolute(self._da)

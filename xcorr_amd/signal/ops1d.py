@@ -286,6 +286,27 @@ def timeshift(x, delay, dtype=None, dim=None, fast=True, sampling_rate=None):
     return out.astype(dtype or x.dtype)
 
 
+# -- signal/rms.py:23-68, signal/absolute.py --------------------------------------
+def rms(x, dim=None):
+    """sqrt(mean(x**2)) along the last axis / `dim` (signal/rms.py:52-58)."""
+    if _is_da(x):
+        dim = _check_dim(x, dim)
+        xt = x.transpose(..., dim)
+        vals = rms(xt.values)
+        y = xr.DataArray(vals.astype(x.dtype), dims=xt.dims[:-1],
+                         coords={d: xt[d] for d in xt.dims[:-1] if d in xt.coords}, name=x.name, attrs=x.attrs)
+        return y
+    x = np.asarray(x)
+    n = x.shape[-1]
+    out = _ops.block_rms(None, np.ascontiguousarray(x, np.float32), n, n, 1)
+    return out[..., 0].astype(x.dtype if x.dtype.kind == 'f' else np.float32)
+
+
+def absolute(x):
+    """|x| (signal/absolute.py); elementwise, stays on the host array library."""
+    return abs(x)
+
+
 # -- signal/hilbert.py:29-120 ---------------------------------------------------
 def hilbert(x, dim=None, **kwargs):
     """Analytic signal along the last axis / `dim` (scipy.signal.hilbert, hilbert.py:69)."""
