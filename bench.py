@@ -6,26 +6,34 @@ bench.py -- pair-windows/s of the MI355X cross-correlation engine.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-One "step" = one station-day batch through the whole hot path on one GPU:
-preprocess of S day-long traces (demean -> cosine taper -> Butterworth
-bandpass), then for each of the W windows the forward transforms (per-window
-one-bit + spectral whitening fused) and the full-lag cross-correlation of all
-P = S(S-1)/2 pairs; every CCF (L = 2n-1 lags) is written to HBM.  Inputs are
-resident in HBM before the timed region; outputs stay in HBM.
+One "step" = one station-day batch through the whole hot path
+(xcorr_amd.workload.StationDay.step, the same object tests/test_gpu_config3.py
+checks against the oracle): preprocess of S day-long traces (demean -> cosine
+taper -> Butterworth bandpass), then for each of the W windows the forward
+transforms (per-window one-bit + spectral whitening fused) and the full-lag
+cross-correlation of all P = S(S-1)/2 pairs; every CCF (L = 2n-1 lags) is
+written to HBM.  Inputs are resident in HBM before the timed region; outputs
+stay in HBM.
 
 Workload (BASELINE.json configs[2], the one the metric is quoted on):
 S = 64 stations x 86400 s @ 50 Hz, n = 180000 (3600 s), 50 % overlap ->
 W = 47 windows, P = 2016 pairs, 94752 pair-windows per step.
 
-Multi-GPU: one process per GPU; every rank processes its own day (seeded by
-rank) -- the path shards over independent station-days / pair-windows with no
-data-path collective ("scaling": "weak").  --shard pairs splits the pair list
-of ONE day over the ranks instead (strong scaling).  RCCL is only used for the
-start/stop rendezvous (and for the time-stack reduce with --stack).
-
-Prints ONE JSON line on rank 0.
+Multi-GPU (one process per GPU, no data-path collective -- SURVEY 8e):
+  N > 1 default, --shard windows : STRONG scaling.  The ranks split the windows of ONE
+      station-day into contiguous blocks; every rank filters the whole day (3 % of a
+      step) but transforms and correlates only its own windows.
+  --shard pairs : strong scaling over the pair list (every rank transforms all windows).
+  --shard days  : weak scaling, every rank its own station-day.
+  --stack [--days D] : BASELINE configs[3].  D station-days are dealt to the ranks, every
+      rank accumulates its days' cross-spectra in the frequency domain
+      (xcx_cc1d_stack_add), inverse-transforms once and the per-rank partial stacks are
+      summed with ONE RCCL reduce-scatter over xGMI (xcx_stack_reduce).
+The launcher's ranks meet through a directory of files (xcorr_amd/rendezvous.py): no
+torch, no MPI.  Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -33,7 +41,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
 
 FS = 50.0
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -49,30 +58,42 @@ def parse():
     ap.add_argument('--window', type=float, default=3600.0)
     ap.add_argument('--overlap', type=float, default=0.5)
     ap.add_argument('--batch', type=int, default=0, help='pair-windows per launch batch')
-    ap.add_argument('--shard', choices=['days', 'pairs', 'windows'], default='days')
+    ap.add_argument('--shard', choices=['auto', 'days', 'pairs', 'windows'], default='auto',
+                    help='auto = windows (strong scaling) for N > 1')
     ap.add_argument('--clip-lag', type=float, default=0.0,
                     help='retain only lags within +-SECONDS (the reference\'s clip_lag); 0 = full lag')
     ap.add_argument('--no-preprocess', action='store_true',
                     help='configs[1]-style: raw traces, L2 normalisation only')
     ap.add_argument('--stack', action='store_true', help='time-stack mode (configs[3])')
+    ap.add_argument('--days', type=int, default=0,
+                    help='--stack: station-days per step, dealt to the ranks (default: one per rank)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--pipeline-front-end', action='store_true',
                     help='overlap the next step\'s preprocess + forward transforms with the pair phase '
                          '(xcx_cc1d_prepare; measured 20-25 %% SLOWER: the streaming front end evicts the '
-                         'cache-resident T ring of the pair pipelines -- kept for A/B)')
+                         'cache-resident T ring of the pair pipelines -- kept for A/B; --shard days only)')
     return ap.parse_args()
 
 
-def synth_day(S, T, day):
-    from xcorr_amd.synth import synthetic_traces
-    return synthetic_traces(S, T, day=day)
+def fast_day(S, T, day):
+    """Cheap synthetic station-day for multi-day runs (float32 generator; same structure as
+    xcorr_amd.synth: common signal with 25-sample moveout + noise + offset)."""
+    rng = np.random.default_rng(777 + day)
+    c = rng.standard_normal(T + 25 * S, dtype=np.float32)
+    out = rng.standard_normal((S, T), dtype=np.float32)
+    for s in range(S):
+        off = 25 * (S - 1 - s)
+        out[s] += 0.5 * c[off:off + T]
+        out[s] += 3.0
+    return out
 
 
 # ---------------------------------------------------------------------------
 # CPU baseline: the oracle's faithful restatement of util/cc.py (complex FFT of
-# length 2n-1), one process per host core, bounded sample.
+# length 2n-1), one process per host core, bounded sample; plus the oracle's
+# preprocess of one station-day row (BASELINE.md section 3 item 4).
 # ---------------------------------------------------------------------------
 def _cpu_worker(args):
     seed, n, reps, fair = args
@@ -89,15 +110,40 @@ def _cpu_worker(args):
     return time.perf_counter() - t0
 
 
-def cpu_baseline(n, seconds):
+def _cpu_pre_worker(args):
+    seed, T = args
+    os.environ['OMP_NUM_THREADS'] = '1'
+    from oracle import ref_numpy as R
+    from xcorr_amd import workload
+    x = np.random.default_rng(seed).standard_normal(T).astype(np.float32)
+    sos = workload.band_sos()
+    w = R.cosine_taper_obspy(T, FS, *workload.TAPER)
+    t0 = time.perf_counter()
+    y = R.demean(x.astype(np.float64)[None])
+    y = y * w
+    R.sosfilt(sos, y)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(n, T, seconds, preprocess):
     import multiprocessing as mp
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    # a one-GPU box owns a 16-core share of its host (more workers only
-    # oversubscribe it); override with XCX_CPU_CORES
-    cores = int(os.environ.get('XCX_CPU_CORES', min(cores, 16)))
+    for qf, pf in (('/sys/fs/cgroup/cpu.max', None),             # a container's CPU share, if smaller
+                   ('/sys/fs/cgroup/cpu/cpu.cfs_quota_us', '/sys/fs/cgroup/cpu/cpu.cfs_period_us')):
+        try:
+            if pf is None:
+                q, per = open(qf).read().split()
+            else:
+                q, per = open(qf).read().strip(), open(pf).read().strip()
+            if q not in ('max', '-1'):
+                cores = max(1, min(cores, -(-int(q) // int(per))))
+            break
+        except (OSError, ValueError):
+            continue
+    cores = int(os.environ.get('XCX_CPU_CORES', cores))     # every core this process may use
     for v in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS'):
         os.environ[v] = '1'
     ctx = mp.get_context('spawn')
@@ -115,8 +161,22 @@ def cpu_baseline(n, seconds):
         t0 = time.perf_counter()
         pool.map(_cpu_worker, [(200 + i, n, 20, True) for i in range(cores)])
         out['fair'] = cores * 20 / (time.perf_counter() - t0)
+        if preprocess:
+            t0 = time.perf_counter()
+            pool.map(_cpu_pre_worker, [(300 + i, T) for i in range(cores)])
+            out['preprocess_station_days_per_s'] = cores / (time.perf_counter() - t0)
     out['cores'] = cores
     return out
+
+
+def lib_sha256():
+    from xcorr_amd import _ffi
+    path = getattr(_ffi, 'LIB_PATH', os.path.join(ROOT, 'xcorr_amd', 'lib', 'libxcx.so'))
+    h = hashlib.sha256()
+    with open(path, 'rb') as fh:
+        for blk in iter(lambda: fh.read(1 << 20), b''):
+            h.update(blk)
+    return h.hexdigest()
 
 
 def main():
@@ -126,14 +186,12 @@ def main():
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if world != a.gpus and world > 1:
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+    from xcorr_amd import rendezvous
+    rdzv = rendezvous.from_env()
 
     import xcorr_amd as X
-    from xcorr_amd import _ffi
-    from xcorr_amd import ops
+    from xcorr_amd import _ffi, ops, workload
+    from xcorr_amd.synth import synthetic_traces
     import ctypes as _C
     ndev = _C.c_int(0)
     _ffi.check(_ffi.lib().xcx_device_count(_C.byref(ndev)))
@@ -144,7 +202,7 @@ def main():
     T = int(round(a.seconds * FS))
     n = int(round(a.window * FS))
     hop = int(round(n * (1.0 - a.overlap)))
-    W = (T - n) // hop + 1
+    W_all = (T - n) // hop + 1
     L = 2 * n - 1
     imin, imax = 0, L
     if a.clip_lag > 0:
@@ -152,80 +210,80 @@ def main():
         imin, imax = n - 1 - half, n + half
         L = imax - imin
     pairs_all = np.array([(i, j) for i in range(S) for j in range(i + 1, S)], np.int32)
-    w_first, W_all = 0, W
-    if a.shard == 'pairs' and world > 1:
+    shard = a.shard
+    if shard == 'auto':
+        shard = 'days' if (world == 1 or a.stack) else 'windows'
+    if a.stack and shard != 'days':
+        raise SystemExit('--stack shards station-days over the ranks (--shard days)')
+    w_first, W = 0, W_all
+    pairs, day0 = pairs_all, 0
+    if world > 1 and shard == 'pairs':
         pairs = np.ascontiguousarray(pairs_all[rank::world])     # cyclic over the triangle
-        day = 0
-    elif a.shard == 'windows' and world > 1:
-        # strong scaling over the windows of ONE day: contiguous blocks, every rank filters the
-        # whole day (2.7 ms) but transforms and correlates only its own windows
-        pairs = pairs_all
-        day = 0
+    elif world > 1 and shard == 'windows':
         w_first = (W_all * rank) // world
         W = (W_all * (rank + 1)) // world - w_first
-    else:
-        pairs = pairs_all
-        day = rank
+    elif world > 1:
+        day0 = rank
     P = len(pairs)
-    ld = (L + 31) // 32 * 32          # 128-byte aligned output rows
-
     preprocess = not a.no_preprocess
-    whiten = (FS, 0.1, 10.0, 0.05) if preprocess else None
-    plan = X.CCPlan(ctx, n, imin, imax, normalize=True, onebit=preprocess, whiten=whiten,
-                    stack=a.stack, batch=a.batch or None)
 
-    # ---- synthetic inputs, resident in HBM before the clock starts ---------
-    raw_h = synth_day(S, T, day)
-    raw = ctx.array(raw_h)
-    work = ctx.empty((S, T)) if preprocess else raw
-    nrows = P if a.stack else P * W
-    out = ctx.empty((nrows, ld))
-    del raw_h
-    if preprocess:
-        import scipy.signal
-        sos = scipy.signal.butter(4, [0.1, 10.0], btype='bandpass', output='sos', fs=FS)
-        taper_n = min(int(0.05 * T), int(30.0 * FS), T // 2)
+    # ---- station-days of this rank, resident in HBM before the clock starts ----
+    ndays = 1
+    my_days = [day0]
+    if a.stack:
+        ndays = a.days or world
+        from xcorr_amd.shard import shard_days
+        my_days = shard_days(ndays, rank, world)
+    sd = workload.StationDay(ctx, S, T, n, hop, pairs, imin, imax, preprocess=preprocess, stack=a.stack,
+                             batch=a.batch or None, w_first=w_first, W=W)
+    plan = sd.plan
+    ld = sd.ld
+    raws = []
+    for d in my_days:
+        host = synthetic_traces(S, T, day=d) if len(my_days) == 1 and ndays <= world else fast_day(S, T, d)
+        if not raws:
+            sd.load(host)
+            raws.append(sd.raw)
+        else:
+            raws.append(ctx.array(host))
+        del host
+    nrows = sd.nrows
+    out = sd.out
 
-    lib = _ffi.lib()
-    wview = work.columns_from(w_first * hop) if w_first else work     # this rank's first window
-
-    # time-stack across ranks (configs[3]): the only exchange step of the path,
-    # one RCCL all-reduce of the per-rank partial stacks over xGMI
+    # time-stack across ranks (configs[3]): the only exchange step of the path
     rccl = None
-    if a.stack and dist is not None:
-        try:
-            uid = [X.Context.comm_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(uid, src=0)
-            ctx.comm_init(uid[0], world, rank)
-            rccl = True
-        except Exception as e:          # e.g. two ranks rehearsing on one GPU
-            rccl = f'unavailable: {e}'
+    if a.stack and world > 1:
+        uid = rdzv.broadcast(X.Context.comm_unique_id() if rank == 0 else b'')
+        ctx.comm_init(uid, world, rank)          # a failure here is fatal: no silent partial stacks
+        rccl = 'reduce_scatter' if (nrows * ld) % world == 0 else 'all_reduce'
 
     def step():
-        if preprocess:
-            ops.copy(ctx, work, raw)
-            ops.demean(ctx, work)
-            ops.taper(ctx, work, taper_n, wtype='cosine')
-            ops.sosfilt(ctx, work, sos)
-        plan.pairs(wview, pairs, W, hop, out=out, ld_out=ld, stride_s=T)
-        if rccl is True:
-            ctx.stack_reduce(out, count=nrows * ld)
+        if not a.stack:
+            sd.step()
+            return
+        if len(my_days) == 1 and world == 1:
+            sd.step()                            # single stacked day: xcx_cc1d_pairs(XCX_STACK)
+            return
+        for r in raws:
+            sd.raw = r
+            sd.front()
+            plan.stack_add(sd.view, pairs, W, hop, stride_s=T)
+        if raws:
+            plan.stack_finish(pairs, out=out, ld_out=ld)
+        else:
+            out.zero()                           # more ranks than days: contributes zeros
+        if rccl:
+            ctx.stack_reduce(out, count=nrows * ld, reduce_scatter=(rccl == 'reduce_scatter'))
 
-    # Optional software pipelining across steps (--pipeline-front-end): while the pair phase of step k
-    # runs, step k+1 is preprocessed on a second context (own stream) and its windows are
-    # transformed on the plan's side stream (xcx_cc1d_prepare).  Every step's full work stays
-    # inside the timed region.  Off by default: it measures slower (see --help).
-    pipelined = preprocess and not a.stack and a.pipeline_front_end and W >= 2
+    # Optional software pipelining across steps (--pipeline-front-end), off by default.
+    pipelined = preprocess and not a.stack and a.pipeline_front_end and W >= 2 and shard == 'days'
     ctx2 = X.Context(local % max(ndev.value, 1)) if pipelined else None
 
     def front():
         plan.prepare_sync()                 # the previous prepare no longer reads `work`
-        ops.copy(ctx2, work, raw)
-        ops.demean(ctx2, work)
-        ops.taper(ctx2, work, taper_n, wtype='cosine')
-        ops.sosfilt(ctx2, work, sos)
+        sd.front(ctx2)
         ctx2.sync()
-        plan.prepare(work, W, hop)
+        plan.prepare(sd.work, W, hop)
 
     def run(K):
         if not pipelined:
@@ -235,14 +293,13 @@ def main():
         if K > 0:
             front()
         for k in range(K):
-            plan.pairs(work, pairs, W, hop, out=out, ld_out=ld)      # consumes the prepared spectra
+            sd.correlate()                       # consumes the prepared spectra
             if k + 1 < K:
                 front()
 
     def barrier():
         ctx.sync()
-        if dist is not None:
-            dist.barrier()
+        rdzv.barrier()
 
     run(a.warmup)
     barrier()
@@ -251,44 +308,43 @@ def main():
     run(a.steps)
     ev_ms = ctx.timer_stop()
     ctx.sync()
-    wall = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        t = torch.tensor([wall], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        wall = float(t.item())
-        dist.barrier()
+    wall = rdzv.max(time.perf_counter() - t0)
+    rdzv.barrier()
 
-    units_rank = P * W * a.steps
-    units_all = units_rank * world if a.shard == 'days' else len(pairs_all) * W_all * a.steps
+    units_rank = P * W * a.steps * (len(my_days) if a.stack else 1)
+    if a.stack:
+        units_all = len(pairs_all) * W_all * ndays * a.steps
+    elif shard == 'days':
+        units_all = units_rank * world
+    else:
+        units_all = len(pairs_all) * W_all * a.steps
     value = units_all / wall
 
     # ---- per-kernel timing of one extra step (HIP events on the stream the
     #      kernels are launched on, inside the library) ----------------------
     kern = None
-    if not a.no_kernel_timing and rank == 0:
-        kern = plan.profile_step(step, level=2)
+    if not a.no_kernel_timing and rank == 0 and world == 1:      # roofline leg: N = 1 only (a lone rank
+        kern = plan.profile_step(step, level=2)                    # cannot re-run a step with a collective)
         phase = plan.profile_step(step, level=1)
         if 'pair_phase' in phase:
             kern['pair_phase'] = phase['pair_phase']
 
     # ---- context numbers (rank 0, outside the timed region) -----------------
     extras = {}
-    if not a.no_kernel_timing and rank == 0:
+    if not a.no_kernel_timing and rank == 0 and world == 1:
         # measured device-copy ceiling next to the nominal HBM peak
-        src_b = raw
-        dst_b = work if work is not raw else ctx.empty(raw.shape)
+        src_b = sd.raw
+        dst_b = sd.work if sd.work is not sd.raw else ctx.empty(sd.raw.shape)
         ops.copy(ctx, dst_b, src_b); ctx.sync()
         t1 = time.perf_counter()
         for _ in range(5):
             ops.copy(ctx, dst_b, src_b)
         ctx.sync()
         extras['copy_GBps_measured'] = 5 * 2 * src_b.nbytes / (time.perf_counter() - t1) / 1e9
-        # PCIe-inclusive rate of the host-pointer form of the same call (bounded sample):
-        # traces in pageable host memory, CCFs copied back
+        # PCIe-inclusive rate of the host-pointer form of the same call (bounded sample)
         try:
             S_h, W_h = min(S, 8), min(W, 3)
-            host_tr = raw.rows_to_host(0, S_h, (W_h - 1) * hop + n)
+            host_tr = sd.raw.rows_to_host(0, S_h, (W_h - 1) * hop + n)
             prs = np.array([(i, j) for i in range(S_h) for j in range(i + 1, S_h)], np.int32)
             hplan = X.CCPlan(ctx, n, normalize=True)
             hplan.pairs(host_tr, prs[:2], W_h, hop)
@@ -298,11 +354,17 @@ def main():
             extras['pcie_inclusive'] = {
                 'value': len(prs) * W_h / dt_h, 'unit': 'pair-windows/s',
                 'sample': f'{len(prs) * W_h} pair-windows, host traces in ({host_tr.nbytes / 1e6:.0f} MB) and '
-                          f'full-lag CCFs out ({len(prs) * W_h * L * 4 / 1e6:.0f} MB) through pageable memory'}
+                          f'full-lag CCFs out ({len(prs) * W_h * L * 4 / 1e6:.0f} MB) through host memory'}
             hplan.close()
         except Exception as e:          # context number only
             extras['pcie_inclusive'] = {'error': str(e)}
 
+    workload_str = (f'{S} stations x {a.seconds:.0f} s @ {FS:.0f} Hz, {len(pairs_all)} pairs x {W_all} windows '
+                    f'(n={n}, {a.overlap:.0%} overlap), '
+                    + (f'lags +-{a.clip_lag:g} s L={L}, ' if a.clip_lag > 0 else f'full lag L={L}, ')
+                    + ('demean+cosine-taper+bandpass(0.1-10 Hz, 4 corners) per station-day, '
+                       'one-bit+whitening per window' if preprocess else 'no preprocess')
+                    + (f', time-stack over {ndays} station-day(s)' if a.stack else ''))
     res = {
         'metric': 'pair-windows/s' if not a.stack else 'pair-windows/s (stacked: windows summed per pair)',
         'value': value,
@@ -312,75 +374,81 @@ def main():
         'warmup': a.warmup,
         'ms_per_step': 1e3 * wall / a.steps,
         'higher_is_better': True,
-        'scaling': 'weak' if a.shard == 'days' else 'strong',
+        'scaling': 'weak' if (shard == 'days' and not (a.stack and a.days)) else 'strong',
         'vs_baseline': None,
         'dtype': 'f32',
         'data': 'synthetic',
         'config': {
-            'workload': (f'{S} stations x {a.seconds:.0f} s @ {FS:.0f} Hz, {len(pairs_all)} pairs x {W_all} windows '
-                         f'(n={n}, {a.overlap:.0%} overlap), ' + (f'lags +-{a.clip_lag:g} s L={L}, ' if a.clip_lag > 0 else f'full lag L={L}, ')
-                         + ('demean+cosine-taper+bandpass(0.1-10 Hz, 4 corners) per station-day, '
-                            'one-bit+whitening per window' if preprocess else 'no preprocess')
-                         + (', time-stack' if a.stack else '')),
+            'workload': workload_str,
             'fft_length': plan.N, 'pair_batch': plan.batch,
-            'shard': a.shard,
-            'overlap_next_step_front_end': bool(pipelined), 'per_rank_pair_windows_per_step': P * W,
+            'shard': shard,
+            'overlap_next_step_front_end': bool(pipelined), 'per_rank_pair_windows_per_step': units_rank // a.steps,
         },
         'cc_samples_per_s': value * L,
         'event_ms_per_step_rank0': ev_ms / a.steps,
     }
     if a.stack:
         res['rccl_stack_reduce'] = rccl
+        res['config']['station_days'] = ndays
     if rank == 0:
+        sha = lib_sha256()
+        res['lib_sha256'] = sha
         # algorithmic bytes per pair-window: every CCF written once
         # + every station window read once (+ the preprocess pass over the day)
         b_pw = 4.0 * L + 4.0 * n * S / len(pairs_all)
         if preprocess:
-            b_pw += 2.0 * 4.0 * T * S / (len(pairs_all) * W)
+            b_pw += 2.0 * 4.0 * T * S / (len(pairs_all) * W_all)
         res['algorithmic_bytes_per_pair_window'] = b_pw
-        res['pipeline_GBps'] = (P * W / (1e-3 * ev_ms / a.steps)) * b_pw / 1e9
+        res['pipeline_GBps'] = (units_rank / a.steps / (1e-3 * ev_ms / a.steps)) * b_pw / 1e9
         res['pipeline_frac_of_hbm_peak'] = res['pipeline_GBps'] / HBM_PEAK_GBS
         if kern:
-            # The inverse pass of a pair-window is two launches: k_pair_cols (I1)
-            # and k_pair_rows (I2).  I2 writes every algorithmic output byte and
-            # is the kernel the roofline is quoted for; `pass` prices the whole
-            # two-launch pass against the full algorithmic bytes per pair-window.
             dom = 'k_pair_dual' if 'k_pair_dual' in kern else 'k_pair_rows'
             names = [k for k in ('k_pair_cols', 'k_pair_rows', 'k_pair_dual') if k in kern]
             B = kern[dom]['units_per_launch']
-            pmc = {}
-            pmc_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'pmc_latest.json')
+            # PMC traffic of the dominant kernel: only from a profile of THIS library build on
+            # THIS workload (tools/prof.sh stamps pmc_latest.json); anything else is null
+            tr, tr_note = None, 'no profiles/pmc_latest.json'
+            pmc_path = os.path.join(ROOT, 'profiles', 'pmc_latest.json')
             if os.path.exists(pmc_path):
                 try:
                     pmc = json.load(open(pmc_path))
-                except Exception:
-                    pmc = {}
+                    st = pmc.get('_stamp', {})
+                    if st.get('lib_sha256') != sha:
+                        tr_note = 'pmc_latest.json was measured on another libxcx.so build'
+                    elif st.get('workload') != workload_str or st.get('pair_batch') != plan.batch:
+                        tr_note = 'pmc_latest.json was measured on another workload'
+                    else:
+                        tr = pmc.get(dom, {}).get('hbm_bytes_per_launch')
+                        tr_note = f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of {st.get('tag')}"
+                except Exception as e:
+                    tr_note = f'pmc_latest.json unreadable: {e}'
             whole_pass = dom == 'k_pair_dual'
             alg_dom = B * (b_pw if whole_pass else 4.0 * L)
-            # k_pair_dual launches of the two pipelines overlap on the GPU: the time
-            # one launch's worth of work takes is the pair-phase wall time (HIP events
-            # on the main stream) divided by the number of launches
+            # k_pair_dual launches of the pipelines overlap on the GPU: the time one launch's
+            # worth of work takes is the pair-phase wall time (HIP events on the main stream)
+            # divided by the number of launches (profiles/*_overlap.json shows the union)
             if whole_pass and 'pair_phase' in kern:
                 eff_us = kern['pair_phase']['total_us'] / kern[dom]['launches']
             else:
                 eff_us = kern[dom]['avg_us']
             ach = alg_dom / (eff_us * 1e-6) / 1e9
-            tr = pmc.get(dom, {}).get('hbm_bytes_per_launch')
+            copy = extras.get('copy_GBps_measured')
             res['roofline'] = {
                 'bound': 'hbm', 'kernel': dom, 'achieved': ach, 'peak': HBM_PEAK_GBS,
                 'unit': 'GB/s', 'frac': ach / HBM_PEAK_GBS,
-                'traffic': tr,
+                'traffic': tr, 'traffic_source': tr_note,
+                # the same algorithmic bytes priced three ways
+                'frac_pair_phase': ach / HBM_PEAK_GBS,
+                'frac_end_to_end': res['pipeline_frac_of_hbm_peak'],
+                'frac_of_measured_copy': (ach / copy) if copy else None,
                 'avg_launch_us': kern[dom]['avg_us'], 'launches': kern[dom]['launches'],
                 'effective_launch_us': eff_us,
                 'concurrent_pipelines': (kern[dom]['avg_us'] / eff_us) if eff_us else None,
                 'algorithmic_bytes_per_launch': alg_dom,
                 'pair_windows_per_launch': B,
                 'kernels_us': {k: v['avg_us'] for k, v in kern.items()},
-                # what the kernel actually moves between L2 and the fabric (Infinity Cache + HBM),
-                # from the PMC passes, at the effective launch time: the quantity that saturates
                 'traffic_GBps': (tr / (eff_us * 1e-6) / 1e9) if (tr and eff_us) else None,
-                'copy_GBps_measured': extras.get('copy_GBps_measured'),
-                'frac_of_measured_copy': (ach / extras['copy_GBps_measured']) if extras.get('copy_GBps_measured') else None,
+                'copy_GBps_measured': copy,
             }
             if 'pcie_inclusive' in extras:
                 res['pcie_inclusive'] = extras['pcie_inclusive']
@@ -390,17 +458,22 @@ def main():
                                            'achieved': B * b_pw / (pass_us * 1e-6) / 1e9,
                                            'frac': B * b_pw / (pass_us * 1e-6) / 1e9 / HBM_PEAK_GBS}
         if not a.no_cpu_baseline and world == 1:
-            cb = cpu_baseline(n, a.cpu_seconds)
+            cb = cpu_baseline(n, T, a.cpu_seconds, preprocess)
             res['cpu_baseline'] = {
                 'value': cb['faithful'], 'unit': 'pair-windows/s', 'cores': cb['cores'],
                 'kind': 'port', 'sample': cb['sample'],
                 'fair_rfft_value': cb['fair'],
             }
+            if 'preprocess_station_days_per_s' in cb:
+                # the preprocess stage on the same host cores,
+                # and the whole step (preprocess + faithful cc) priced per pair-window
+                pre = cb['preprocess_station_days_per_s']
+                res['cpu_baseline']['preprocess_station_days_per_s'] = pre
+                t_step = S / pre + len(pairs_all) * W_all / cb['faithful']
+                res['cpu_baseline']['whole_step_value'] = len(pairs_all) * W_all / t_step
             res['speedup_vs_cpu_baseline'] = value / cb['faithful']
         print(json.dumps(res), flush=True)
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    rdzv.close()
 
 
 if __name__ == '__main__':

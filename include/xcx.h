@@ -109,6 +109,21 @@ int xcx_cc1d_pairs(xcx_plan* plan, const float* traces, int S, int W,
                    long stride_s, long stride_w, const int* pairs, int P,
                    float* out, long ld_out, int on_device);
 
+/* Multi-call time-stack (BASELINE configs[3]: 30 days per pair): an XCX_STACK plan accumulates
+ * the cross-spectra  G[p][k] += sum_w X_{i,w}[k] conj X_{j,w}[k]  of every call in the frequency
+ * domain (one cgemm-shaped update per call on the matrix cores) and pays for the P inverse
+ * transforms once, in xcx_cc1d_stack_finish -- by linearity the result equals the sum over the
+ * calls of xcx_cc1d_pairs(XCX_STACK) outputs (the reference has no stack function; SURVEY 8c:
+ * oracle = sum over windows of util/cc.py:22-79 outputs).  Every add of one accumulation must
+ * pass the same S and pair list; W and the traces may differ.  finish writes row p at
+ * out + p*ld_out (L floats), returns the number of windows summed in *windows (may be null)
+ * and clears the accumulator.  xcx_cc1d_pairs on the same plan is refused while an
+ * accumulation is open. */
+int xcx_cc1d_stack_add(xcx_plan* plan, const float* traces, int S, int W, long stride_s,
+                       long stride_w, const int* pairs, int P, int on_device);
+int xcx_cc1d_stack_finish(xcx_plan* plan, const int* pairs, int P, float* out, long ld_out,
+                          int on_device, long long* windows);
+
 /* Software pipelining across batches (station-days): compute the spectra of ALL S x W
  * windows of `traces` (device pointer) on a side stream, into a second spectra buffer,
  * while the pair phase of the previous xcx_cc1d_pairs call is still running.  The next
@@ -177,6 +192,12 @@ int xcx_sosfiltfilt(xcx_ctx* ctx, float* x, long batch, long n,
                     const double* sos, int n_sections, int on_device);
 int xcx_sosfilt(xcx_ctx* ctx, float* x, long batch, long n, const double* sos,
                 int n_sections, int on_device);
+/* ObsPy Trace.filter(..., zerophase=True) (xcorr/stream/process.py:279-282 ->
+ * obspy.signal.filter): sosfilt from rest, then sosfilt of the reversed result
+ * from rest, reversed back.  No padding and no steady-state start values, so it
+ * differs from xcx_sosfiltfilt (scipy.signal.sosfiltfilt) near the row ends. */
+int xcx_sosfilt_zerophase(xcx_ctx* ctx, float* x, long batch, long n,
+                          const double* sos, int n_sections, int on_device);
 
 /* Signal-to-noise pieces of xcorr/signal/snr.py:107-116 (envelope=False): per
  * row, s = max |x| over the signal mask with its index (first occurrence) and
@@ -275,6 +296,9 @@ int xcx_spectrogram(xcx_ctx* ctx, const float* x, float* S, long batch, long n,
  * xcx_stack_reduce sums `count` floats in place across ranks
  * (ncclAllReduce) or leaves each rank with its count/nranks share
  * (ncclReduceScatter, reduce_scatter != 0; recv = stack + rank*count/nranks).
+ * Without a communicator on `ctx` it returns XCX_EINVAL (also for one rank:
+ * a single-rank world initialises a 1-rank communicator), so a failed or
+ * forgotten xcx_comm_init can never pass a partial stack off as the total.
  */
 int xcx_comm_unique_id(char* id_bytes128);
 int xcx_comm_init(xcx_ctx* ctx, const char* id_bytes128, int nranks, int rank);

@@ -28,7 +28,7 @@ import scipy.stats
 __all__ = [
     'cc', 'cc_fair', 'lag', 'weight', 'weight_full', 'lag_indices',
     'norm1d', 'correlate1d', 'demean', 'detrend_linear', 'window', 'taper',
-    'butter_sos', 'sosfiltfilt', 'sosfilt', 'unbias', 'timeshift',
+    'butter_sos', 'sosfiltfilt', 'sosfilt', 'sosfilt_zerophase', 'unbias', 'timeshift',
     'onebit', 'whiten_weights', 'whiten_spectrum', 'whiten_norm',
     'cosine_taper_obspy', 'clip_lag_indices', 'cc_pairs', 'stack',
     'next_fast_len', 'synthetic_traces', 'window_starts', 'all_pairs',
@@ -604,6 +604,15 @@ def cheby2_lowpass_sos(freq, sampling_rate, maxorder=12):
         order, wn = scipy.signal.cheb2ord(wp, ws, rp, rs, analog=0)
     z, p, k = scipy.signal.cheby2(order, rs, wn, btype='low', analog=0, output='zpk')
     return scipy.signal.zpk2sos(z, p, k)
+
+
+def sosfilt_zerophase(sos, x):
+    """ObsPy ``Trace.filter(..., zerophase=True)`` (obspy.signal.filter, documented behaviour):
+    ``firstpass = sosfilt(sos, data); return sosfilt(sos, firstpass[::-1])[::-1]`` -- both passes
+    from rest, no padding (NOT scipy.signal.sosfiltfilt)."""
+    x = np.asarray(x, dtype=np.float64)
+    first = scipy.signal.sosfilt(sos, x, axis=-1)
+    return scipy.signal.sosfilt(sos, first[..., ::-1], axis=-1)[..., ::-1]
 
 
 def decimate(x, sampling_rate, factor, no_filter=False):

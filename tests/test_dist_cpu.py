@@ -62,3 +62,45 @@ def test_two_rank_sharding_matches_single_process():
     ref_stack = sum(R.cc_pairs(R.synthetic_traces(S, T, day=d), pairs, n, hop, dtype=np.float64).sum(axis=1)
                     for d in range(3))
     np.testing.assert_allclose(stack, ref_stack, atol=1e-12)
+
+
+def _rdzv_worker(rank, world, key, root, q):
+    from xcorr_amd.rendezvous import FileRendezvous
+    r = FileRendezvous(rank, world, key, root=root, timeout=60)
+    r.barrier()
+    uid = r.broadcast(bytes(range(128)) if rank == 0 else b'')
+    slow = r.max(1.0 + rank)
+    got = r.allgather(bytes([rank]) * 3)
+    r.barrier()
+    q.put((rank, uid, slow, got))
+    r.close()
+
+
+def test_file_rendezvous_three_ranks(tmp_path):
+    """bench.py's start/stop rendezvous (no torch): barrier, max over ranks, broadcast of the
+    128-byte RCCL id, all-gather -- three processes meeting in a directory."""
+    import multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    world = 3
+    procs = [ctx.Process(target=_rdzv_worker, args=(r, world, 'test', str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, uid, slow, got in res:
+        assert uid == bytes(range(128)) and slow == float(world)
+        assert got == [bytes([r]) * 3 for r in range(world)]
+
+
+def test_window_blocks_cover_the_day():
+    """bench.py --shard windows: contiguous window blocks per rank, disjoint, covering all W."""
+    for W_all in (47, 48, 5):
+        for world in (1, 2, 4, 8):
+            blocks = [((W_all * r) // world, (W_all * (r + 1)) // world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == W_all
+            assert all(b[1] == c[0] for b, c in zip(blocks, blocks[1:]))
+            sizes = [b[1] - b[0] for b in blocks]
+            assert max(sizes) - min(sizes) <= 1

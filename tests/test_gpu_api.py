@@ -171,9 +171,14 @@ def test_bench_contract_small(ctx):
     assert d['n_gpus'] == 1 and d['steps'] == 1 and d['vs_baseline'] is None and d['value'] > 0
     assert d['config']['workload'].startswith('6 stations') and 'model' not in d['config']
     r = d['roofline']
-    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'traffic_source', 'frac_end_to_end',
+              'frac_pair_phase', 'frac_of_measured_copy'):
         assert k in r, k
     assert r['bound'] == 'hbm' and r['peak'] == 8000.0 and 0 < r['frac'] < 1
+    # PMC traffic belongs to the profiled workload only: a 6-station run must not inherit it
+    assert r['traffic'] is None and 'workload' in r['traffic_source'] or 'build' in r['traffic_source'] \
+        or 'no profiles' in r['traffic_source']
+    assert len(d['lib_sha256']) == 64
 
 
 def test_prepare_pipelines_the_forward_transforms(ctx):

@@ -1,0 +1,77 @@
+"""GPU, >= 2 devices: the only exchange step of the path -- xcx_comm_init + xcx_stack_reduce
+(RCCL all-reduce / reduce-scatter over xGMI) with one PROCESS per GPU, launched before any GPU
+call in the parent, ids exchanged through the file rendezvous (no torch).  Skipped on a
+one-GPU box (two ranks cannot share a device under RCCL: `ncclCommInitRank ... invalid usage`)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_RANK = r'''
+import os, sys, numpy as np
+sys.path.insert(0, {root!r})
+import xcorr_amd as X
+from xcorr_amd.rendezvous import FileRendezvous
+rank, world, key, rdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+rd = FileRendezvous(rank, world, key, root=rdir, timeout=120)
+ctx = X.Context(rank)
+uid = rd.broadcast(X.Context.comm_unique_id() if rank == 0 else b'')
+ctx.comm_init(uid, world, rank)
+S, n, hop, W = 6, 2000, 1000, 3
+from xcorr_amd.synth import synthetic_traces
+pairs = np.array([(i, j) for i in range(S) for j in range(i + 1, S)], np.int32)
+P = len(pairs) + (-len(pairs)) % world            # rows padded so that the count divides
+plan = X.CCPlan(ctx, n, stack=True)
+L = plan.L
+out = ctx.empty((P, L)).zero()
+days = [d for d in range(5) if d % world == rank]
+for d in days:
+    plan.stack_add(synthetic_traces(S, hop * (W - 1) + n, day=d), pairs, W, hop)
+plan.stack_finish(pairs, out=out)
+part = out.to_host().copy()
+ctx.stack_reduce(out)                             # all-reduce: every rank holds the total
+ctx.sync()
+total = out.to_host().copy()
+out.copy_from(part)
+ctx.stack_reduce(out, reduce_scatter=True)        # each rank keeps its share of the rows
+ctx.sync()
+share = out.to_host().reshape(world, -1)[rank].copy()
+np.save(os.path.join(rdir, f'total_{{rank}}.npy'), total)
+np.save(os.path.join(rdir, f'share_{{rank}}.npy'), share)
+rd.barrier()
+'''
+
+
+def test_two_rank_rccl_stack_reduce(tmp_path):
+    import ctypes as C
+    import subprocess
+    from xcorr_amd import _ffi
+    n = C.c_int(0)
+    _ffi.check(_ffi.lib().xcx_device_count(C.byref(n)))      # counts devices, touches no GPU state
+    if n.value < 2:
+        pytest.skip(f'needs >= 2 GPUs for one RCCL rank per device (found {n.value})')
+    world = 2
+    script = tmp_path / 'rank.py'
+    script.write_text(_RANK.format(root=ROOT))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), 'rccl', str(tmp_path)], env=env)
+             for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    from oracle import ref_numpy as R
+    from xcorr_amd.synth import synthetic_traces
+    S, nn, hop, W = 6, 2000, 1000, 3
+    pairs = R.all_pairs(S)
+    ref = sum(R.cc_pairs(synthetic_traces(S, hop * (W - 1) + nn, day=d), pairs, nn, hop, dtype=np.float64).sum(axis=1)
+              for d in range(5))
+    tot = [np.load(tmp_path / f'total_{r}.npy') for r in range(world)]
+    for t in tot:
+        assert np.abs(t[:len(pairs)] - ref).max() / np.abs(ref).max() < 1e-5
+    assert np.array_equal(tot[0], tot[1])
+    shares = np.concatenate([np.load(tmp_path / f'share_{r}.npy') for r in range(world)])
+    assert np.array_equal(shares.reshape(tot[0].shape), tot[0])

@@ -10,6 +10,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import ref_numpy as R          # noqa: E402  (checker only)
 import xcorr_amd as X                      # noqa: E402
+from xcorr_amd._ffi import XcxError        # noqa: E402
 
 TOL = 1e-5
 
@@ -365,3 +366,77 @@ def test_clipped_plans_use_shorter_transforms(ctx):
     assert np.abs(got1 - full.cc(x, y)[:, n - 1:n + 5000]).max() <= 2e-6 * np.abs(ref).max()
     for p in (full, clip, one_sided):
         p.close()
+
+
+def test_stack_plan_reuse_keeps_descriptors_consistent(ctx):
+    """one stacking plan reused with W=3 (Gram path), W=1 (no Gram),
+    W=3 again, and with xcx_plan_set_batch between calls -- descriptors and the Gram row
+    map must be rebuilt together (stale rows read the wrong cross-spectra / out of bounds)."""
+    from xcorr_amd import _ffi
+    S, n, hop = 7, 2000, 1000
+    tr = R.synthetic_traces(S, hop * 2 + n)
+    pairs = R.all_pairs(S)
+    per = R.cc_pairs(tr, pairs, n, hop, dtype=np.float64)          # [P, 3, L]
+    ref3, ref1 = per.sum(axis=1), per[:, 0]
+    plan = X.CCPlan(ctx, n, stack=True)
+    assert relerr(plan.pairs(tr, pairs, 3, hop), ref3) < TOL
+    assert relerr(plan.pairs(tr, pairs, 1, hop), ref1) < TOL
+    assert relerr(plan.pairs(tr, pairs, 3, hop), ref3) < TOL
+    _ffi.check(_ffi.lib().xcx_plan_set_batch(plan.handle, 5))
+    assert relerr(plan.pairs(tr, pairs, 3, hop), ref3) < TOL
+    sub = pairs[::2]                                               # another pair list on the same plan
+    assert relerr(plan.pairs(tr, sub, 3, hop), ref3[::2]) < TOL
+    assert relerr(plan.pairs(tr, pairs, 3, hop), ref3) < TOL
+    plan.close()
+
+
+def test_stack_add_finish_equals_sum_of_days(ctx):
+    """xcx_cc1d_stack_add / _finish: cross-spectra of several calls ("days", different W)
+    accumulate in the frequency domain; the result is the sum of the per-day stacks."""
+    S, n, hop = 6, 2500, 1250
+    pairs = np.array([(0, 1), (4, 2), (3, 3), (0, 5), (4, 2), (1, 5)], np.int32)   # duplicate + auto pair
+    days = [(R.synthetic_traces(S, hop * (W - 1) + n, day=d), W) for d, W in enumerate((3, 1, 4))]
+    ref = sum(R.cc_pairs(tr, pairs, n, hop, dtype=np.float64).sum(axis=1) for tr, _ in days)
+    plan = X.CCPlan(ctx, n, stack=True)
+    for k, (tr, W) in enumerate(days):
+        plan.stack_add(ctx.array(tr) if k == 1 else tr, pairs, W, hop)    # device and host traces
+    with pytest.raises(XcxError):
+        plan.pairs(days[0][0], pairs, 3, hop)                     # refused while accumulating
+    with pytest.raises(XcxError):
+        plan.stack_add(days[0][0], pairs[:3], 3, hop)             # another pair list
+    got, nw = plan.stack_finish(pairs)
+    assert nw == 8 and relerr(got, ref) < TOL
+    with pytest.raises(XcxError):
+        plan.stack_finish(pairs)                                  # accumulator is empty again
+    # padded device output; the plan is reusable for a plain stacked call afterwards
+    L = 2 * n - 1
+    ld = (L + 31) // 32 * 32
+    out = ctx.empty((len(pairs), ld)).zero()
+    for tr, W in days[:2]:
+        plan.stack_add(tr, pairs, W, hop)
+    plan.stack_finish(pairs, out=out, ld_out=ld)
+    ref2 = sum(R.cc_pairs(tr, pairs, n, hop, dtype=np.float64).sum(axis=1) for tr, _ in days[:2])
+    assert relerr(out.rows_to_host(0, len(pairs), L), ref2) < TOL
+    assert np.all(out.to_host()[:, L:] == 0)
+    st = plan.pairs(days[2][0], pairs, 4, hop)
+    assert relerr(st, R.cc_pairs(days[2][0], pairs, n, hop, dtype=np.float64).sum(axis=1)) < TOL
+    with pytest.raises(XcxError):
+        X.CCPlan(ctx, n).stack_add(days[0][0], pairs, 3, hop)     # not a stacking plan
+    plan.close()
+
+
+def test_output_buffers_are_validated(ctx):
+    """an undersized / wrong-typed `out` is refused before the library writes."""
+    S, n, hop, W = 3, 1000, 500, 2
+    tr = R.synthetic_traces(S, hop * (W - 1) + n)
+    pairs = R.all_pairs(S)
+    plan = X.CCPlan(ctx, n)
+    with pytest.raises(ValueError):
+        plan.pairs(tr, pairs, W, hop, out=np.empty((len(pairs), W, plan.L - 1), np.float32))
+    with pytest.raises(ValueError):
+        plan.pairs(tr, pairs, W, hop, out=np.empty((len(pairs), W, plan.L), np.float64))
+    with pytest.raises(ValueError):
+        plan.pairs(ctx.array(tr), pairs, W, hop, out=ctx.empty((len(pairs) * W - 1, plan.L)))
+    with pytest.raises(ValueError):
+        plan.cc(tr[:1, :n], tr[1:2, :n], out=np.empty((1, plan.L))[:, ::2])
+    plan.close()

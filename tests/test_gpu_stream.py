@@ -113,3 +113,21 @@ def test_device_resident_rows(ctx, raw):
     assert np.array_equal(d.to_host(), raw)            # input untouched
     z = ops.lanczos(ctx, d, 1000, 3.25, 5.0, 20)
     assert relerr(z.to_host(), R.lanczos_interpolation(raw, 3.25, 5.0, 1000, 20)) < TOL
+
+
+def test_filter_zerophase_is_obspys_two_pass_form(ctx, raw):
+    """Trace.filter(zerophase=True) = sosfilt forward from rest, then sosfilt of the
+    reversed signal from rest -- NOT scipy's sosfiltfilt (odd padding + steady-state start)."""
+    x = raw[:, :60001]
+    for kw in (dict(type='bandpass', freqmin=1., freqmax=20.), dict(type='highpass', freq=.5)):
+        sos = stream.butter_sos(kw['type'], 250., 4, **{k: v for k, v in kw.items() if k != 'type'})
+        y = stream.filter(x, 250., zerophase=True, ctx=ctx, **kw)
+        ref = R.sosfilt_zerophase(sos, x)
+        assert relerr(y, ref) < 2 * TOL                 # two float32 passes
+        # and it does differ from sosfiltfilt at the edges
+        assert relerr(R.sosfiltfilt(sos, x.astype(np.float64)), ref) > 1e-3
+    d = ctx.array(x)                                    # device rows, day-long chunked scan path
+    xl = np.ascontiguousarray(np.tile(x[:2], (1, 9))[:, :500001])
+    sos = stream.butter_sos('bandpass', 250., 4, freqmin=1., freqmax=20.)
+    assert relerr(ops.sosfilt_zerophase(ctx, xl, sos), R.sosfilt_zerophase(sos, xl)) < 2 * TOL
+    assert relerr(ops.sosfilt_zerophase(ctx, d, sos).to_host(), R.sosfilt_zerophase(sos, x)) < 2 * TOL

@@ -120,6 +120,11 @@ def test_stream_filter_designs_and_lengths():
         assert s.shape[0] <= 6 and np.allclose(s, R.cheby2_lowpass_sos(0.5 * 250. / factor, 250.))
         w, h = scipy.signal.sosfreqz(s, worN=4096, fs=250.)
         assert np.all(20 * np.log10(np.abs(h[w >= 0.5 * 250. / factor]) + 1e-300) <= -95.9)   # 96 dB stop band
+        # independent of the (duplicated) design routine: a low-pass of order <= 12 that is flat to
+        # 1 dB over the lower 60 % of the new band and monotone into the stop band
+        db = 20 * np.log10(np.abs(h) + 1e-300)
+        assert np.all(np.abs(db[w <= 0.3 * 250. / factor]) < 1.0) and abs(db[0]) < 1e-6
+        assert 2 * s.shape[0] <= 12
     assert stream.cosine_taper_length(4320000, 50., 0.05, 30.) == 1500
     assert stream.cosine_taper_length(1000, 50., 0.05, 30.) == 50
     assert stream.cosine_taper_length(10, 50., None, None) == 5
@@ -143,3 +148,23 @@ def test_fft_axes_and_spectrogram_design():
         spectral._design(50., 0.2, 2, None, 'hann')
     with pytest.raises(ValueError):
         spectral._design(50., 2.5, 2, 'power', 'hann')
+
+
+def test_output_buffer_validation_is_host_side():
+    """`out` capacity / dtype / contiguity are checked before any library call."""
+    from xcorr_amd.engine import _check_out
+    L, ld = 1999, 2016
+    _check_out(np.empty((5, ld), np.float32), 5, ld, L)
+    _check_out(np.empty(4 * ld + L, np.float32), 5, ld, L)          # the last row needs only L
+    with pytest.raises(ValueError, match='holds'):
+        _check_out(np.empty(4 * ld + L - 1, np.float32), 5, ld, L)
+    with pytest.raises(ValueError, match='ld_out'):
+        _check_out(np.empty((5, L), np.float32), 5, L - 1, L)
+    with pytest.raises(ValueError, match='float32'):
+        _check_out(np.empty((5, ld), np.float64), 5, ld, L)
+    with pytest.raises(ValueError, match='contiguous'):
+        _check_out(np.empty((5, 2 * ld), np.float32)[:, ::2], 5, ld, L)
+    ro = np.empty((5, ld), np.float32)
+    ro.flags.writeable = False
+    with pytest.raises(ValueError, match='read-only'):
+        _check_out(ro, 5, ld, L)

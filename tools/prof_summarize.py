@@ -52,11 +52,57 @@ for k in set(fetch) | set(write):
               'hbm_bytes_per_launch': fb + wb,
               'fetch_kib_raw_avg': fetch.get(k, {}).get('avg'), 'write_kib_raw_avg': write.get(k, {}).get('avg')}
 summ['pmc'] = hbm
+
+# ---- overlap evidence: union busy time of the dominant kernel's dispatches ------------------
+# (two k_wpair_dual pipelines run concurrently; per-launch durations do not add up to wall time)
+def overlap(kernel_substr='k_wpair_dual'):
+    iv = []
+    for f in glob.glob(os.path.join(out, 'kt', '**', '*kernel_trace.csv'), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kernel_substr in r.get('Kernel_Name', ''):
+                iv.append((int(r['Start_Timestamp']), int(r['End_Timestamp'])))
+    if not iv:
+        return None
+    iv.sort()
+    union = 0
+    cs, ce = iv[0]
+    for a, b in iv[1:]:
+        if a > ce:
+            union += ce - cs
+            cs, ce = a, b
+        else:
+            ce = max(ce, b)
+    union += ce - cs
+    total = sum(b - a for a, b in iv)
+    return {'kernel': kernel_substr, 'dispatches': len(iv), 'sum_of_durations_us': total / 1e3,
+            'union_busy_us': union / 1e3, 'avg_duration_us': total / 1e3 / len(iv),
+            'effective_us_per_dispatch': union / 1e3 / len(iv),
+            'mean_dispatches_in_flight': total / union if union else None,
+            'first_start_to_last_end_us': (max(b for _, b in iv) - iv[0][0]) / 1e3}
+
+ov = overlap()
+if ov:
+    summ['overlap'] = ov
+
+# ---- stamp: which library build and workload these counters belong to ---------------------
+stamp = {'tag': os.path.basename(out.rstrip('/')).replace('prof_', '')}
+try:
+    for ln in open(os.path.join(out, 'bench_kt.log')):
+        if ln.startswith('{'):
+            d = json.loads(ln)
+            stamp.update({'lib_sha256': d.get('lib_sha256'), 'workload': d['config']['workload'],
+                          'pair_batch': d['config'].get('pair_batch'), 'value_during_kernel_trace': d.get('value')})
+except OSError:
+    pass
+summ['stamp'] = stamp
 json.dump(summ, open(os.path.join(out, 'summary.json'), 'w'), indent=1)
 # bench.py reads this (kernel ids as reported by xcx_plan_profile_read)
 alias = {'k_wpair_rows': 'k_pair_rows', 'k_wpair_cols': 'k_pair_cols', 'k_wpair_fused': 'k_pair_dual', 'k_wpair_dual': 'k_pair_dual',
          'k_wfwd_rows': 'k_fwd_rows', 'k_wfwd_cols': 'k_fwd_cols'}
 latest = {alias.get(k, k): v for k, v in hbm.items()}
+latest['_stamp'] = stamp
+if ov:
+    latest['_overlap'] = ov
 json.dump(latest, open(os.path.join(out, 'pmc_latest.json'), 'w'), indent=1)
 with open(os.path.join(out, 'summary.txt'), 'w') as fh:
     fh.write('kernel                 calls   avg_us     pct   fetch_MB(x2)  write_MB  (per launch)\n')
@@ -64,4 +110,9 @@ with open(os.path.join(out, 'summary.txt'), 'w') as fh:
         h = hbm.get(k, {})
         fh.write(f"{k:22s} {v['calls']:6d} {v['avg_ns']/1e3:8.1f} {v['pct']:7.2f} "
                  f"{h.get('fetch_bytes_per_launch_corrected_x2', 0)/1e6:12.2f} {h.get('write_bytes_per_launch', 0)/1e6:9.2f}\n")
+    if ov:
+        fh.write(f"\n{ov['kernel']}: {ov['dispatches']} dispatches, sum of durations {ov['sum_of_durations_us']:.0f} us, "
+                 f"union busy {ov['union_busy_us']:.0f} us -> {ov['mean_dispatches_in_flight']:.2f} in flight on average, "
+                 f"{ov['effective_us_per_dispatch']:.1f} us per dispatch effective (avg duration {ov['avg_duration_us']:.1f} us)\n")
+    fh.write(f"stamp: {json.dumps(stamp)}\n")
 print(open(os.path.join(out, 'summary.txt')).read())

@@ -70,6 +70,7 @@ SIGNATURES = {
     'xcx_onebit': [_vp, _vp, _l, _l, _i],
     'xcx_sosfiltfilt': [_vp, _vp, _l, _l, _vp, _i, _i],
     'xcx_sosfilt': [_vp, _vp, _l, _l, _vp, _i, _i],
+    'xcx_sosfilt_zerophase': [_vp, _vp, _l, _l, _vp, _i, _i],
     'xcx_snr': [_vp, _vp, _l, _l, _vp, _vp, _vp, _vp, _vp, _i],
     'xcx_timeshift': [_vp, _vp, _vp, _l, _l, _vp, C.c_double, _i],
     'xcx_cc2d': [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i],
@@ -83,6 +84,8 @@ SIGNATURES = {
     'xcx_block_rms': [_vp, _vp, _vp, _l, _l, _l, _l, _l, _i],
     'xcx_spectrogram': [_vp, _vp, _vp, _l, _l, _i, _i, _vp, C.c_double, _i, _i],
     'xcx_ram_normalize': [_vp, _vp, _l, _l, _l, _i],
+    'xcx_cc1d_stack_add': [_vp, _vp, _i, _i, _l, _l, _vp, _i, _i],
+    'xcx_cc1d_stack_finish': [_vp, _vp, _i, _vp, _l, _i, _vp],
     'xcx_cc1d_prepare': [_vp, _vp, _i, _i, _l, _l],
     'xcx_cc1d_prepare_sync': [_vp],
     'xcx_comm_unique_id': [C.c_char_p],

@@ -50,10 +50,10 @@ extern "C" int xcx_comm_destroy(xcx_ctx* ctx) {
 
 extern "C" int xcx_stack_reduce(xcx_ctx* ctx, float* stack, size_t count, int reduce_scatter) {
   if (!ctx || !stack) return set_err(XCX_EINVAL, "null argument");
-  if (!ctx->comm) {
-    if (ctx->nranks == 1) return XCX_OK;   // single rank: nothing to exchange
-    return set_err(XCX_EINVAL, "xcx_comm_init() not called");
-  }
+  // No communicator is an error even for one rank: a multi-rank job whose xcx_comm_init failed
+  // or was forgotten would otherwise get its partial stack back as if it were the total.
+  // (A single-rank world calls xcx_comm_init(ctx, id, 1, 0) like any other.)
+  if (!ctx->comm) return set_err(XCX_EINVAL, "xcx_stack_reduce: xcx_comm_init() not called on this context");
   ncclComm_t comm = (ncclComm_t)ctx->comm;
   if (reduce_scatter) {
     if (count % ctx->nranks) return set_err(XCX_EINVAL, "count not divisible by nranks");

@@ -46,7 +46,10 @@ __global__ __launch_bounds__(kWNT * kWPB) void k_gram(GramArgs a) {
       const int si = t0.x + i, sj = t0.y + j;
       if (si < S && sj < S) {
         const int p = a.pidx[si * S + sj];
-        if (p >= 0) a.C[(size_t)p * a.c_pitch + k] = acc[i][j];
+        if (p >= 0) {
+          cf* dst = a.C + (size_t)p * a.c_pitch + k;
+          *dst = a.accumulate ? cadd(*dst, acc[i][j]) : acc[i][j];
+        }
       }
     }
 }
@@ -147,11 +150,17 @@ __global__ __launch_bounds__(256, 3) void k_gram_mfma(GramArgs a) {
       cf* dst = a.C + (size_t)p * a.c_pitch + f0;
       const cf* src_e = lo + (tid + 256 * q) * 4;
       if (f0 + 3 < a.nfreq) {
-        const float4 lo4 = reinterpret_cast<const float4*>(src_e)[0], hi4 = reinterpret_cast<const float4*>(src_e)[1];
+        float4 lo4 = reinterpret_cast<const float4*>(src_e)[0], hi4 = reinterpret_cast<const float4*>(src_e)[1];
+        if (a.accumulate) {
+          const float4 o0 = reinterpret_cast<const float4*>(dst)[0], o1 = reinterpret_cast<const float4*>(dst)[1];
+          lo4 = make_float4(lo4.x + o0.x, lo4.y + o0.y, lo4.z + o0.z, lo4.w + o0.w);
+          hi4 = make_float4(hi4.x + o1.x, hi4.y + o1.y, hi4.z + o1.z, hi4.w + o1.w);
+        }
         reinterpret_cast<float4*>(dst)[0] = lo4;
         reinterpret_cast<float4*>(dst)[1] = hi4;
       } else {
-        for (int k = 0; k < 4; ++k) if (f0 + k < a.nfreq) dst[k] = src_e[k];
+        for (int k = 0; k < 4; ++k)
+          if (f0 + k < a.nfreq) dst[k] = a.accumulate ? cadd(dst[k], src_e[k]) : src_e[k];
       }
     }
   };

@@ -453,8 +453,11 @@ int run_pass(xcx_ctx* ctx, float* x, long rows, long n, const SosParams& P,
   return XCX_OK;
 }
 
+enum { kModeForward = 0, kModeFiltFilt = 1, kModeZeroPhase = 2 };
+
 template <int K>
-int filt_impl(xcx_ctx* ctx, float* dx, long rows, long n, const SosParams& P, bool filtfilt) {
+int filt_impl(xcx_ctx* ctx, float* dx, long rows, long n, const SosParams& P, int mode) {
+  const bool filtfilt = mode == kModeFiltFilt;
   // grow-only per-context workspaces (no allocation in the steady state)
   DevBuf &zbuf = ctx->scratch[1], &mbuf = ctx->scratch[2], &zi_d = ctx->scratch[3],
          &tail = ctx->scratch[4], &init = ctx->scratch[5], &fend = ctx->scratch[6];
@@ -462,6 +465,10 @@ int filt_impl(xcx_ctx* ctx, float* dx, long rows, long n, const SosParams& P, bo
   auto cleanup = [&]() {};
   if (!filtfilt) {
     rc = run_pass<K, false>(ctx, dx, rows, n, P, nullptr, nullptr, zbuf, mbuf);
+    // ObsPy zerophase=True: the same filter once more over the reversed signal, again from rest
+    // (no padding, no steady-state start values -- unlike scipy.signal.sosfiltfilt)
+    if (rc == XCX_OK && mode == kModeZeroPhase)
+      rc = run_pass<K, true>(ctx, dx, rows, n, P, nullptr, nullptr, zbuf, mbuf);
     cleanup();
     return rc;
   }
@@ -498,7 +505,7 @@ int filt_impl(xcx_ctx* ctx, float* dx, long rows, long n, const SosParams& P, bo
 }
 
 int filt_entry(xcx_ctx* ctx, float* x, long batch, long n, const double* sos, int K, int on_device,
-               bool filtfilt) {
+               int filtfilt) {
   if (!ctx || !x) return set_err(XCX_EINVAL, "null argument");
   if (batch < 1 || n < 1) return set_err(XCX_EINVAL, "batch and n must be >= 1");
   SosParams P;
@@ -535,10 +542,15 @@ int filt_entry(xcx_ctx* ctx, float* x, long batch, long n, const double* sos, in
 
 extern "C" int xcx_sosfiltfilt(xcx_ctx* ctx, float* x, long batch, long n, const double* sos,
                                int n_sections, int on_device) {
-  return filt_entry(ctx, x, batch, n, sos, n_sections, on_device, true);
+  return filt_entry(ctx, x, batch, n, sos, n_sections, on_device, kModeFiltFilt);
+}
+
+extern "C" int xcx_sosfilt_zerophase(xcx_ctx* ctx, float* x, long batch, long n, const double* sos,
+                                     int n_sections, int on_device) {
+  return filt_entry(ctx, x, batch, n, sos, n_sections, on_device, kModeZeroPhase);
 }
 
 extern "C" int xcx_sosfilt(xcx_ctx* ctx, float* x, long batch, long n, const double* sos,
                            int n_sections, int on_device) {
-  return filt_entry(ctx, x, batch, n, sos, n_sections, on_device, false);
+  return filt_entry(ctx, x, batch, n, sos, n_sections, on_device, kModeForward);
 }

@@ -766,6 +766,7 @@ struct GramArgs {
   const int2* tiles; int ntiles;    // (first station of the i block, of the j block)
   const int* pidx;                  // [S*S] -> row of C, or -1
   cf* C; size_t c_pitch;            // C[p*c_pitch + k]
+  int accumulate;                   // 0: C = G;  1: C += G (multi-day stack, xcx_cc1d_stack_add)
 };
 
 hipError_t launch_gram(const GramArgs& a, hipStream_t s);

@@ -336,6 +336,8 @@ struct xcx_plan {
   const float* prep_traces = nullptr; int prep_S = 0, prep_W = 0; long prep_ss = 0, prep_sw = 0;
   size_t fused_err_off = 0;  // index of the error flag inside fsync
   unsigned long long gram_key = 0; int gram_ntiles = 0;
+  // multi-call accumulation in gramC (xcx_cc1d_stack_add / _finish)
+  unsigned long long acc_key = 0; int acc_count = 0, acc_S = 0, acc_P = 0; long long acc_windows = 0; long acc_ld = 0;
   bool fused_ran = false;
   DevBuf psum, psq;          // partial statistics of a forward chunk
   int L = 0;                 // retained lags
@@ -925,6 +927,171 @@ static unsigned long long fnv(const void* data, size_t bytes, unsigned long long
   return h;
 }
 
+
+// ---------------------------------------------------------------------------
+// Time-stack through the cross-spectrum ("Gram") buffer:
+//   stack_tables : pair list -> row of gramC per pair, 8x8 station tiles, inverse descriptors
+//   stack_gram   : gramC (+)= sum_w X_{i,w} conj X_{j,w} for the spectra currently in p->spectra
+//   stack_inverse: one inverse transform per pair, gramC -> out
+// xcx_cc1d_pairs(XCX_STACK) = tables + forward + gram + inverse of ONE call;
+// xcx_cc1d_stack_add / _finish split it so that several calls (days) accumulate in the
+// frequency domain and pay for the P inverse transforms once.
+// ---------------------------------------------------------------------------
+static int stack_tables(xcx_plan* p, const int* pairs, int S, int P, long ld_out) {
+  xcx_ctx* ctx = p->ctx;
+  int rc;
+  unsigned long long key = fnv(pairs, sizeof(int) * 2 * (size_t)P, 1469598103934665603ULL);
+  long hdr[3] = {S, P, ld_out};
+  key = fnv(hdr, sizeof hdr, key) | 1ULL;
+  if (key == p->gram_key && key == p->desc_key && p->hdescs.size() == (size_t)P) return XCX_OK;
+  std::vector<int> perm(P);
+  for (int i = 0; i < P; ++i) perm[i] = i;
+  std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
+    int ta = (pairs[2 * a] >> 3) * 8192 + (pairs[2 * a + 1] >> 3);
+    int tb = (pairs[2 * b] >> 3) * 8192 + (pairs[2 * b + 1] >> 3);
+    return ta < tb;
+  });
+  const int nb = (S + kGT - 1) / kGT;
+  std::vector<int> pidx((size_t)S * S, -1);
+  std::vector<char> used((size_t)nb * nb, 0);
+  p->hdescs.resize(P);
+  for (int q = 0; q < P; ++q) {
+    // processing order q; duplicate pairs share the row of their first occurrence
+    const int pi = perm[q];
+    const int i = pairs[2 * pi], j = pairs[2 * pi + 1];
+    if (pidx[(size_t)i * S + j] < 0) pidx[(size_t)i * S + j] = q;
+    used[(size_t)(i / kGT) * nb + j / kGT] = 1;
+    const int row = pidx[(size_t)i * S + j];
+    p->hdescs[q] = PwDesc{row, row, (long long)pi * ld_out};
+  }
+  std::vector<int2> tiles;
+  for (int bi = 0; bi < nb; ++bi)
+    for (int bj = 0; bj < nb; ++bj)
+      if (used[(size_t)bi * nb + bj]) tiles.push_back(make_int2(bi * kGT, bj * kGT));
+  p->desc_key = 0; p->gram_key = 0;
+  if ((rc = upload(ctx, p->gramPidx, pidx.data(), pidx.size() * sizeof(int)))) return rc;
+  if ((rc = upload(ctx, p->gramTiles, tiles.data(), tiles.size() * sizeof(int2)))) return rc;
+  if ((rc = upload(ctx, p->descs, p->hdescs.data(), (size_t)P * sizeof(PwDesc)))) return rc;
+  p->gram_ntiles = (int)tiles.size();
+  p->gram_key = key;
+  p->desc_key = key;
+  return XCX_OK;
+}
+
+static int stack_gram(xcx_plan* p, int S, int W, int P, int accumulate) {
+  xcx_ctx* ctx = p->ctx;
+  const Geom& g = p->g;
+  int rc;
+  if ((rc = p->gramC.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)P))) return rc;
+  GramArgs ga{};
+  ga.X = (const cf*)p->spectra.ptr;
+  ga.spec_pitch = p->spec_pitch;
+  ga.S = S; ga.W = W;
+  ga.nfreq = g.N1 * (g.N2h + 1);
+  ga.tiles = (const int2*)p->gramTiles.ptr;
+  ga.ntiles = p->gram_ntiles;
+  ga.pidx = (const int*)p->gramPidx.ptr;
+  ga.C = (cf*)p->gramC.ptr;
+  ga.c_pitch = p->spec_pitch;
+  ga.accumulate = accumulate;
+  {
+    ProfScope ps(p, KID_GRAM, P);
+    HIP_TRY(launch_gram(ga, ctx->stream));
+  }
+  p->launches += 1;
+  return XCX_OK;
+}
+
+static int stack_inverse(xcx_plan* p, int P, float* dout) {
+  xcx_ctx* ctx = p->ctx;
+  const Geom& g = p->g;
+  int rc;
+  const int B = p->batch;
+  const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
+  if ((rc = p->T.ensure(ctx, sizeof(cf) * tm_per * B * 2 * (p->dual ? p->nchains : 1)))) return rc;
+  const cf* src = (const cf*)p->gramC.ptr;
+  if (p->dual) return dual_run(p, 0, (size_t)P, -1, dout, src);
+  for (size_t d0 = 0; d0 < (size_t)P; d0 += B)
+    if ((rc = pair_batch(p, d0, (int)std::min((size_t)B, P - d0), dout, -1, src))) return rc;
+  return XCX_OK;
+}
+
+static int check_pairs(const int* pairs, int S, int P) {
+  for (int i = 0; i < P; ++i)
+    if (pairs[2 * i] < 0 || pairs[2 * i] >= S || pairs[2 * i + 1] < 0 || pairs[2 * i + 1] >= S)
+      return set_err(XCX_EINVAL, "pair %d = (%d,%d) outside [0,%d)", i, pairs[2 * i], pairs[2 * i + 1], S);
+  return XCX_OK;
+}
+
+extern "C" int xcx_cc1d_stack_add(xcx_plan* p, const float* traces, int S, int W, long stride_s,
+                                  long stride_w, const int* pairs, int P, int on_device) {
+  if (!p || !traces || !pairs) return set_err(XCX_EINVAL, "null argument");
+  if (S < 1 || W < 1 || P < 1) return set_err(XCX_EINVAL, "S, W, P must be >= 1");
+  if (stride_s < 0 || stride_w < 0) return set_err(XCX_EINVAL, "negative stride");
+  xcx_ctx* ctx = p->ctx;
+  const Geom& g = p->g;
+  if (!(g.flags & XCX_F_STACK)) return set_err(XCX_EINVAL, "xcx_cc1d_stack_add needs an XCX_STACK plan");
+  if (!p->wave) return set_err(XCX_EUNSUPPORTED, "xcx_cc1d_stack_add needs the wave engine");
+  if ((long long)S * W > 0x7fffffffLL / 2) return set_err(XCX_EINVAL, "S*W too large");
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc;
+  if ((rc = check_pairs(pairs, S, P))) return rc;
+  unsigned long long akey = fnv(pairs, sizeof(int) * 2 * (size_t)P, 1469598103934665603ULL);
+  akey = fnv(&S, sizeof S, akey) | 1ULL;
+  if (p->acc_count > 0 && akey != p->acc_key)
+    return set_err(XCX_EINVAL, "xcx_cc1d_stack_add: pair list / station count differ from the accumulation in progress");
+  const float* dtr = traces;
+  if (!on_device) {
+    const size_t span = (size_t)(S - 1) * stride_s + (size_t)(W - 1) * stride_w + g.n;
+    if ((rc = p->dtraces.ensure(ctx, span * sizeof(float)))) return rc;
+    HIP_TRY(hipMemcpyAsync(p->dtraces.ptr, traces, span * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    dtr = (const float*)p->dtraces.ptr;
+  }
+  // tables keyed without ld_out: the finish call supplies it (descriptors are rebuilt there if it differs)
+  if ((rc = stack_tables(p, pairs, S, P, p->acc_ld))) return rc;
+  if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)S * W))) return rc;
+  if ((rc = forward(p, dtr, stride_s, stride_w, W, 0, 0, S * W, 0))) return rc;
+  if ((rc = stack_gram(p, S, W, P, p->acc_count > 0 ? 1 : 0))) return rc;
+  if (!on_device) HIP_TRY(hipStreamSynchronize(ctx->stream));     // the staging buffer may be reused
+  p->acc_key = akey; p->acc_S = S; p->acc_P = P;
+  p->acc_count += 1; p->acc_windows += W;
+  return XCX_OK;
+}
+
+extern "C" int xcx_cc1d_stack_finish(xcx_plan* p, const int* pairs, int P, float* out, long ld_out,
+                                     int on_device, long long* windows) {
+  if (!p || !pairs || !out) return set_err(XCX_EINVAL, "null argument");
+  if (p->acc_count < 1) return set_err(XCX_EINVAL, "xcx_cc1d_stack_finish: nothing accumulated");
+  xcx_ctx* ctx = p->ctx;
+  HIP_TRY(hipSetDevice(ctx->device));
+  const long L = p->L;
+  if (ld_out == 0) ld_out = L;
+  if (ld_out < L) return set_err(XCX_EINVAL, "ld_out (%ld) < L (%ld)", ld_out, L);
+  int rc;
+  const int S = p->acc_S;
+  if (P != p->acc_P) return set_err(XCX_EINVAL, "xcx_cc1d_stack_finish: P differs from the accumulated pair list");
+  if ((rc = check_pairs(pairs, S, P))) return rc;
+  unsigned long long akey = fnv(pairs, sizeof(int) * 2 * (size_t)P, 1469598103934665603ULL);
+  akey = fnv(&S, sizeof S, akey) | 1ULL;
+  if (akey != p->acc_key) return set_err(XCX_EINVAL, "xcx_cc1d_stack_finish: pair list differs from the accumulated one");
+  p->acc_ld = ld_out;
+  if ((rc = stack_tables(p, pairs, S, P, ld_out))) return rc;     // same rows of gramC, out offsets for this pitch
+  float* dout = out;
+  if (!on_device) {
+    if ((rc = p->dout.ensure(ctx, (size_t)P * (size_t)ld_out * sizeof(float)))) return rc;
+    dout = (float*)p->dout.ptr;
+  }
+  if ((rc = stack_inverse(p, P, dout))) return rc;
+  if (windows) *windows = p->acc_windows;
+  p->acc_count = 0; p->acc_windows = 0;
+  if (!on_device) {
+    HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld_out * sizeof(float), dout, (size_t)ld_out * sizeof(float),
+                             (size_t)L * sizeof(float), (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  return XCX_OK;
+}
+
 extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
                               long stride_s, long stride_w, const int* pairs,
                               int P, float* out, long ld_out, int on_device) {
@@ -938,11 +1105,9 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
   if (ld_out == 0) ld_out = L;
   if (ld_out < L) return set_err(XCX_EINVAL, "ld_out (%ld) < L (%ld)", ld_out, L);
   if (stride_s < 0 || stride_w < 0) return set_err(XCX_EINVAL, "negative stride");
-  for (int i = 0; i < P; ++i)
-    if (pairs[2 * i] < 0 || pairs[2 * i] >= S || pairs[2 * i + 1] < 0 || pairs[2 * i + 1] >= S)
-      return set_err(XCX_EINVAL, "pair %d = (%d,%d) outside [0,%d)", i, pairs[2 * i], pairs[2 * i + 1], S);
-  if ((long long)S * W > 0x7fffffffLL / 2) return set_err(XCX_EINVAL, "S*W too large");
   int rc;
+  if ((rc = check_pairs(pairs, S, P))) return rc;
+  if ((long long)S * W > 0x7fffffffLL / 2) return set_err(XCX_EINVAL, "S*W too large");
   const float* dtr = traces;
   float* dout = out;
   const size_t nrows = stack ? (size_t)P : (size_t)P * W;
@@ -961,9 +1126,10 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
   const bool allw = !stack && W > 1 && sizeof(cf) * p->spec_pitch * (size_t)S * W <= ((size_t)24 << 30);
   int hdr[5] = {S, W, P, (int)stack, (int)allw};
   key = fnv(hdr, sizeof hdr, key);
-  key = fnv(&ld_out, sizeof ld_out, key);
+  key = fnv(&ld_out, sizeof ld_out, key) & ~1ULL;      // even: never equal to a stack_tables() key (odd)
   const size_t ndesc = stack ? (size_t)P : (size_t)P * W;
-  if (key != p->desc_key || p->hdescs.size() != ndesc) {
+  const bool via_gram = stack && p->wave && p->gram && W > 1;     // descriptors come from stack_tables()
+  if (!via_gram && (key != p->desc_key || p->hdescs.size() != ndesc)) {
     std::vector<int> perm(P);
     for (int i = 0; i < P; ++i) perm[i] = i;
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
@@ -988,6 +1154,9 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
     }
     if ((rc = upload(ctx, p->descs, p->hdescs.data(), ndesc * sizeof(PwDesc)))) return rc;
     p->desc_key = key;
+    // the Gram path rewrites slot_a/slot_b of these descriptors (rows of gramC): a rebuilt
+    // descriptor array must be remapped again even if the Gram tables themselves are current
+    p->gram_key = 0;
   }
   const int B = p->batch;
   const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
@@ -1006,50 +1175,10 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
     int ns = W;
     if (p->wave && p->gram && W > 1) {
       // cgemm-style stack: G_k = A_k A_k^H per frequency, then one inverse per pair
-      if (key != p->gram_key) {
-        std::vector<int> pidx((size_t)S * S, -1);
-        std::vector<char> used((size_t)((S + kGT - 1) / kGT) * ((S + kGT - 1) / kGT), 0);
-        const int nb = (S + kGT - 1) / kGT;
-        for (size_t q = 0; q < (size_t)P; ++q) {
-          // hdescs are in processing order: row q of C belongs to descriptor q
-          const int pi = (int)(p->hdescs[q].out_off / ld_out);
-          const int i = pairs[2 * pi], j = pairs[2 * pi + 1];
-          if (pidx[(size_t)i * S + j] < 0) pidx[(size_t)i * S + j] = (int)q;
-          used[(size_t)(i / kGT) * nb + j / kGT] = 1;
-        }
-        std::vector<int2> tiles;
-        for (int bi = 0; bi < nb; ++bi)
-          for (int bj = 0; bj < nb; ++bj)
-            if (used[(size_t)bi * nb + bj]) tiles.push_back(make_int2(bi * kGT, bj * kGT));
-        if ((rc = upload(ctx, p->gramPidx, pidx.data(), pidx.size() * sizeof(int)))) return rc;
-        if ((rc = upload(ctx, p->gramTiles, tiles.data(), tiles.size() * sizeof(int2)))) return rc;
-        p->gram_ntiles = (int)tiles.size();
-        p->gram_key = key;
-        // duplicate pairs share a row of C: point their descriptors at it
-        for (size_t q = 0; q < (size_t)P; ++q) {
-          const int pi = (int)(p->hdescs[q].out_off / ld_out);
-          const int row = pidx[(size_t)pairs[2 * pi] * S + pairs[2 * pi + 1]];
-          p->hdescs[q].slot_a = row;
-          p->hdescs[q].slot_b = row;
-        }
-        if ((rc = upload(ctx, p->descs, p->hdescs.data(), ndesc * sizeof(PwDesc)))) return rc;
-      }
-      if ((rc = p->gramC.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)P))) return rc;
-      GramArgs ga{};
-      ga.X = (const cf*)p->spectra.ptr;
-      ga.spec_pitch = p->spec_pitch;
-      ga.S = S; ga.W = W;
-      ga.nfreq = g.N1 * (g.N2h + 1);
-      ga.tiles = (const int2*)p->gramTiles.ptr;
-      ga.ntiles = p->gram_ntiles;
-      ga.pidx = (const int*)p->gramPidx.ptr;
-      ga.C = (cf*)p->gramC.ptr;
-      ga.c_pitch = p->spec_pitch;
-      {
-        ProfScope ps(p, KID_GRAM, P);
-        HIP_TRY(launch_gram(ga, ctx->stream));
-      }
-      p->launches += 1;
+      if (p->acc_count > 0)
+        return set_err(XCX_EINVAL, "xcx_cc1d_pairs: a xcx_cc1d_stack_add accumulation is in progress on this plan");
+      if ((rc = stack_tables(p, pairs, S, P, ld_out))) return rc;
+      if ((rc = stack_gram(p, S, W, P, 0))) return rc;
       src = (const cf*)p->gramC.ptr;
       ns = -1;
     }

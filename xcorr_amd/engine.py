@@ -150,6 +150,28 @@ class Context:
                                           int(bool(reduce_scatter))))
 
 
+def _check_out(out, nrows, ld, L):
+    """Refuse an output buffer the library would overrun: it writes `nrows` rows of L float32
+    at a pitch of `ld` floats (the last row needs only L)."""
+    if ld < L:
+        raise ValueError(f'ld_out ({ld}) < L ({L})')
+    need = 4 * ((nrows - 1) * ld + L)
+    if isinstance(out, DeviceArray):
+        if out.dtype != np.float32:
+            raise ValueError('`out` must be float32')
+        own = getattr(out, '_owner', None)       # a column view: what is left of the owner's allocation
+        have = out.nbytes if own is None else own.nbytes - (out.ptr - own.ptr)
+    else:
+        if not isinstance(out, np.ndarray) or out.dtype != np.float32 or not out.flags['C_CONTIGUOUS']:
+            raise ValueError('`out` must be a C-contiguous float32 numpy array or a DeviceArray')
+        if not out.flags['WRITEABLE']:
+            raise ValueError('`out` is read-only')
+        have = out.nbytes
+    if have < need:
+        raise ValueError(f'`out` holds {have} bytes, the call writes {need} '
+                         f'({nrows} rows x {L} lags at a pitch of {ld} floats)')
+
+
 _default = {}
 
 
@@ -264,6 +286,7 @@ class CCPlan:
         if (W - 1) * stride_w + self.n > T:
             raise ValueError('windows exceed the trace length')
         on_dev = isinstance(traces, DeviceArray)
+        nrows = P if self.stack else P * W
         if on_dev:
             if not isinstance(out, DeviceArray):
                 raise ValueError('device traces need a DeviceArray `out`')
@@ -272,10 +295,38 @@ class CCPlan:
             if out is None:
                 shape = (P, self.L) if self.stack else (P, W, self.L)
                 out = np.empty(shape, dtype=np.float32)
+        _check_out(out, nrows, int(ld_out) or self.L, self.L)
         check(_ffi.lib().xcx_cc1d_pairs(
             self.handle, ptr(traces), S, W, stride_s, stride_w, ptr(pairs), P,
             ptr(out), int(ld_out), int(on_dev)))
         return out
+
+    def stack_add(self, traces, pairs, W, stride_w, stride_s=None):
+        """Accumulate the cross-spectra of W windows of every pair (xcx_cc1d_stack_add): one
+        call per station-day of a multi-day stack; finish with :meth:`stack_finish`."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        S, T = traces.shape
+        stride_s = T if stride_s is None else stride_s
+        if (W - 1) * stride_w + self.n > T:
+            raise ValueError('windows exceed the trace length')
+        on_dev = isinstance(traces, DeviceArray)
+        if not on_dev:
+            traces = np.ascontiguousarray(traces, dtype=np.float32)
+        check(_ffi.lib().xcx_cc1d_stack_add(self.handle, ptr(traces), S, int(W), int(stride_s),
+                                            int(stride_w), ptr(pairs), len(pairs), int(on_dev)))
+
+    def stack_finish(self, pairs, out=None, ld_out=0):
+        """Inverse-transform the accumulated cross-spectra -> (out [P, L], windows summed)."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        P = len(pairs)
+        if out is None:
+            out = np.empty((P, self.L), dtype=np.float32)
+        on_dev = isinstance(out, DeviceArray)
+        _check_out(out, P, int(ld_out) or self.L, self.L)
+        nw = C.c_longlong(0)
+        check(_ffi.lib().xcx_cc1d_stack_finish(self.handle, ptr(pairs), P, ptr(out), int(ld_out),
+                                               int(on_dev), C.byref(nw)))
+        return out, nw.value
 
     def cc(self, x, y, out=None):
         """Batched two-input form: x, y [batch, n] -> [batch, L]."""
@@ -291,6 +342,7 @@ class CCPlan:
                 out = self.ctx.empty((batch, self.L))
             else:
                 out = np.empty(x.shape[:-1] + (self.L,), dtype=np.float32)
+        _check_out(out, batch, self.L, self.L)
         check(_ffi.lib().xcx_cc1d(self.handle, ptr(x), ptr(y), batch, ptr(out),
                                   int(on_dev)))
         return out

@@ -14,7 +14,7 @@ from ._ffi import check, ptr
 from .engine import DeviceArray, default_context
 
 __all__ = ['copy', 'norm1d', 'demean', 'detrend_linear', 'taper', 'unbias',
-           'onebit', 'sosfiltfilt', 'sosfilt', 'timeshift', 'snr', 'correlate2d',
+           'onebit', 'sosfiltfilt', 'sosfilt', 'sosfilt_zerophase', 'timeshift', 'snr', 'correlate2d',
            'fft', 'ifft', 'rfft', 'irfft', 'hilbert', 'decimate', 'lanczos', 'block_rms', 'spectrogram', 'ram_normalize']
 
 
@@ -120,6 +120,17 @@ def sosfilt(ctx, x, sos):
     buf, b, n, dev, _ = _prep(x)
     check(_ffi.lib().xcx_sosfilt(ctx.handle, ptr(buf), b, n, ptr(sos),
                                  sos.shape[0], dev))
+    return buf
+
+
+def sosfilt_zerophase(ctx, x, sos):
+    """ObsPy ``zerophase=True``: sosfilt from rest, then sosfilt of the reversed
+    signal from rest (no padding; not scipy's sosfiltfilt)."""
+    ctx = _ctx(ctx, x)
+    sos = _sos(sos)
+    buf, b, n, dev, _ = _prep(x)
+    check(_ffi.lib().xcx_sosfilt_zerophase(ctx.handle, ptr(buf), b, n, ptr(sos),
+                                           sos.shape[0], dev))
     return buf
 
 

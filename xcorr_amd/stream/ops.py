@@ -61,7 +61,7 @@ def detrend(x, type='demean', ctx=None):
 def filter(x, sampling_rate, type, corners=4, zerophase=False, ctx=None, **options):
     """``Trace.filter(type, freq= | freqmin=, freqmax=, corners=4, zerophase=False)``."""
     sos = butter_sos(type, sampling_rate, corners, **options)
-    return _ops.sosfiltfilt(ctx, x, sos) if zerophase else _ops.sosfilt(ctx, x, sos)
+    return _ops.sosfilt_zerophase(ctx, x, sos) if zerophase else _ops.sosfilt(ctx, x, sos)
 
 
 def taper(x, sampling_rate, max_percentage=0.05, type='cosine', max_length=None, ctx=None):
