@@ -31,6 +31,8 @@ def run(budget=60.0, seed=0, ctx=None):
     pairs = np.array([allp[i] for i in rng.choice(len(allp), k, replace=False)], np.int32)
     tr = (rng.standard_normal((S, T)) + rng.uniform(-1, 1)).astype(np.float32)
     plan = CCPlan(ctx, n, imin, imax, stack=stack, **flags)
+    if os.environ.get('FUZZ_VERBOSE'):
+        print(cases, dict(n=n, W=W, hop=hop, S=S, imin=imin, imax=imax, stack=stack, P=len(pairs), N1=plan.N1, N2=plan.N2, batch=plan.batch, **flags), flush=True)
     got = plan.pairs(tr, pairs, W, hop)
     ref = R.cc_pairs(tr, pairs, n, hop, normalize=flags['normalize'], index_min=imin, index_max=imax,
                      onebit_=flags['onebit'], demean_=flags['demean'], dtype=np.float64)[:, :W]

@@ -106,6 +106,14 @@ template <int M, int N, bool INV> XCX_DEV cf mul_wconst(cf a) {
   }
 }
 
+// base + unsigned 32-bit element offset.  With a wave-uniform base the address is
+// SGPR pair + zero-extended VGPR, which selects the saddr form of global_load/store
+// (no per-lane 64-bit address arithmetic); a signed int index does not.
+template <class T> XCX_DEV T* uoff(T* base, unsigned elem) {
+  typedef typename std::conditional<std::is_const<T>::value, const char, char>::type B;
+  return reinterpret_cast<T*>(reinterpret_cast<B*>(base) + (size_t)(elem * (unsigned)sizeof(T)));
+}
+
 // compile-time loop
 template <class F, int... Is>
 XCX_DEV void static_for_impl(F&& f, std::integer_sequence<int, Is...>) {
@@ -336,7 +344,7 @@ XCX_DEV void stage_tw_base(const cf* __restrict__ tw,
   for (int it = 0; it < G::IT; ++it) {
     const int b = tid_of<NT>() + it * NT;
     const int j = (G::GUARD && b >= G::NBF) ? 0 : b / NB;
-    base[it] = tw[(j % NS) * G::STEP];
+    base[it] = *uoff(tw, (unsigned)((j % NS) * G::STEP));
   }
 }
 
@@ -441,6 +449,60 @@ XCX_DEV void stage_exchange(float* __restrict__ ldsf, Idx idx,
   }
 }
 
+// The same exchange for ONE sequence (NB = 1) in the column kernels' padded layout
+// idx(p) = p + (p >> 3).  The pad makes idx non-linear, and the compiler then recomputes a
+// shift + add per LDS access (~200 integer VALU instructions per 1536-point column).  Both
+// access patterns step by multiples of 8 (or stay inside one aligned group of 8), where
+// idx(p0 + d) = idx(p0) + d + d/8 holds exactly: one base per butterfly, every other address
+// is a compile-time immediate of the ds instruction.
+template <int L, int RA, int NSA, int RB, int NT>
+XCX_DEV void stage_exchange_pad8(float* __restrict__ ldsf,
+                                 const typename StageGeom<L, RA, NSA, 1, NT>::Regs& src,
+                                 typename StageGeom<L, RB, NSA * RA, 1, NT>::Regs& dst) {
+  using GA = StageGeom<L, RA, NSA, 1, NT>;
+  using GB = StageGeom<L, RB, NSA * RA, 1, NT>;
+  constexpr int RD = L / RB;
+  constexpr bool WFAST = (NSA == 1) ? (RA % 8 == 0) : (NSA % 8 == 0);
+  constexpr bool RFAST = (RD % 8 == 0);
+  const int tid = tid_of<NT>();
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+#pragma unroll
+    for (int it = 0; it < GA::IT; ++it) {
+      const int j = tid + it * NT;
+      if (!GA::GUARD || j < GA::NBF) {
+        const int k = (NSA > 1) ? (j % NSA) : 0;
+        const int j0 = (j - k) * RA + k;
+        const int base = j0 + (j0 >> 3);
+        static_for<RA>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          constexpr int d = t * NSA;
+          const float f = half ? src[it][t].y : src[it][t].x;
+          if constexpr (WFAST) ldsf[base + d + (d >> 3)] = f;
+          else ldsf[(j0 + d) + ((j0 + d) >> 3)] = f;
+        });
+      }
+    }
+    group_sync<NT>();
+#pragma unroll
+    for (int it = 0; it < GB::IT; ++it) {
+      const int j = tid + it * NT;
+      if (!GB::GUARD || j < GB::NBF) {
+        const int base = j + (j >> 3);
+        static_for<RB>([&](auto tc) {
+          constexpr int t = decltype(tc)::value;
+          constexpr int d = t * RD;
+          float f;
+          if constexpr (RFAST) f = ldsf[base + d + (d >> 3)];
+          else f = ldsf[(j + d) + ((j + d) >> 3)];
+          if (half) dst[it][t].y = f; else dst[it][t].x = f;
+        });
+      }
+    }
+    group_sync<NT>();
+  }
+}
+
 // twiddle (chain from the per-iteration base factor) + butterfly, in registers
 template <int L, int R, int NS, int NB, int NT, bool INV>
 XCX_DEV void stage_compute(typename StageGeom<L, R, NS, NB, NT>::Regs& v,
@@ -495,8 +557,8 @@ XCX_DEV void subfft(cf* __restrict__ lds, const cf* __restrict__ tw, In in,
 // tab[0..QL) = w_N^{ql},  tab[QL + qh] = w_N^{QL*qh}
 constexpr int kTwQL = 512;
 XCX_DEV cf twN_lookup(const cf* __restrict__ tab, unsigned q) {
-  const cf lo = tab[q & (kTwQL - 1)];
-  const cf hi = tab[kTwQL + (q >> 9)];
+  const cf lo = *uoff(tab, q & (kTwQL - 1));
+  const cf hi = *uoff(tab, kTwQL + (q >> 9));
   return cmul(lo, hi);
 }
 

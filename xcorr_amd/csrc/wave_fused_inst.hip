@@ -49,4 +49,22 @@ hipError_t XCX_CAT3(launch_wdual_, XCX_FC_L, _, XCX_FR_L)(const WDualArgs& a, hi
   return hipGetLastError();
 }
 
+hipError_t XCX_CAT3(launch_wflow_, XCX_FC_L, _, XCX_FR_L)(const WFlowArgs& a, hipStream_t s) {
+  constexpr size_t lc = lds_col_floats(RXC::L), lr = lds_row_floats(RXR::L);
+  constexpr size_t lds = sizeof(float) * (lc > lr ? lc : lr) * kWPB;
+  constexpr int CPX = (RXR::L + 1 + 7) / 8, RPX = 2 * (((RXC::L / kWRB + 1) / 2 + 7) / 8);
+  const int nbatch = (a.count + a.B - 1) / a.B;
+  const long wpg = ((long)(CPX + RPX) * a.B + kWPB - 1) / kWPB;
+  const long nwg = 8L * wpg * (nbatch + kFlowLag);           // trailing groups: rows of the last batches
+  if (nwg > 0x7fffffffL) return hipErrorInvalidValue;
+  const dim3 grid((unsigned)nwg);
+  if (a.nstack < 0)
+    hipLaunchKernelGGL((k_wpair_flow<RXC, RXR, 2>), grid, dim3(kWNT * kWPB), lds, s, a);
+  else if (a.nstack > 1)
+    hipLaunchKernelGGL((k_wpair_flow<RXC, RXR, 1>), grid, dim3(kWNT * kWPB), lds, s, a);
+  else
+    hipLaunchKernelGGL((k_wpair_flow<RXC, RXR, 0>), grid, dim3(kWNT * kWPB), lds, s, a);
+  return hipGetLastError();
+}
+
 }  // namespace xcx

@@ -28,6 +28,36 @@
 
 namespace xcx {
 
+// ---------------------------------------------------------------------------
+// Diagnostic build only (-DXCX_STAMPS, tools/stamps.sh): s_memtime stamps at the phase
+// boundaries of the pair bodies, to see where a wave's lifetime goes.  In the product build
+// every macro below expands to nothing.
+// ---------------------------------------------------------------------------
+#ifdef XCX_STAMPS
+constexpr int kNStamp = 12;
+typedef unsigned long long StampArr[kNStamp];
+// the VGPR operand pins the stamp behind the instruction that produced `pin`
+XCX_DEV unsigned long long stamp_wait(float pin) {
+  unsigned long long t;
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(pin) : "memory");
+  return t;
+}
+XCX_DEV unsigned long long stamp_nowait(float pin) {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t) : "v"(pin) : "memory");
+  return t;
+}
+#define XCX_ST_PARAM , StampArr& xst
+#define XCX_ST_ARG , xst
+#define XCX_STAMP(i, pin) xst[i] = stamp_wait(pin)
+#define XCX_STAMP_NW(i, pin) xst[i] = stamp_nowait(pin)
+#else
+#define XCX_ST_PARAM
+#define XCX_ST_ARG
+#define XCX_STAMP(i, pin)
+#define XCX_STAMP_NW(i, pin)
+#endif
+
 // minimum waves per SIMD the register allocator must leave room for
 #ifndef XCX_COL_WAVES
 #define XCX_COL_WAVES 1
@@ -43,7 +73,11 @@ constexpr int kWPB = 4;      // independent waves packed into one 256-thread wor
 constexpr int lds_col_floats(int L) { return (L + (L >> 3) + 1 + 3) & ~3; }
 constexpr int lds_row_floats(int L) { return ((L + (L >> 3) + 1) * 16 + 3) & ~3; }
 constexpr int lds_frow_floats(int L) { return L * 16 * 2; }
-XCX_DEV int wave_in_group() { return (int)(threadIdx.x >> 6); }
+// wave-uniform BY CONSTRUCTION: readfirstlane tells the compiler so, and everything derived from it
+// (work item, descriptor, column / tile base pointers) lives in SGPRs -- descriptor loads become
+// s_load (scalar cache) and the data loads take the saddr + 32-bit voffset form instead of
+// per-lane 64-bit addresses
+XCX_DEV int wave_in_group() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 // LDS index of column kernels: one 8-byte pad slot every 8 positions makes the
 // stride-R stores of the first Stockham stage bank-conflict free
@@ -66,17 +100,33 @@ template <class RX> struct ColGeom {
 };
 
 template <class RX, bool INV, class In, class Epi>
-XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in, Epi epi) {
+XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in, Epi epi XCX_ST_PARAM) {
   constexpr int L = RX::L;
   constexpr int R0 = RX::R0, R1 = RX::R1, R2 = RX::R2;
   static_assert(RX::S == 2 || RX::S == 3, "column configs have two or three stages");
   float* __restrict__ ldsf = reinterpret_cast<float*>(lds);
-  auto idx = [](int p, int) { return cpad(p); };
   using G0 = StageGeom<L, R0, 1, 1, kWNT>;
   using G1 = StageGeom<L, R1, R0, 1, kWNT>;
   cf b1[G1::IT];
   stage_tw_base<L, R1, R0, 1, kWNT>(tw, b1);
   cf v0[G0::IT][R0];
+#ifdef XCX_STAMPS
+#pragma unroll
+  for (int it = 0; it < G0::IT; ++it) {
+    const int j = tid_of<kWNT>() + it * kWNT;
+    if (!G0::GUARD || j < G0::NBF) {
+#pragma unroll
+      for (int t = 0; t < R0; ++t) v0[it][t] = in(j + t * (L / R0), 0);
+    }
+  }
+  XCX_STAMP(1, v0[G0::IT - 1][R0 - 1].x);          // inputs have arrived (product formed)
+#pragma unroll
+  for (int it = 0; it < G0::IT; ++it) {
+    const int j = tid_of<kWNT>() + it * kWNT;
+    if (!G0::GUARD || j < G0::NBF) Bfly<R0, INV>::run(v0[it]);
+  }
+  XCX_STAMP(2, v0[G0::IT - 1][R0 - 1].x);          // stage 0 computed
+#else
 #pragma unroll
   for (int it = 0; it < G0::IT; ++it) {
     const int j = tid_of<kWNT>() + it * kWNT;
@@ -86,9 +136,10 @@ XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in
       Bfly<R0, INV>::run(v0[it]);
     }
   }
+#endif
   cf v1[G1::IT][R1];
   if constexpr (RX::S == 2) {
-    stage_exchange<L, R0, 1, R1, 1, kWNT>(ldsf, idx, v0, v1);
+    stage_exchange_pad8<L, R0, 1, R1, kWNT>(ldsf, v0, v1);
     stage_compute<L, R1, R0, 1, kWNT, INV>(v1, b1);
 #pragma unroll
     for (int it = 0; it < G1::IT; ++it) {
@@ -102,11 +153,15 @@ XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in
     using G2 = StageGeom<L, R2, R0 * R1, 1, kWNT>;
     cf b2[G2::IT];
     stage_tw_base<L, R2, R0 * R1, 1, kWNT>(tw, b2);
-    stage_exchange<L, R0, 1, R1, 1, kWNT>(ldsf, idx, v0, v1);
+    stage_exchange_pad8<L, R0, 1, R1, kWNT>(ldsf, v0, v1);
+    XCX_STAMP(3, v1[G1::IT - 1][R1 - 1].y);
     stage_compute<L, R1, R0, 1, kWNT, INV>(v1, b1);
+    XCX_STAMP(4, v1[G1::IT - 1][R1 - 1].y);
     cf v2[G2::IT][R2];
-    stage_exchange<L, R1, R0, R2, 1, kWNT>(ldsf, idx, v1, v2);
+    stage_exchange_pad8<L, R1, R0, R2, kWNT>(ldsf, v1, v2);
+    XCX_STAMP(5, v2[G2::IT - 1][R2 - 1].y);
     stage_compute<L, R2, R0 * R1, 1, kWNT, INV>(v2, b2);
+    XCX_STAMP(6, v2[G2::IT - 1][R2 - 1].y);
 #pragma unroll
     for (int it = 0; it < G2::IT; ++it) {
       const int j = tid_of<kWNT>() + it * kWNT;
@@ -282,7 +337,10 @@ void k_wfwd_cols(WF2Args a) {
       dst[k1] = cscale(o, scale);
     }
   };
-  wave_col_fft<RX, false>(lds, a.tw_sub, in, epi);
+#ifdef XCX_STAMPS
+  StampArr xst;
+#endif
+  wave_col_fft<RX, false>(lds, a.tw_sub, in, epi XCX_ST_ARG);
 }
 
 // ---------------------------------------------------------------------------
@@ -306,7 +364,7 @@ struct WI1Args {
 template <class RX, int MODE>
 XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_t spec_pitch,
                            const PwDesc d, int nstack, int k2, cf* __restrict__ T,
-                           const cf* __restrict__ tw_sub, const cf* __restrict__ twN, const Geom& g) {
+                           const cf* __restrict__ tw_sub, const cf* __restrict__ twN, const Geom& g XCX_ST_PARAM) {
   constexpr int N1 = RX::L;
   const int N2h = g.N2h;
   const cf* __restrict__ A = X + (size_t)d.slot_a * spec_pitch + (size_t)k2 * N1;
@@ -328,9 +386,9 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
   const cf gstep = twN_lookup(twN, (unsigned)CG::NSL * kk);
   auto in = [=](int k1, int) -> cf {
     if constexpr (MODE == 2) {
-      return A[k1];
+      return *uoff(A, (unsigned)k1);
     } else {
-      cf acc = cmulc(A[k1], Bp[k1]);
+      cf acc = cmulc(*uoff(A, (unsigned)k1), *uoff(Bp, (unsigned)k1));
       if constexpr (MODE == 1) {
         for (int w = 1; w < nstack; ++w)
           acc = cadd(acc, cmulc(A[k1 + w * sstride], Bp[k1 + w * sstride]));
@@ -343,18 +401,33 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
   auto epi = [=](int it, int j0, int, cf (&v)[CG::RL]) {
     cf g8 = gstep, f = f0[it];
     if constexpr (CG::RL > 8) g8 = csq(csq(csq(gstep)));
+    int res0 = j0 + shift;
+    if (res0 >= N1) res0 -= N1;
+    const unsigned off0 = (unsigned)((res0 >> 4) * trow + (res0 & 15));
+    const int twrap = (N1 - res0 + CG::NSL - 1) / CG::NSL;            // first t whose residue wraps
+    const unsigned wrapsz = (unsigned)(N1 / kWRB) * (unsigned)trow;
     static_for<CG::RL>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
       if constexpr (t > 0) {
         if constexpr (t % 8 == 0) { f = f0[it]; static_for<t / 8>([&](auto) { f = cmul(f, g8); }); }
         else f = cmul(f, gstep);
       }
-      int res = j0 + t * CG::NSL + shift;
-      if (res >= N1) res -= N1;
-      Tc[(res >> 4) * trow + (res & 15)] = cmulc(v[t], f);
+      // res = (j0 + shift + t NSL) mod N1; with NSL a multiple of 16 the tile offset advances by a
+      // constant per t and wraps once: offset = off0 + t dstep - (t >= twrap ? wrapsz : 0)
+      if constexpr (CG::NSL % kWRB == 0) {
+        constexpr unsigned dstep = (unsigned)(CG::NSL / kWRB);
+        const unsigned o = off0 + (unsigned)t * dstep * (unsigned)trow - ((t >= twrap) ? wrapsz : 0u);
+        *uoff(Tc, o) = cmulc(v[t], f);
+      } else {
+        int res = j0 + t * CG::NSL + shift;
+        if (res >= N1) res -= N1;
+        *uoff(Tc, (unsigned)((res >> 4) * trow + (res & 15))) = cmulc(v[t], f);
+      }
     });
   };
-  wave_col_fft<RX, true>(lds, tw_sub, in, epi);
+  wave_col_fft<RX, true>(lds, tw_sub, in, epi XCX_ST_ARG);
+  XCX_STAMP_NW(7, gstep.x);                          // T stores issued
+  XCX_STAMP(8, gstep.x);                             // ... and acknowledged
 }
 
 template <class RX, int MODE>
@@ -369,8 +442,11 @@ void k_wpair_cols(WI1Args a) {
   const int k2 = (q / a.B) * 8 + x;
   const int pwl = q % a.B;
   if (k2 > N2h) return;
+#ifdef XCX_STAMPS
+  StampArr xst;
+#endif
   pair_col_body<RX, MODE>(lds, a.X, a.spec_pitch, a.pw[pwl], a.nstack, k2,
-                           a.T + (size_t)pwl * RX::L * (N2h + 1), a.tw_sub, a.tw_N, g);
+                           a.T + (size_t)pwl * RX::L * (N2h + 1), a.tw_sub, a.tw_N, g XCX_ST_ARG);
 }
 
 // ---------------------------------------------------------------------------
@@ -410,7 +486,7 @@ template <bool SC1> XCX_DEV cf load_t(const cf* p) {
 template <class RX, bool SC1, bool UNBIAS>
 XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, float* __restrict__ out, int blk,
                            const cf* __restrict__ tw_sub, const cf* __restrict__ twu, float* __restrict__ trash,
-                           const Geom& g) {
+                           const Geom& g XCX_ST_PARAM) {
   constexpr int N2h = RX::L;
   constexpr int R = RX::R0;
   constexpr int S = N2h / R;
@@ -424,6 +500,71 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
   stage_tw_base<N2h, RX::R1, RX::R0, kWRB, kWNT>(tw_sub, b1);
 
   // ---- stage 0: paired butterflies (j, S-j) with the Hermitian untangle ----
+#ifdef XCX_STAMPS
+  cf s0a[IT][R], s0b[IT][R];
+  auto load_it = [&](int it, cf (&av)[R], cf (&bv)[R]) {
+    const int w = lane + it * kWNT;
+    if ((TOTAL % kWNT) != 0 && w >= TOTAL) return;
+    const int r = w % kWRB;
+    const int j = w / kWRB;                       // 0..S/2
+    const int jp = (j == 0) ? 0 : (S - j);
+    const bool single = jp == j;
+#pragma unroll
+    for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(uoff(Tt, (unsigned)((j + S * t) * kWRB + r)));
+    if (!single) {
+#pragma unroll
+      for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(uoff(Tt, (unsigned)((jp + S * t) * kWRB + r)));
+    } else if (j == 0) {
+#pragma unroll
+      for (int t = 0; t < R; ++t) bv[t] = av[(t + 1) % R];   // mirror of S*t' is S*(R-t')
+    } else {
+#pragma unroll
+      for (int t = 0; t < R; ++t) bv[t] = av[t];             // j = S/2 mirrors inside itself
+    }
+  };
+  auto compute_it = [&](int it, cf (&av)[R], cf (&bv)[R]) {
+    const int w = lane + it * kWNT;
+    if ((TOTAL % kWNT) != 0 && w >= TOTAL) return;
+    const int r = w % kWRB;
+    const int j = w / kWRB;
+    const int jp = (j == 0) ? 0 : (S - j);
+    const bool single = jp == j;
+    // Hermitian untangle, shared by the pair: with h = H[k] (k = j + S t),
+    // g = H[N2h-k] = bv[R-1-t], e = e^{+2 pi i k/N2} = conj(twu[j]) e^{+2 pi i t/(2R)}
+    //   sm = h + conj g,  ed = e (h - conj g)
+    //   U_j [t]     = sm + i ed
+    //   U_j'[R-1-t] = conj(sm) + i conj(ed)      (because e_{N2h-k} = -conj e_k)
+    const cf ej = cconj(*uoff(twu, (unsigned)j));
+    cf uj[R], ujp[R];
+    static_for<R>([&](auto tc) {
+      constexpr int t = decltype(tc)::value;
+      const cf h = av[t], hb = cconj(bv[R - 1 - t]);
+      const cf sm = cadd(h, hb), df = csub(h, hb);
+      const cf ed = cmul(mul_wconst<t, 2 * R, true>(ej), df);
+      uj[t] = make_float2(sm.x - ed.y, sm.y + ed.x);
+      ujp[R - 1 - t] = make_float2(sm.x + ed.y, ed.x - sm.y);
+    });
+    if (j == 0) {                                  // DC and Nyquist of the row are real
+      const float dc = av[0].x, ny = load_t<SC1>(uoff(Tt, (unsigned)(N2h * kWRB + r))).x;
+      uj[0] = make_float2(dc + ny, dc - ny);
+    }
+    Bfly<R, true>::run(uj);
+    if (!single) Bfly<R, true>::run(ujp);
+    // Stockham positions of stage 0 (NS = 1): butterfly j -> j*R + t; real and
+    // imaginary parts go through the half-size LDS buffer in two rounds below
+#pragma unroll
+    for (int t = 0; t < R; ++t) { s0a[it][t] = uj[t]; s0b[it][t] = ujp[t]; }
+  };
+  {
+    cf av_all[IT][R], bv_all[IT][R];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) load_it(it, av_all[it], bv_all[it]);
+    XCX_STAMP(1, av_all[0][0].x);                  // T tile has arrived
+#pragma unroll
+    for (int it = 0; it < IT; ++it) compute_it(it, av_all[it], bv_all[it]);
+    XCX_STAMP(2, s0a[0][0].x);
+  }
+#else
   cf s0a[IT][R], s0b[IT][R];
 #pragma unroll
   for (int it = 0; it < IT; ++it) {
@@ -435,10 +576,10 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
     const bool single = jp == j;
     cf av[R], bv[R];
 #pragma unroll
-    for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(Tt + (j + S * t) * kWRB + r);
+    for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(uoff(Tt, (unsigned)((j + S * t) * kWRB + r)));
     if (!single) {
 #pragma unroll
-      for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(Tt + (jp + S * t) * kWRB + r);
+      for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(uoff(Tt, (unsigned)((jp + S * t) * kWRB + r)));
     } else if (j == 0) {
 #pragma unroll
       for (int t = 0; t < R; ++t) bv[t] = av[(t + 1) % R];   // mirror of S*t' is S*(R-t')
@@ -451,7 +592,7 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
     //   sm = h + conj g,  ed = e (h - conj g)
     //   U_j [t]     = sm + i ed
     //   U_j'[R-1-t] = conj(sm) + i conj(ed)      (because e_{N2h-k} = -conj e_k)
-    const cf ej = cconj(twu[j]);
+    const cf ej = cconj(*uoff(twu, (unsigned)j));
     cf uj[R], ujp[R];
     static_for<R>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
@@ -462,7 +603,7 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
       ujp[R - 1 - t] = make_float2(sm.x + ed.y, ed.x - sm.y);
     });
     if (j == 0) {                                  // DC and Nyquist of the row are real
-      const float dc = av[0].x, ny = load_t<SC1>(Tt + N2h * kWRB + r).x;
+      const float dc = av[0].x, ny = load_t<SC1>(uoff(Tt, (unsigned)(N2h * kWRB + r))).x;
       uj[0] = make_float2(dc + ny, dc - ny);
     }
     Bfly<R, true>::run(uj);
@@ -472,6 +613,7 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
 #pragma unroll
     for (int t = 0; t < R; ++t) { s0a[it][t] = uj[t]; s0b[it][t] = ujp[t]; }
   }
+#endif
   float* __restrict__ ldsf = reinterpret_cast<float*>(lds);
   using G1 = StageGeom<N2h, RX::R1, RX::R0, kWRB, kWNT>;
   cf v1[G1::IT][RX::R1];
@@ -484,11 +626,17 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
       const int r = w % kWRB;
       const int j = w / kWRB;
       const int jp = (j == 0) ? 0 : (S - j);
+      // rpad(p0 + d, r) = rpad(p0, r) + (d + d/8) * 16 when the group of 8 is not left (R % 8 == 0,
+      // p0 = j R) or d is a multiple of 8: one base per butterfly, immediates for the rest
+      constexpr bool WF = (R % 8 == 0);
+      const int wa = rpad(j * R, r), wb = rpad(jp * R, r);
 #pragma unroll
-      for (int t = 0; t < R; ++t) ldsf[rpad(j * R + t, r)] = half ? s0a[it][t].y : s0a[it][t].x;
+      for (int t = 0; t < R; ++t)
+        ldsf[WF ? wa + (t + (t >> 3)) * kWRB : rpad(j * R + t, r)] = half ? s0a[it][t].y : s0a[it][t].x;
       if (jp != j) {
 #pragma unroll
-        for (int t = 0; t < R; ++t) ldsf[rpad(jp * R + t, r)] = half ? s0b[it][t].y : s0b[it][t].x;
+        for (int t = 0; t < R; ++t)
+          ldsf[WF ? wb + (t + (t >> 3)) * kWRB : rpad(jp * R + t, r)] = half ? s0b[it][t].y : s0b[it][t].x;
       }
     }
     group_sync<kWNT>();
@@ -497,16 +645,21 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
       const int b = lane + it * kWNT;
       if (!G1::GUARD || b < G1::NBF) {
         const int c = b % kWRB, j = b / kWRB;
+        constexpr int RD = N2h / RX::R1;
+        constexpr bool RF = (RD % 8 == 0);
+        const int rb = rpad(j, c);
 #pragma unroll
         for (int t = 0; t < RX::R1; ++t) {
-          const float f = ldsf[rpad(j + t * (N2h / RX::R1), c)];
+          const float f = ldsf[RF ? rb + (t * RD + (t * RD >> 3)) * kWRB : rpad(j + t * RD, c)];
           if (half) v1[it][t].y = f; else v1[it][t].x = f;
         }
       }
     }
     group_sync<kWNT>();
   }
+  XCX_STAMP(3, v1[G1::IT - 1][RX::R1 - 1].y);
   stage_compute<N2h, RX::R1, RX::R0, kWRB, kWNT, true>(v1, b1);
+  XCX_STAMP(4, v1[G1::IT - 1][RX::R1 - 1].y);
   // ---- second stage + output ---------------------------------------------
   // Branch-free stores: a lag outside [idx_min, idx_max) (the N-(2n-1) padding
   // lags, or a clipped slice) is redirected to a per-lane trash word instead
@@ -552,6 +705,16 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
 #endif
     }
   };
+#if XCX_BUFSTORE
+  // circular lag index in BYTES without a compare/select: x = 4 (base + N1 k) wraps to x - 4N once
+  // x >= 4 (N - idx_min).  min_u32(x, x - 4N) picks the wrapped value exactly when it is in range:
+  // below the wrap point x - 4N underflows to a huge offset (min = x); from 4N on x - 4N < x; in
+  // between (only when idx_min > 0) both candidates are >= 4 (N - idx_min) >= 4 Lout and the buffer
+  // range check drops the store, as it must (lag below idx_min).  Negative indices (idx_min > n-1)
+  // are huge either way.  One running byte offset per butterfly: 3 VALU instructions per lag.
+  const unsigned NB = 4u * (unsigned)N, N1b = 4u * (unsigned)N1;
+  const unsigned base4 = 4u * (unsigned)base;
+#endif
 #pragma unroll
   for (int it = 0; it < G1::IT; ++it) {
     const int b = lane + it * kWNT;
@@ -559,10 +722,28 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
       const int j = b / kWRB;
       const int k = j % RX::R0;
       const int j0 = (j - k) * RX::R1 + k;
+#if XCX_BUFSTORE
+      if constexpr (!UNBIAS) {
+        const unsigned mb = base4 + 2u * N1b * (unsigned)j0;
+#pragma unroll
+        for (int t = 0; t < RX::R1; ++t) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const unsigned x = mb + N1b * (unsigned)(2 * t * RX::R0 + h);
+            const unsigned y = x - NB;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h ? v1[it][t].y : v1[it][t].x), rsrc,
+                                                  (int)(x < y ? x : y), 0, /*nt*/ 2);
+          }
+        }
+        continue;
+      }
+#endif
 #pragma unroll
       for (int t = 0; t < RX::R1; ++t) out_f(j0 + t * RX::R0, 0, v1[it][t]);
     }
   }
+  XCX_STAMP_NW(7, v1[0][0].x);                       // CCF stores issued
+  XCX_STAMP(8, v1[0][0].x);                          // ... and acknowledged
 }
 
 template <class RX>
@@ -573,10 +754,13 @@ void k_wpair_rows(WI2Args a) {
   cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave_in_group() * lds_row_floats(RX::L));
   const int pwl = blockIdx.y, blk = blockIdx.x * kWPB + wave_in_group();
   const cf* __restrict__ Tt = a.T + ((size_t)pwl * (g.N1 / kWRB) + blk) * (size_t)(RX::L + 1) * kWRB;
+#ifdef XCX_STAMPS
+  StampArr xst;
+#endif
   if (g.flags & XCX_F_UNBIAS)
-    pair_row_body<RX, false, true>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, a.trash, g);
+    pair_row_body<RX, false, true>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, a.trash, g XCX_ST_ARG);
   else
-    pair_row_body<RX, false, false>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, a.trash, g);
+    pair_row_body<RX, false, false>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, a.trash, g XCX_ST_ARG);
 }
 
 // ---------------------------------------------------------------------------
@@ -642,6 +826,9 @@ __global__ __launch_bounds__(kWNT * kWPB) void k_wpair_fused(WFusedArgs a) {
   const size_t tslot = (size_t)N1 * NC;
   cf* __restrict__ Tx = a.Tring + (size_t)x * 3 * tslot;
   int* tick = a.ticket + x * 32;
+#ifdef XCX_STAMPS
+  StampArr xst;
+#endif
   for (;;) {
     int t = 0;
     if (tid_of<kWNT>() == 0) t = __hip_atomic_fetch_add(tick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -664,17 +851,17 @@ __global__ __launch_bounds__(kWNT * kWPB) void k_wpair_fused(WFusedArgs a) {
         const int kp = k - 3;
         spin_until(a.rdone + (((kp >> 3) << 6) | (x << 3) | (kp & 7)), NR, a.err);
       }
-      pair_col_body<RXC, MODE>(lds, a.X, a.spec_pitch, a.pw[pw], a.nstack, sub, T, a.tw_N1, a.tw_N, g);
+      pair_col_body<RXC, MODE>(lds, a.X, a.spec_pitch, a.pw[pw], a.nstack, sub, T, a.tw_N1, a.tw_N, g XCX_ST_ARG);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // T stores are in L2
       if (tid_of<kWNT>() == 0) __hip_atomic_fetch_add(a.cdone + pw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       spin_until(a.cdone + pw, NC, a.err);
       if (g.flags & XCX_F_UNBIAS)
         pair_row_body<RXR, true, true>(lds, T + (size_t)sub * NC * kWRB, a.out + a.pw[pw].out_off, sub,
-                                       a.tw_N2h, a.tw_unt, a.trash, g);
+                                       a.tw_N2h, a.tw_unt, a.trash, g XCX_ST_ARG);
       else
         pair_row_body<RXR, true, false>(lds, T + (size_t)sub * NC * kWRB, a.out + a.pw[pw].out_off, sub,
-                                        a.tw_N2h, a.tw_unt, a.trash, g);
+                                        a.tw_N2h, a.tw_unt, a.trash, g XCX_ST_ARG);
       // all T loads of this wave have returned (their values were consumed)
       if (tid_of<kWNT>() == 0) __hip_atomic_fetch_add(a.rdone + pw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -695,6 +882,9 @@ struct WDualArgs {
   const PwDesc* pw_r; int Br; const cf* Tr; float* out; float* trash; // row pass: batch b-1
   const cf* tw_N1; const cf* tw_N2h; const cf* tw_unt; const cf* tw_N;
   Geom g;
+#ifdef XCX_STAMPS
+  unsigned long long* stamps;      // [waves of the launch][kNStamp] or null
+#endif
 };
 
 // amdgpu_waves_per_eu(3,3): same 128 VGPRs / 4 waves per SIMD at run time, but
@@ -723,13 +913,30 @@ void k_wpair_dual(WDualArgs a) {
   // (A persistent-wave loop over this sequence was tried: the loop-carried
   // state pushes the kernel into scratch spills and it runs 4x slower.)
   const int grp = q / (CPX + RPX), pos = q % (CPX + RPX);
+#ifdef XCX_STAMPS
+  StampArr xst;
+  for (int i = 0; i < kNStamp; ++i) xst[i] = 0;
+  xst[0] = stamp_nowait(0.f);
+  struct StampOut {
+    StampArr& t; unsigned long long* dst; int q, kind;
+    __device__ ~StampOut() {
+      if (!dst || (threadIdx.x & 63)) return;
+      unsigned hwid;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+      t[9] = stamp_nowait(0.f);
+      t[10] = ((unsigned long long)kind << 32) | hwid;
+      t[11] = __builtin_amdgcn_s_memrealtime();
+      for (int i = 0; i < kNStamp; ++i) dst[(size_t)q * kNStamp + i] = t[i];
+    }
+  } stamp_out{xst, a.stamps, q, pos < CPX ? 1 : 2};
+#endif
   if (pos < CPX) {
     const int ci = grp * CPX + pos;
     const int k2 = (ci / Bm) * 8 + x;
     const int pwl = ci % Bm;
     if (k2 > N2h || pwl >= a.Bc) return;
     pair_col_body<RXC, MODE>(lds, a.X, a.spec_pitch, a.pw_c[pwl], a.nstack, k2,
-                              a.Tc + (size_t)pwl * N1 * (N2h + 1), a.tw_N1, a.tw_N, g);
+                              a.Tc + (size_t)pwl * N1 * (N2h + 1), a.tw_N1, a.tw_N, g XCX_ST_ARG);
   } else {
     // adjacent 16-row tiles (2bp, 2bp+1) are consecutive items of the SAME XCD:
     // the two 64-byte halves of every 128-byte output line are written from one
@@ -741,9 +948,141 @@ void k_wpair_dual(WDualArgs a) {
     if (blk >= NR || pwl >= a.Br) return;
     const cf* __restrict__ Tt = a.Tr + ((size_t)pwl * NR + blk) * (size_t)(N2h + 1) * kWRB;
     if (g.flags & XCX_F_UNBIAS)
-      pair_row_body<RXR, false, true>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, a.trash, g);
+      pair_row_body<RXR, false, true>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, a.trash, g XCX_ST_ARG);
     else
-      pair_row_body<RXR, false, false>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, a.trash, g);
+      pair_row_body<RXR, false, false>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, a.trash, g XCX_ST_ARG);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Flow pair kernel: the WHOLE pair phase (every batch) in ONE launch.
+//
+// The dual kernel above is launched once per batch of 25 pair-windows so that the T ring stays
+// inside the Infinity Cache; a launch of ~1.3 machine rounds starts all its waves together,
+// which then load, compute and store in lock-step (bursts on the memory pipeline, then on the
+// VALU: SQ_WAIT_INST_ANY 41 % at 25 % VALU use) and drains through a tail before the stream's
+// next launch may begin.  Here the same work items are laid out for all batches back to back:
+//   group g  =  column items of batch g  (interleaved CPX:RPX per XCD as in k_wpair_dual)
+//             + row items of batch g-2,
+// workgroups are dispatched in index order, every wave slot is refilled the moment a wave
+// retires, and the phases of neighbouring waves drift apart: a steady, desynchronised flow.
+// The batch-level dependencies become counters in memory:
+//   rows of batch b  wait until cdone[b] == (N2h+1) * B_b   (all its columns stored T),
+//   cols of batch b  wait until rdone[b-R] == NR * B_{b-R}  (ring slot b mod R consumed).
+// The rows of batch b ride in group b+2 and R >= 4, so both refer to items at least one WHOLE
+// group (~1.3 machine rounds of other work) earlier in dispatch order and a wait is normally
+// satisfied on its first poll; every wait is bounded and a
+// timeout raises *err (the host then reports XCX_EHIP instead of returning wrong numbers).
+// Progress: workgroups of one XCD are dispatched in index order and a wave only ever waits
+// for lower-indexed items, so the lowest unfinished item is always resident and runnable.
+// T lives in UNCACHED device memory (hipDeviceMallocUncached): its producers and consumers
+// sit on different XCDs whose L2s are not coherent, and inside one launch there is no kernel
+// boundary to write back / invalidate them; uncached accesses go straight to the fabric
+// (Infinity Cache), which is where T traffic went anyway.  A column wave signals after
+// s_waitcnt vmcnt(0) (its T stores are acknowledged by the fabric).
+// ---------------------------------------------------------------------------
+struct WFlowArgs {
+  const cf* X; size_t spec_pitch;
+  const PwDesc* pw; int count;      // pair-windows of the whole run
+  int B;                            // pair-windows per batch (T ring granule)
+  int R;                            // ring size in batches
+  int nstack;
+  cf* T;                            // [R][B][N1/16][N2h+1][16], uncached
+  float* out; float* trash;
+  int* cdone; int* rdone;           // [batches][8 shards][32 ints], zeroed before the launch
+  int* err;
+  const cf* tw_N1; const cf* tw_N2h; const cf* tw_unt; const cf* tw_N;
+  Geom g;
+};
+
+// completion counters are sharded by the XCD label of the signalling wave (8 words, one 128-byte
+// line each): a single word takes ~12 ns per atomic, i.e. 36 us for the 3025 column waves of a
+// batch -- longer than the batch itself.  A waiter reads the 8 shards with one wave instruction.
+constexpr int kFlowShardInts = 32;                           // ints per shard (one cache line)
+constexpr int kFlowLag = 2;                                  // rows of batch g-2 ride in group g
+
+XCX_DEV bool flow_wait8(const int* shards, int target_lane, int* err) {
+  const int lane = tid_of<kWNT>();
+  bool ok = false;
+  for (int i = 0; i < (1 << 21); ++i) {                      // ~2 s at 1 us per poll
+    const int v = (lane < 8) ? __hip_atomic_load(shards + lane * kFlowShardInts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                             : 0x7fffffff;
+    if (__builtin_amdgcn_ballot_w64(lane < 8 && v < target_lane) == 0) { ok = true; break; }
+    // somebody already timed out: the launch is lost, drain it quickly
+    if ((i & 15) == 15 && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    __builtin_amdgcn_s_sleep(32);
+  }
+  if (!ok && lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  return ok;
+}
+
+template <class RXC, class RXR, int MODE>
+__global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(XCX_DUAL_WAVES, XCX_DUAL_WAVES)))
+void k_wpair_flow(WFlowArgs a) {
+  extern __shared__ __attribute__((aligned(16))) cf lds_all[];
+  const Geom g = a.g;
+  constexpr int N1 = RXC::L;
+  constexpr int N2h = RXR::L;
+  constexpr int NR = N1 / kWRB;
+  constexpr int CPX = (N2h + 1 + 7) / 8;
+  constexpr int RPX = 2 * (((NR + 1) / 2 + 7) / 8);
+  constexpr int kPerWave = lds_col_floats(N1) > lds_row_floats(N2h) ? lds_col_floats(N1) : lds_row_floats(N2h);
+  cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave_in_group() * kPerWave);
+  const int B = a.B;
+  const int x = blockIdx.x & 7;
+  const int wpg = ((CPX + RPX) * B + kWPB - 1) / kWPB;       // workgroups per (group, XCD)
+  const int wg = (int)(blockIdx.x >> 3);
+  const int grp_b = wg / wpg;                                 // group = batch index of the column items
+  const int q = (wg - grp_b * wpg) * kWPB + wave_in_group();
+  const int nbatch = (a.count + B - 1) / B;
+  const int grp = q / (CPX + RPX), pos = q % (CPX + RPX);
+  const int lane = tid_of<kWNT>();
+  // per-shard item counts of one pair-window (lane l < 8 holds shard l's)
+  const int ncx = (lane <= N2h) ? (N2h - lane) / 8 + 1 : 0;          // columns k2 = l, l+8, ...
+  int nrx = 0;
+#pragma unroll
+  for (int rr = 0; rr < RPX; ++rr) nrx += (2 * ((rr >> 1) * 8 + lane) + (rr & 1) < NR) ? 1 : 0;
+#ifdef XCX_STAMPS
+  StampArr xst;
+#endif
+  if (pos < CPX) {
+    const int b = grp_b;
+    if (b >= nbatch) return;
+    const int Bc = min(B, a.count - b * B);
+    const int ci = grp * CPX + pos;
+    const int k2 = (ci / B) * 8 + x;
+    const int pwl = ci % B;
+    if (k2 > N2h || pwl >= Bc) return;
+    if (b >= a.R) {                                           // ring slot consumed?
+      const int bp = b - a.R;
+      if (!flow_wait8(a.rdone + (size_t)bp * 8 * kFlowShardInts, nrx * min(B, a.count - bp * B), a.err)) return;
+    }
+    cf* Tb = a.T + (size_t)(b % a.R) * B * N1 * (N2h + 1);
+    pair_col_body<RXC, MODE>(lds, a.X, a.spec_pitch, a.pw[b * B + pwl], a.nstack, k2,
+                              Tb + (size_t)pwl * N1 * (N2h + 1), a.tw_N1, a.tw_N, g XCX_ST_ARG);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // T stores acknowledged
+    if (lane == 0)
+      __hip_atomic_fetch_add(a.cdone + ((size_t)b * 8 + x) * kFlowShardInts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    const int b = grp_b - kFlowLag;
+    if (b < 0 || b >= nbatch) return;
+    const int Br = min(B, a.count - b * B);
+    const int ri = grp * RPX + (pos - CPX);
+    const int pwl = ri / RPX;
+    const int rr = ri % RPX;
+    const int blk = 2 * ((rr >> 1) * 8 + x) + (rr & 1);
+    if (blk >= NR || pwl >= Br) return;
+    if (!flow_wait8(a.cdone + (size_t)b * 8 * kFlowShardInts, ncx * Br, a.err)) return;
+    const cf* __restrict__ Tt = a.T + ((size_t)(b % a.R) * B * NR + (size_t)pwl * NR + blk) * (size_t)(N2h + 1) * kWRB;
+    float* o = a.out + a.pw[b * B + pwl].out_off;
+    if (g.flags & XCX_F_UNBIAS)
+      pair_row_body<RXR, true, true>(lds, Tt, o, blk, a.tw_N2h, a.tw_unt, a.trash, g XCX_ST_ARG);
+    else
+      pair_row_body<RXR, true, false>(lds, Tt, o, blk, a.tw_N2h, a.tw_unt, a.trash, g XCX_ST_ARG);
+    // every T load of this wave has returned (the values were consumed by the stores above)
+    if (lane == 0)
+      __hip_atomic_fetch_add(a.rdone + ((size_t)b * 8 + x) * kFlowShardInts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

@@ -58,7 +58,7 @@ static const WColEntry kWCols[] = {XCX_WCOL_LIST(XCX_WCOL_ROW)};
 static const WRowEntry kWRows[] = {XCX_WROW_LIST(XCX_WROW_ROW)};
 static const int kNWCols = sizeof(kWCols) / sizeof(kWCols[0]);
 static const int kNWRows = sizeof(kWRows) / sizeof(kWRows[0]);
-#define XCX_WFUSED_ROW(C, R) {C, R, launch_wfused_##C##_##R, launch_wdual_##C##_##R},
+#define XCX_WFUSED_ROW(C, R) {C, R, launch_wfused_##C##_##R, launch_wdual_##C##_##R, launch_wflow_##C##_##R},
 static const WFusedEntry kWFused[] = {XCX_WFUSED_LIST(XCX_WFUSED_ROW)};
 static const int kNWFused = sizeof(kWFused) / sizeof(kWFused[0]);
 
@@ -156,6 +156,8 @@ __global__ __launch_bounds__(kNT) void k_stats(
 // ---------------------------------------------------------------------------
 // context
 // ---------------------------------------------------------------------------
+static int flow_check(xcx_ctx* ctx);
+
 extern "C" int xcx_device_count(int* count) {
   if (!count) return set_err(XCX_EINVAL, "count is null");
   int c = 0;
@@ -195,6 +197,9 @@ extern "C" int xcx_destroy(xcx_ctx* ctx) {
   ctx->sg_tab.release();
   ctx->sos_tab.release();
   for (auto& b : ctx->scratch) b.release();
+  if (ctx->flow_T) (void)hipFree(ctx->flow_T);
+  if (ctx->flow_err_dev) (void)hipFree(ctx->flow_err_dev);
+  if (ctx->flow_err_host) (void)hipHostFree(ctx->flow_err_host);
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
   (void)hipStreamDestroy(ctx->stream);
@@ -245,7 +250,7 @@ extern "C" int xcx_memcpy_d2h(xcx_ctx* ctx, void* dst, const void* src, size_t b
   if (!ctx || !dst || !src) return set_err(XCX_EINVAL, "null argument");
   HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return XCX_OK;
+  return flow_check(ctx);
 }
 extern "C" int xcx_memcpy_d2d(xcx_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (!ctx || !dst || !src) return set_err(XCX_EINVAL, "null argument");
@@ -258,12 +263,26 @@ extern "C" int xcx_memcpy2d_d2h(xcx_ctx* ctx, void* dst, size_t dpitch, const vo
   HIP_TRY(hipMemcpy2DAsync(dst, dpitch, src, spitch, width_bytes, rows,
                            hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return flow_check(ctx);
+}
+// after a synchronisation of the context's stream: did a flow launch give up on a dependency?
+static int flow_check(xcx_ctx* ctx) {
+  if (!ctx->flow_ran || !ctx->flow_err_host) return XCX_OK;
+  if (hipStreamQuery(ctx->stream) != hipSuccess) { (void)hipGetLastError(); return XCX_OK; }   // still running: checked later
+  ctx->flow_ran = false;
+  if (*ctx->flow_err_host) {
+    *ctx->flow_err_host = 0;
+    (void)hipMemsetAsync(ctx->flow_err_dev, 0, sizeof(int), ctx->stream);
+    return set_err(XCX_EHIP, "flow pair kernel: a batch dependency wait timed out; the CCFs of the last call are invalid "
+                             "(set XCX_FLOW=0 to use the per-batch launches)");
+  }
   return XCX_OK;
 }
+
 extern "C" int xcx_sync(xcx_ctx* ctx) {
   if (!ctx) return set_err(XCX_EINVAL, "null ctx");
   HIP_TRY(hipStreamSynchronize(ctx->stream));
-  return XCX_OK;
+  return flow_check(ctx);
 }
 extern "C" int xcx_timer_start(xcx_ctx* ctx) {
   if (!ctx) return set_err(XCX_EINVAL, "null ctx");
@@ -275,7 +294,7 @@ extern "C" int xcx_timer_stop(xcx_ctx* ctx, float* ms) {
   HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(hipEventSynchronize(ctx->ev1));
   HIP_TRY(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
-  return XCX_OK;
+  return flow_check(ctx);
 }
 
 // ---------------------------------------------------------------------------
@@ -317,6 +336,9 @@ struct xcx_plan {
   DevBuf trash;              // 64 floats: sink of out-of-range lags (branch-free stores)
   int fused_blocks = 0;
   const WFusedEntry* dual = nullptr;    // one-launch I2(b-1) + I1(b) kernel, if built for (N1, N2h)
+  bool flow = false;                    // whole pair phase in one launch (k_wpair_flow), default when built
+  DevBuf flow_sync;                     // cdone / rdone counters
+  int flow_R = 4;
   // pending row pass of the dual pipeline
   // dual pipelines ("chains"): each chain owns a stream and a double-buffered T
   // and runs its launches in order; chains interleave on the GPU so that one
@@ -335,6 +357,9 @@ struct xcx_plan {
   bool prep_valid = false; unsigned long long pairs_count = 0;   // pair phases recorded in pairs_done[count & 1]
   const float* prep_traces = nullptr; int prep_S = 0, prep_W = 0; long prep_ss = 0, prep_sw = 0;
   size_t fused_err_off = 0;  // index of the error flag inside fsync
+#ifdef XCX_STAMPS
+  DevBuf stampbuf; size_t stamp_waves = 0;
+#endif
   unsigned long long gram_key = 0; int gram_ntiles = 0;
   // multi-call accumulation in gramC (xcx_cc1d_stack_add / _finish)
   unsigned long long acc_key = 0; int acc_count = 0, acc_S = 0, acc_P = 0; long long acc_windows = 0; long acc_ld = 0;
@@ -471,6 +496,12 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
       for (int i = 0; i < kNWFused; ++i)
         if (kWFused[i].N1 == g.N1 && kWFused[i].N2h == g.N2h) p->dual = &kWFused[i];
     if (const char* ce = getenv("XCX_CHAINS")) p->nchains = std::max(1, std::min(xcx_plan::kMaxChains, atoi(ce)));
+    {
+      // opt-in for now (XCX_FLOW=1): parity-green, within +-3 % of the per-batch launches
+      const char* fl = getenv("XCX_FLOW");
+      p->flow = p->dual && fl && strcmp(fl, "1") == 0;
+      if (const char* fr = getenv("XCX_FLOW_RING")) p->flow_R = std::max(kFlowLag + 1, std::min(64, atoi(fr)));
+    }
     if (!p->dual) p->nchains = 1;
     if (p->dual) {
       // batch so that the whole T ring (chains x 2 buffers) is ~144 MB: it then stays
@@ -527,6 +558,7 @@ extern "C" int xcx_plan_destroy(xcx_plan* p) {
   if (p->prep_done) (void)hipEventDestroy(p->prep_done);
   for (auto& e : p->pairs_done) if (e) (void)hipEventDestroy(e);
   p->spectra_next.release();
+  p->flow_sync.release();
   DevBuf* bufs[] = {&p->tw_N1, &p->tw_N2h, &p->tw_unt, &p->tw_N, &p->stats,
                     &p->Tm_f, &p->Tn_f, &p->spectra, &p->T, &p->descs,
                     &p->dtraces, &p->dout, &p->dpairs, &p->psum, &p->psq, &p->Tring, &p->fsync, &p->trash, &p->gramC, &p->gramTiles, &p->gramPidx};
@@ -821,6 +853,21 @@ static int dual_launch(xcx_plan* p, int chain, size_t d0, int Bc, int nstack, fl
   a.tw_N = (const cf*)p->tw_N.ptr;
   a.g = g;
   if (Bc == 0 && a.Br == 0) return XCX_OK;
+#ifdef XCX_STAMPS
+  {
+    // diagnostic build: the XCX_STAMP_LAUNCH-th dual launch (a steady-state one) records
+    // per-wave phase stamps; read back with xcx_debug_stamps()
+    static const long which = getenv("XCX_STAMP_LAUNCH") ? atol(getenv("XCX_STAMP_LAUNCH")) : 400;
+    a.stamps = nullptr;
+    if (p->launches == which) {
+      const size_t nw = (size_t)8 * 4 * 64 * (size_t)std::max(Bc, a.Br);     // generous upper bound of waves
+      if (p->stampbuf.ensure(p->ctx, nw * kNStamp * sizeof(unsigned long long))) return XCX_ENOMEM;
+      HIP_TRY(hipMemsetAsync(p->stampbuf.ptr, 0, nw * kNStamp * sizeof(unsigned long long), ch.stream));
+      a.stamps = (unsigned long long*)p->stampbuf.ptr;
+      p->stamp_waves = nw;
+    }
+  }
+#endif
   {
     ProfScope ps(p, KID_PAIR_FUSED, Bc > 0 ? Bc : a.Br, ch.stream);
     HIP_TRY(p->dual->dual(a, ch.stream));
@@ -868,6 +915,66 @@ static int dual_run(xcx_plan* p, size_t first, size_t count, int nstack, float* 
       HIP_TRY(hipStreamWaitEvent(ctx->stream, p->chains[c].done, 0));
     }
   }
+  return XCX_OK;
+}
+
+// the whole run [first, first+count) as ONE launch of the flow kernel (see wave_kernels.h)
+static int flow_run(xcx_plan* p, size_t first, size_t count, int nstack, float* out, const cf* Xsrc = nullptr) {
+  xcx_ctx* ctx = p->ctx;
+  const Geom& g = p->g;
+  int rc;
+  if ((rc = flow_check(ctx))) return rc;                     // a previous launch timed out?
+  const int B = p->batch, R = p->flow_R;
+  const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
+  const size_t tbytes = sizeof(cf) * tm_per * (size_t)B * R;
+  if (ctx->flow_T_bytes < tbytes) {
+    if (ctx->flow_T) { HIP_TRY(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->flow_T); ctx->flow_T = nullptr; ctx->flow_T_bytes = 0; }
+    // uncached: producers and consumers of T sit on different XCDs inside one launch
+    static const char* tm = getenv("XCX_FLOW_T");            // A/B only: "plain" is NOT coherent across XCDs
+    hipError_t e = (tm && strcmp(tm, "plain") == 0) ? hipMalloc(&ctx->flow_T, tbytes)
+                 : hipExtMallocWithFlags(&ctx->flow_T, tbytes, (tm && strcmp(tm, "fg") == 0) ? hipDeviceMallocFinegrained : hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); return set_err(XCX_ENOMEM, "uncached T ring of %zu bytes: %s", tbytes, hipGetErrorString(e)); }
+    ctx->flow_T_bytes = tbytes;
+  }
+  if (!ctx->flow_err_dev) {
+    HIP_TRY(hipMalloc((void**)&ctx->flow_err_dev, sizeof(int)));
+    HIP_TRY(hipHostMalloc((void**)&ctx->flow_err_host, sizeof(int), hipHostMallocDefault));
+    *ctx->flow_err_host = 0;
+    HIP_TRY(hipMemsetAsync(ctx->flow_err_dev, 0, sizeof(int), ctx->stream));
+  }
+  const int nbatch = (int)((count + B - 1) / B);
+  const size_t nsync = (size_t)(nbatch + 1) * 8 * kFlowShardInts;     // ints per counter array
+  if ((rc = p->flow_sync.ensure(ctx, sizeof(int) * 2 * nsync))) return rc;
+  HIP_TRY(hipMemsetAsync(p->flow_sync.ptr, 0, sizeof(int) * 2 * nsync, ctx->stream));
+  WFlowArgs a{};
+  a.X = Xsrc ? Xsrc : (const cf*)p->spectra.ptr;
+  a.spec_pitch = p->spec_pitch;
+  a.pw = (const PwDesc*)p->descs.ptr + first;
+  a.count = (int)count;
+  a.B = B; a.R = R;
+  a.nstack = nstack;
+  a.T = (cf*)ctx->flow_T;
+  a.out = out;
+  a.trash = (float*)p->trash.ptr;
+  a.cdone = (int*)p->flow_sync.ptr;
+  a.rdone = a.cdone + nsync;
+  a.err = ctx->flow_err_dev;
+  a.tw_N1 = (const cf*)p->tw_N1.ptr;
+  a.tw_N2h = (const cf*)p->tw_N2h.ptr;
+  a.tw_unt = (const cf*)p->tw_unt.ptr;
+  a.tw_N = (const cf*)p->tw_N.ptr;
+  a.g = g;
+  {
+    ProfScope phase(p, KID_PAIR_PHASE, (int)count);
+    ProfScope ps(p, KID_PAIR_FUSED, (int)count);
+    HIP_TRY(p->dual->flow(a, ctx->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(ctx->flow_err_host, ctx->flow_err_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  static const bool dbg_sync = getenv("XCX_FLOW_SYNC") != nullptr;     // debugging aid
+  if (dbg_sync) HIP_TRY(hipDeviceSynchronize());
+  ctx->flow_ran = true;
+  p->launches += 1;
+  p->pair_windows += (long long)count;
   return XCX_OK;
 }
 
@@ -1010,6 +1117,7 @@ static int stack_inverse(xcx_plan* p, int P, float* dout) {
   const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
   if ((rc = p->T.ensure(ctx, sizeof(cf) * tm_per * B * 2 * (p->dual ? p->nchains : 1)))) return rc;
   const cf* src = (const cf*)p->gramC.ptr;
+  if (p->flow) return flow_run(p, 0, (size_t)P, -1, dout, src);
   if (p->dual) return dual_run(p, 0, (size_t)P, -1, dout, src);
   for (size_t d0 = 0; d0 < (size_t)P; d0 += B)
     if ((rc = pair_batch(p, d0, (int)std::min((size_t)B, P - d0), dout, -1, src))) return rc;
@@ -1088,6 +1196,7 @@ extern "C" int xcx_cc1d_stack_finish(xcx_plan* p, const int* pairs, int P, float
     HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld_out * sizeof(float), dout, (size_t)ld_out * sizeof(float),
                              (size_t)L * sizeof(float), (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return flow_check(ctx);
   }
   return XCX_OK;
 }
@@ -1118,6 +1227,8 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
     if ((rc = p->dout.ensure(ctx, nrows * (size_t)ld_out * sizeof(float)))) return rc;
     dtr = (const float*)p->dtraces.ptr;
     dout = (float*)p->dout.ptr;
+    static const bool poison = getenv("XCX_POISON") != nullptr;       // debugging aid: unwritten lags read as NaN
+    if (poison) HIP_TRY(hipMemsetAsync(dout, 0xff, nrows * (size_t)ld_out * sizeof(float), ctx->stream));
   }
   // processing order: pairs grouped by 8x8 station tiles so that one launch
   // batch touches few distinct spectra (L2 / Infinity-Cache reuse)
@@ -1132,9 +1243,12 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
   if (!via_gram && (key != p->desc_key || p->hdescs.size() != ndesc)) {
     std::vector<int> perm(P);
     for (int i = 0; i < P; ++i) perm[i] = i;
+    // station-tile edge of the processing order: a launch batch should cover whole tiles
+    // (25 pair-windows = one 5 x 5 tile = 10 distinct station spectra)
+    static const int tile = getenv("XCX_TILE") ? std::max(1, atoi(getenv("XCX_TILE"))) : 8;
     std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
-      int ta = (pairs[2 * a] >> 3) * 8192 + (pairs[2 * a + 1] >> 3);
-      int tb = (pairs[2 * b] >> 3) * 8192 + (pairs[2 * b + 1] >> 3);
+      int ta = (pairs[2 * a] / tile) * 8192 + (pairs[2 * a + 1] / tile);
+      int tb = (pairs[2 * b] / tile) * 8192 + (pairs[2 * b + 1] / tile);
       return ta < tb;
     });
     p->hdescs.resize(ndesc);
@@ -1184,6 +1298,8 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
     }
     if (p->fused && ns > 0) {
       if ((rc = pair_fused(p, 0, P, dout, ns))) return rc;
+    } else if (p->flow) {
+      if ((rc = flow_run(p, 0, (size_t)P, ns, dout, src))) return rc;
     } else if (p->dual) {
       if ((rc = dual_run(p, 0, (size_t)P, ns, dout, src))) return rc;
     } else {
@@ -1203,6 +1319,8 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
     if (p->fused) {
       for (int w = 0; w < W; ++w)
         if ((rc = pair_fused(p, (size_t)w * P, P, dout, 1))) return rc;
+    } else if (p->flow) {
+      if ((rc = flow_run(p, 0, ndesc, 1, dout))) return rc;
     } else if (p->dual) {
       if ((rc = dual_run(p, 0, ndesc, 1, dout))) return rc;
     } else {
@@ -1216,6 +1334,8 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
       if ((rc = forward(p, dtr, stride_s, stride_w, 1, w, 0, S, 0))) return rc;
       if (p->fused) {
         if ((rc = pair_fused(p, (size_t)w * P, P, dout, 1))) return rc;
+      } else if (p->flow) {
+        if ((rc = flow_run(p, (size_t)w * P, (size_t)P, 1, dout))) return rc;
       } else if (p->dual) {
         if ((rc = dual_run(p, (size_t)w * P, (size_t)P, 1, dout))) return rc;
       } else {
@@ -1235,6 +1355,7 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
     HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld_out * sizeof(float), dout, (size_t)ld_out * sizeof(float),
                              (size_t)L * sizeof(float), nrows, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return flow_check(ctx);
   }
   return XCX_OK;
 }
@@ -1356,3 +1477,14 @@ int xcx_internal_spectra(xcx_plan* p, size_t slots) {
   return p->spectra.ensure(p->ctx, sizeof(cf) * p->spec_pitch * slots);
 }
 xcx_ctx* xcx_internal_ctx(xcx_plan* p) { return p->ctx; }
+
+#ifdef XCX_STAMPS
+// diagnostic build only (not part of include/xcx.h): copy the recorded phase stamps to the host
+extern "C" long xcx_debug_stamps(xcx_plan* p, unsigned long long* host, long max_waves) {
+  if (!p || !p->stampbuf.ptr) return 0;
+  (void)hipDeviceSynchronize();
+  const long n = (long)std::min<size_t>(p->stamp_waves, (size_t)max_waves);
+  if (hipMemcpy(host, p->stampbuf.ptr, (size_t)n * kNStamp * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return n;
+}
+#endif

@@ -32,4 +32,10 @@ struct xcx_ctx {
   unsigned long long sg_key = 0;
   xcx::DevBuf sos_tab;                   // cached transition-matrix powers of the chunked SOS scan
   unsigned long long sos_key = 0;
+  // flow pair kernel (one launch per pair phase, in-kernel batch dependencies): device error
+  // flag + pinned host mirror, checked by every synchronising entry point
+  void* flow_T = nullptr; size_t flow_T_bytes = 0;   // uncached T ring, shared by the context's plans (grow-only)
+  int* flow_err_dev = nullptr;
+  int* flow_err_host = nullptr;
+  bool flow_ran = false;
 };
