@@ -25,11 +25,10 @@ hipError_t XCX_CAT3(launch_wfused_, XCX_FC_L, _, XCX_FR_L)(const WFusedArgs& a, 
 }
 
 hipError_t XCX_CAT3(launch_wdual_, XCX_FC_L, _, XCX_FR_L)(const WDualArgs& a, hipStream_t s) {
-  constexpr size_t lc = lds_col_floats(RXC::L), lr = lds_row_floats(RXR::L);
-  constexpr size_t lds = sizeof(float) * (lc > lr ? lc : lr) * kWPB;
-  constexpr int CPX = (RXR::L + 1 + 7) / 8, RPX = 2 * (((RXC::L / kWRB + 1) / 2 + 7) / 8);
+  using PG = PairGeom<RXC, RXR>;
+  constexpr size_t lds = sizeof(float) * PG::kLdsFloats;
   const int Bm = a.Bc > a.Br ? a.Bc : a.Br;
-  const dim3 grid(8u * (((CPX + RPX) * Bm + kWPB - 1) / kWPB));
+  const dim3 grid(8u * (unsigned)((PG::CWX + PG::RWX) * Bm));
   // occupancy knob: pad the LDS request so that at most `wgs` workgroups share a CU
   static const int wgs = getenv("XCX_DUAL_WGS") ? atoi(getenv("XCX_DUAL_WGS")) : 0;
   size_t lds_req = lds;
@@ -50,11 +49,10 @@ hipError_t XCX_CAT3(launch_wdual_, XCX_FC_L, _, XCX_FR_L)(const WDualArgs& a, hi
 }
 
 hipError_t XCX_CAT3(launch_wflow_, XCX_FC_L, _, XCX_FR_L)(const WFlowArgs& a, hipStream_t s) {
-  constexpr size_t lc = lds_col_floats(RXC::L), lr = lds_row_floats(RXR::L);
-  constexpr size_t lds = sizeof(float) * (lc > lr ? lc : lr) * kWPB;
-  constexpr int CPX = (RXR::L + 1 + 7) / 8, RPX = 2 * (((RXC::L / kWRB + 1) / 2 + 7) / 8);
+  using PG = PairGeom<RXC, RXR>;
+  constexpr size_t lds = sizeof(float) * PG::kLdsFloats;
   const int nbatch = (a.count + a.B - 1) / a.B;
-  const long wpg = ((long)(CPX + RPX) * a.B + kWPB - 1) / kWPB;
+  const long wpg = (long)(PG::CWX + PG::RWX) * a.B;
   const long nwg = 8L * wpg * (nbatch + kFlowLag);           // trailing groups: rows of the last batches
   if (nwg > 0x7fffffffL) return hipErrorInvalidValue;
   const dim3 grid((unsigned)nwg);

@@ -16,9 +16,10 @@
 // Layouts (all chosen so that every global access of a wave instruction is a
 // run of full 128-byte lines):
 //   Tf / X : [k2 in 0..N2h][N1]        column-major, Nyquist = column N2h
-//   T      : [res >> 4][k2 in 0..N2h][res & 15]   16-row tiles, where
+//   T      : [res >> 6][k2 in 0..N2h][res & 63]   64-row tiles, where
 //            res = (m1 + shift) mod N1 is the OUTPUT residue of row m1
-//            (slots k2 = 0 and N2h are real: only .x is consumed)
+//            (slots k2 = 0 and N2h are real: only .x is consumed); a row wave
+//            owns the 16-row quarter (res >> 4) & 3 of a tile
 //
 // The C2R row kernel reads each T element exactly once: butterflies j and
 // S-j of its first stage are computed by the same lane, which therefore holds
@@ -66,6 +67,9 @@ XCX_DEV unsigned long long stamp_nowait(float pin) {
 #define XCX_ROW_WAVES 1
 #endif
 constexpr int kWRB = 16;     // rows per wave
+constexpr int kTR = 64;      // rows per T tile: T = [res >> 6][k2 in 0..N2h][res & 63]; a column wave (one k2)
+                             // stores 64 consecutive residues = 512 contiguous bytes per instruction, and the four
+                             // row waves of a workgroup read the four 16-row quarters of one tile
 constexpr int kWNT = 64;     // one wave
 constexpr int kWPB = 4;      // independent waves packed into one 256-thread workgroup
 
@@ -78,6 +82,13 @@ constexpr int lds_frow_floats(int L) { return L * 16 * 2; }
 // s_load (scalar cache) and the data loads take the saddr + 32-bit voffset form instead of
 // per-lane 64-bit addresses
 XCX_DEV int wave_in_group() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
+// the 16-row quarter `blk & 3` of T tile `blk >> 2` of one pair-window
+XCX_DEV const cf* t_quarter(const cf* __restrict__ Tpw, int blk, int N2h) {
+  return Tpw + (size_t)((blk >> 2) * (N2h + 1)) * kTR + (blk & 3) * kWRB;
+}
+// staging buffer of the workgroup-cooperative CCF store: (N2h + 1) lag blocks x 64 rows of float
+constexpr int lds_stage_floats(int N2h) { return (N2h + 1) * kTR; }
 
 // LDS index of column kernels: one 8-byte pad slot every 8 positions makes the
 // stride-R stores of the first Stockham stage bank-conflict free
@@ -99,8 +110,15 @@ template <class RX> struct ColGeom {
   using Last = StageGeom<L, RL, NSL, 1, kWNT>;
 };
 
+// `ltid`: lane -> butterfly slot of the LAST stage (default: the lane itself).  Any permutation
+// within 0..63 is valid when that stage has a multiple of 64 butterflies: its inputs come out of
+// LDS by position, so only the stage's own indexing has to follow.
+template <class RX> struct ColRot {
+  using CG = ColGeom<RX>;
+  static constexpr bool ok = (CG::Last::NBF % kWNT == 0) && (CG::NSL % kTR == 0);
+};
 template <class RX, bool INV, class In, class Epi>
-XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in, Epi epi XCX_ST_PARAM) {
+XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in, Epi epi, int ltid XCX_ST_PARAM) {
   constexpr int L = RX::L;
   constexpr int R0 = RX::R0, R1 = RX::R1, R2 = RX::R2;
   static_assert(RX::S == 2 || RX::S == 3, "column configs have two or three stages");
@@ -108,7 +126,7 @@ XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in
   using G0 = StageGeom<L, R0, 1, 1, kWNT>;
   using G1 = StageGeom<L, R1, R0, 1, kWNT>;
   cf b1[G1::IT];
-  stage_tw_base<L, R1, R0, 1, kWNT>(tw, b1);
+  stage_tw_base<L, R1, R0, 1, kWNT>(tw, b1, RX::S == 2 ? ltid : tid_of<kWNT>());
   cf v0[G0::IT][R0];
 #ifdef XCX_STAMPS
 #pragma unroll
@@ -139,11 +157,11 @@ XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in
 #endif
   cf v1[G1::IT][R1];
   if constexpr (RX::S == 2) {
-    stage_exchange_pad8<L, R0, 1, R1, kWNT>(ldsf, v0, v1);
+    stage_exchange_pad8<L, R0, 1, R1, kWNT>(ldsf, v0, v1, ltid);
     stage_compute<L, R1, R0, 1, kWNT, INV>(v1, b1);
 #pragma unroll
     for (int it = 0; it < G1::IT; ++it) {
-      const int j = tid_of<kWNT>() + it * kWNT;
+      const int j = ltid + it * kWNT;
       if (!G1::GUARD || j < G1::NBF) {
         const int k = j % R0;
         epi(it, (j - k) * R1 + k, 0, v1[it]);
@@ -152,19 +170,19 @@ XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in
   } else {
     using G2 = StageGeom<L, R2, R0 * R1, 1, kWNT>;
     cf b2[G2::IT];
-    stage_tw_base<L, R2, R0 * R1, 1, kWNT>(tw, b2);
+    stage_tw_base<L, R2, R0 * R1, 1, kWNT>(tw, b2, ltid);
     stage_exchange_pad8<L, R0, 1, R1, kWNT>(ldsf, v0, v1);
     XCX_STAMP(3, v1[G1::IT - 1][R1 - 1].y);
     stage_compute<L, R1, R0, 1, kWNT, INV>(v1, b1);
     XCX_STAMP(4, v1[G1::IT - 1][R1 - 1].y);
     cf v2[G2::IT][R2];
-    stage_exchange_pad8<L, R1, R0, R2, kWNT>(ldsf, v1, v2);
+    stage_exchange_pad8<L, R1, R0, R2, kWNT>(ldsf, v1, v2, ltid);
     XCX_STAMP(5, v2[G2::IT - 1][R2 - 1].y);
     stage_compute<L, R2, R0 * R1, 1, kWNT, INV>(v2, b2);
     XCX_STAMP(6, v2[G2::IT - 1][R2 - 1].y);
 #pragma unroll
     for (int it = 0; it < G2::IT; ++it) {
-      const int j = tid_of<kWNT>() + it * kWNT;
+      const int j = ltid + it * kWNT;
       if (!G2::GUARD || j < G2::NBF) {
         const int k = j % (R0 * R1);
         epi(it, (j - k) * R2 + k, 0, v2[it]);
@@ -340,7 +358,7 @@ void k_wfwd_cols(WF2Args a) {
 #ifdef XCX_STAMPS
   StampArr xst;
 #endif
-  wave_col_fft<RX, false>(lds, a.tw_sub, in, epi XCX_ST_ARG);
+  wave_col_fft<RX, false>(lds, a.tw_sub, in, epi, tid_of<kWNT>() XCX_ST_ARG);
 }
 
 // ---------------------------------------------------------------------------
@@ -375,16 +393,23 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
   using CG = ColGeom<RX>;
   // four-step factors w_N^{-(j0 + t*NSL) k2}: base per (lane, iteration) and
   // the wave-uniform step g = w_N^{-NSL k2}; powers by multiplication
+  // last-stage slots rotated so that lane l holds the residues res = l (mod 64): every T store
+  // instruction then writes ONE aligned 512-byte run of a 64-row tile (four whole lines) instead
+  // of the tail of one tile and the head of the next
+  const int ltid = ColRot<RX>::ok ? ((tid_of<kWNT>() - shift) & (kWNT - 1)) : tid_of<kWNT>();
   cf f0[CG::Last::IT];
 #pragma unroll
   for (int it = 0; it < CG::Last::IT; ++it) {
-    const int b = tid_of<kWNT>() + it * kWNT;
+    const int b = ltid + it * kWNT;
     const int j = (CG::Last::GUARD && b >= CG::Last::NBF) ? 0 : b;
     const int k = j % CG::NSL;
     f0[it] = twN_lookup(twN, (unsigned)((j - k) * CG::RL + k) * kk);
   }
   const cf gstep = twN_lookup(twN, (unsigned)CG::NSL * kk);
   auto in = [=](int k1, int) -> cf {
+#ifdef XCX_SKIP_XLD
+    k1 &= 15;                                    // ablation: every load hits the same 128 bytes
+#endif
     if constexpr (MODE == 2) {
       return *uoff(A, (unsigned)k1);
     } else {
@@ -396,36 +421,39 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
       return acc;
     }
   };
-  cf* __restrict__ Tc = T + k2 * kWRB;
-  const int trow = (N2h + 1) * kWRB;          // float2 per 16-row tile
+  cf* __restrict__ Tc = T + k2 * kTR;
+  const int trow = (N2h + 1) * kTR;           // float2 per 64-row tile
   auto epi = [=](int it, int j0, int, cf (&v)[CG::RL]) {
     cf g8 = gstep, f = f0[it];
     if constexpr (CG::RL > 8) g8 = csq(csq(csq(gstep)));
     int res0 = j0 + shift;
     if (res0 >= N1) res0 -= N1;
-    const unsigned off0 = (unsigned)((res0 >> 4) * trow + (res0 & 15));
+    const unsigned off0 = (unsigned)((res0 >> 6) * trow + (res0 & 63));
     const int twrap = (N1 - res0 + CG::NSL - 1) / CG::NSL;            // first t whose residue wraps
-    const unsigned wrapsz = (unsigned)(N1 / kWRB) * (unsigned)trow;
+    const unsigned wrapsz = (unsigned)(N1 / kTR) * (unsigned)trow;
     static_for<CG::RL>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
       if constexpr (t > 0) {
         if constexpr (t % 8 == 0) { f = f0[it]; static_for<t / 8>([&](auto) { f = cmul(f, g8); }); }
         else f = cmul(f, gstep);
       }
-      // res = (j0 + shift + t NSL) mod N1; with NSL a multiple of 16 the tile offset advances by a
+      // res = (j0 + shift + t NSL) mod N1; with NSL a multiple of 64 the tile offset advances by a
       // constant per t and wraps once: offset = off0 + t dstep - (t >= twrap ? wrapsz : 0)
-      if constexpr (CG::NSL % kWRB == 0) {
-        constexpr unsigned dstep = (unsigned)(CG::NSL / kWRB);
+      if constexpr (CG::NSL % kTR == 0) {
+        constexpr unsigned dstep = (unsigned)(CG::NSL / kTR);
         const unsigned o = off0 + (unsigned)t * dstep * (unsigned)trow - ((t >= twrap) ? wrapsz : 0u);
+#ifdef XCX_SKIP_TST
+        if (N2h == -1)                             // ablation: never true at run time
+#endif
         *uoff(Tc, o) = cmulc(v[t], f);
       } else {
         int res = j0 + t * CG::NSL + shift;
         if (res >= N1) res -= N1;
-        *uoff(Tc, (unsigned)((res >> 4) * trow + (res & 15))) = cmulc(v[t], f);
+        *uoff(Tc, (unsigned)((res >> 6) * trow + (res & 63))) = cmulc(v[t], f);
       }
     });
   };
-  wave_col_fft<RX, true>(lds, tw_sub, in, epi XCX_ST_ARG);
+  wave_col_fft<RX, true>(lds, tw_sub, in, epi, ltid XCX_ST_ARG);
   XCX_STAMP_NW(7, gstep.x);                          // T stores issued
   XCX_STAMP(8, gstep.x);                             // ... and acknowledged
 }
@@ -463,6 +491,9 @@ struct WI2Args {
 // T loads of the row body: plain, or sc1 (L1 bypass, served by the XCD's L2)
 // when the producer ran in the same launch on the same XCD (fused kernel)
 template <bool SC1> XCX_DEV cf load_t(const cf* p) {
+#ifdef XCX_SKIP_TLD
+  p = reinterpret_cast<const cf*>(reinterpret_cast<unsigned long long>(p) & ~0xfffffULL);   // ablation: one hot line per MB
+#endif
 #ifdef XCX_T_NT_LOAD
   if constexpr (!SC1) {
     const unsigned long long u = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(p));
@@ -483,10 +514,18 @@ template <bool SC1> XCX_DEV cf load_t(const cf* p) {
 #ifndef XCX_BUFSTORE
 #define XCX_BUFSTORE 1
 #endif
-template <class RX, bool SC1, bool UNBIAS>
+// COOP: the four waves of the workgroup own the four quarters of ONE 64-row tile (blk = 4 wgblk +
+// wave) of one pair-window and store the CCF together: every wave parks its 16 x 2 N2h values in
+// the workgroup's LDS as [lag block][64 rows], and the workgroup then writes 16 bytes per lane,
+// 256 contiguous bytes per lag block (four blocks per wave instruction).  A wave alone can only
+// ever write 64-byte runs (16 rows x 4 bytes, the next run N1 floats away): measured on the same
+// traffic mix (tools/micro/fabric2.hip) 4-byte segmented stores cap the pass at 1.12 M
+// pair-windows/s, 16-byte 256-byte runs at 1.57 M.  `stg` = workgroup-wide staging buffer
+// (lds_stage_floats(N2h) floats, may alias the waves' exchange buffers); contains __syncthreads().
+template <class RX, bool SC1, bool UNBIAS, bool COOP = false>
 XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, float* __restrict__ out, int blk,
                            const cf* __restrict__ tw_sub, const cf* __restrict__ twu, float* __restrict__ trash,
-                           const Geom& g XCX_ST_PARAM) {
+                           float* __restrict__ stg, const Geom& g XCX_ST_PARAM) {
   constexpr int N2h = RX::L;
   constexpr int R = RX::R0;
   constexpr int S = N2h / R;
@@ -510,10 +549,10 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
     const int jp = (j == 0) ? 0 : (S - j);
     const bool single = jp == j;
 #pragma unroll
-    for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(uoff(Tt, (unsigned)((j + S * t) * kWRB + r)));
+    for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(uoff(Tt, (unsigned)((j + S * t) * kTR + r)));
     if (!single) {
 #pragma unroll
-      for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(uoff(Tt, (unsigned)((jp + S * t) * kWRB + r)));
+      for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(uoff(Tt, (unsigned)((jp + S * t) * kTR + r)));
     } else if (j == 0) {
 #pragma unroll
       for (int t = 0; t < R; ++t) bv[t] = av[(t + 1) % R];   // mirror of S*t' is S*(R-t')
@@ -545,7 +584,7 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
       ujp[R - 1 - t] = make_float2(sm.x + ed.y, ed.x - sm.y);
     });
     if (j == 0) {                                  // DC and Nyquist of the row are real
-      const float dc = av[0].x, ny = load_t<SC1>(uoff(Tt, (unsigned)(N2h * kWRB + r))).x;
+      const float dc = av[0].x, ny = load_t<SC1>(uoff(Tt, (unsigned)(N2h * kTR + r))).x;
       uj[0] = make_float2(dc + ny, dc - ny);
     }
     Bfly<R, true>::run(uj);
@@ -576,10 +615,10 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
     const bool single = jp == j;
     cf av[R], bv[R];
 #pragma unroll
-    for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(uoff(Tt, (unsigned)((j + S * t) * kWRB + r)));
+    for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(uoff(Tt, (unsigned)((j + S * t) * kTR + r)));
     if (!single) {
 #pragma unroll
-      for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(uoff(Tt, (unsigned)((jp + S * t) * kWRB + r)));
+      for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(uoff(Tt, (unsigned)((jp + S * t) * kTR + r)));
     } else if (j == 0) {
 #pragma unroll
       for (int t = 0; t < R; ++t) bv[t] = av[(t + 1) % R];   // mirror of S*t' is S*(R-t')
@@ -603,7 +642,7 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
       ujp[R - 1 - t] = make_float2(sm.x + ed.y, ed.x - sm.y);
     });
     if (j == 0) {                                  // DC and Nyquist of the row are real
-      const float dc = av[0].x, ny = load_t<SC1>(uoff(Tt, (unsigned)(N2h * kWRB + r))).x;
+      const float dc = av[0].x, ny = load_t<SC1>(uoff(Tt, (unsigned)(N2h * kTR + r))).x;
       uj[0] = make_float2(dc + ny, dc - ny);
     }
     Bfly<R, true>::run(uj);
@@ -617,6 +656,16 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
   float* __restrict__ ldsf = reinterpret_cast<float*>(lds);
   using G1 = StageGeom<N2h, RX::R1, RX::R0, kWRB, kWNT>;
   cf v1[G1::IT][RX::R1];
+#ifdef XCX_ABLATE_MATH
+#pragma unroll
+  for (int it = 0; it < G1::IT; ++it)
+#pragma unroll
+    for (int t = 0; t < RX::R1; ++t) {
+      const int e = it * RX::R1 + t;
+      v1[it][t] = (e & 1) ? s0b[(e / 2 / R) % IT][(e / 2) % R] : s0a[(e / 2 / R) % IT][(e / 2) % R];
+    }
+  (void)ldsf;
+#else
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -657,6 +706,7 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
     }
     group_sync<kWNT>();
   }
+#endif
   XCX_STAMP(3, v1[G1::IT - 1][RX::R1 - 1].y);
   stage_compute<N2h, RX::R1, RX::R0, kWRB, kWNT, true>(v1, b1);
   XCX_STAMP(4, v1[G1::IT - 1][RX::R1 - 1].y);
@@ -683,6 +733,86 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out_u, 0, (int)(Lout * 4u), 0x00020000);
 #else
   float* __restrict__ trash_l = trash + lane;
+#endif
+#if XCX_BUFSTORE
+  if constexpr (COOP) {
+    // Row res = 16 blk + c of the tile holds, for kk = 2 m + h, the lag o = res + N1 (kk + wr + q0)
+    // (before the circular wrap), wr = 1 for the rows whose m1 + shift passed N1 (res < shift),
+    // q0 = floor((n - 1 - idx_min) / N1).  Lag block s = kk + wr is therefore common to all 64 rows.
+    // Two passes (kk < N2h, then the rest) keep the staging buffer at (N2h + 1) x 64 floats.
+    constexpr int KH = N2h;
+    const int c = lane & 15;
+    const int res_l = blk * kWRB + c;
+    const int wr = (res_l < shift) ? 1 : 0;
+    const int q0 = ((n - 1 - idx_min) - shift) / N1;          // exact: shift = (n - 1 - idx_min) mod N1
+    const int col = (blk & 3) * kWRB + c;                      // row inside the tile
+    const int res0 = (blk >> 2) * kTR;                         // first residue of the tile
+    const int tid = (int)threadIdx.x;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();                                         // exchange buffers / previous pass drained
+#pragma unroll
+      for (int it = 0; it < G1::IT; ++it) {
+        const int b = lane + it * kWNT;
+        if (!G1::GUARD || b < G1::NBF) {
+          const int j = b / kWRB;
+          const int k = j % RX::R0;
+          const int j0 = (j - k) * RX::R1 + k;
+#pragma unroll
+          for (int t = 0; t < RX::R1; ++t) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const int kk = 2 * (j0 + t * RX::R0) + h;
+              if ((kk >= KH) == (half == 1)) {
+                float v = h ? v1[it][t].y : v1[it][t].x;
+                if constexpr (UNBIAS) {
+                  int o = res_l + N1 * (kk + wr + q0);
+                  if (o >= N - idx_min) o -= N;
+                  int lag = o + idx_min - (n - 1);
+                  lag = lag < 0 ? -lag : lag;
+                  v *= (float)n / (float)(n - lag);
+                }
+                stg[(kk + wr - half * KH) * kTR + col] = v;
+              }
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // lag blocks s = half KH .. half KH + KH of this pass; 16 float4 groups per block
+      for (int i = tid; i < (KH + 1) * (kTR / 4); i += kWNT * kWPB) {
+        const int sl = i >> 4, gq = i & 15;
+        const int s = sl + half * KH;
+#ifdef XCX_SKIP_CCF
+        if (n != -1) continue;                     // ablation: always true at run time
+#endif
+        const float4 v = *reinterpret_cast<const float4*>(stg + sl * kTR + 4 * gq);
+        const int r0 = res0 + 4 * gq;                          // residues r0 .. r0 + 3
+        int o = r0 + N1 * (s + q0);
+        if (o >= N - idx_min) o -= N;                          // N, N1, r0 are multiples of 4: never splits a group
+        // element e is real data iff its row has kk = s - wr_e inside this pass, and retained iff
+        // 0 <= o + e < Lout
+        const int wr0 = (r0 < shift) ? 1 : 0, wr3 = (r0 + 3 < shift) ? 1 : 0;
+        const bool uniform = wr0 == wr3 && (s - wr0) >= half * KH && (s - wr0) < (half + 1) * KH;
+        if (uniform && o >= 0 && (unsigned)(o + 3) < Lout) {
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 w4 = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+          __builtin_amdgcn_raw_buffer_store_b128(w4, rsrc, o * 4, 0, /*nt*/ 2);
+        } else {
+          const float ve[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int kk = s - ((r0 + e < shift) ? 1 : 0);
+            if (kk >= half * KH && kk < (half + 1) * KH)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ve[e]), rsrc, (o + e) * 4, 0, /*nt*/ 2);   // range-checked
+          }
+        }
+      }
+    }
+    XCX_STAMP_NW(7, v1[0][0].x);
+    XCX_STAMP(8, v1[0][0].x);
+    return;
+  }
 #endif
   auto out_f = [=](int m, int, cf u) {
 #pragma unroll
@@ -752,15 +882,17 @@ void k_wpair_rows(WI2Args a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   const Geom g = a.g;
   cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave_in_group() * lds_row_floats(RX::L));
+  // the four waves of a workgroup = the four quarters of one 64-row tile (cooperative CCF store)
   const int pwl = blockIdx.y, blk = blockIdx.x * kWPB + wave_in_group();
-  const cf* __restrict__ Tt = a.T + ((size_t)pwl * (g.N1 / kWRB) + blk) * (size_t)(RX::L + 1) * kWRB;
+  const cf* __restrict__ Tt = t_quarter(a.T + (size_t)pwl * g.N1 * (RX::L + 1), blk, RX::L);
+  float* stg = reinterpret_cast<float*>(lds_all);
 #ifdef XCX_STAMPS
   StampArr xst;
 #endif
   if (g.flags & XCX_F_UNBIAS)
-    pair_row_body<RX, false, true>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, a.trash, g XCX_ST_ARG);
+    pair_row_body<RX, false, true, true>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, a.trash, stg, g XCX_ST_ARG);
   else
-    pair_row_body<RX, false, false>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, a.trash, g XCX_ST_ARG);
+    pair_row_body<RX, false, false, true>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, a.trash, stg, g XCX_ST_ARG);
 }
 
 // ---------------------------------------------------------------------------
@@ -857,11 +989,11 @@ __global__ __launch_bounds__(kWNT * kWPB) void k_wpair_fused(WFusedArgs a) {
     } else {
       spin_until(a.cdone + pw, NC, a.err);
       if (g.flags & XCX_F_UNBIAS)
-        pair_row_body<RXR, true, true>(lds, T + (size_t)sub * NC * kWRB, a.out + a.pw[pw].out_off, sub,
-                                       a.tw_N2h, a.tw_unt, a.trash, g XCX_ST_ARG);
+        pair_row_body<RXR, true, true>(lds, t_quarter(T, sub, N2h), a.out + a.pw[pw].out_off, sub,
+                                       a.tw_N2h, a.tw_unt, a.trash, nullptr, g XCX_ST_ARG);
       else
-        pair_row_body<RXR, true, false>(lds, T + (size_t)sub * NC * kWRB, a.out + a.pw[pw].out_off, sub,
-                                        a.tw_N2h, a.tw_unt, a.trash, g XCX_ST_ARG);
+        pair_row_body<RXR, true, false>(lds, t_quarter(T, sub, N2h), a.out + a.pw[pw].out_off, sub,
+                                        a.tw_N2h, a.tw_unt, a.trash, nullptr, g XCX_ST_ARG);
       // all T loads of this wave have returned (their values were consumed)
       if (tid_of<kWNT>() == 0) __hip_atomic_fetch_add(a.rdone + pw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -887,33 +1019,46 @@ struct WDualArgs {
 #endif
 };
 
-// amdgpu_waves_per_eu(3,3): same 128 VGPRs / 4 waves per SIMD at run time, but
-// the scheduler then orders for latency instead of register pressure (+14 %)
+// amdgpu_waves_per_eu(4,4): the pair pass is bound by memory latency x occupancy (the arithmetic
+// is hidden: a build without butterflies runs only 8 % faster), so the fourth wave per SIMD counts
+// for more than a spill-free allocation: 128 VGPRs with 12 bytes of scratch measured +1.6 % over
+// 137 VGPRs / 3 waves, and 3 waves forced by LDS padding (XCX_DUAL_WGS=3) -10 %.
 #ifndef XCX_DUAL_WAVES
-#define XCX_DUAL_WAVES 3
+#define XCX_DUAL_WAVES 4
 #endif
+// work decomposition shared by the dual and flow kernels: per XCD and pair-window
+//   CWX column workgroups (four columns k2 = x mod 8 each; consecutive items = the same column
+//       of consecutive pair-windows, so a station column stays in that XCD's L2), and
+//   RWX row workgroups (one 64-row tile each: cooperative CCF store),
+// interleaved CWX : RWX (4 : 3 at N1 = 1536, N2h = 120) so that VALU-heavy column waves and
+// store-heavy row waves share every CU.
+template <class RXC, class RXR> struct PairGeom {
+  static constexpr int N1 = RXC::L, N2h = RXR::L;
+  static constexpr int NR = N1 / kWRB;                 // 16-row quarters per pair-window
+  static constexpr int NRW = N1 / kTR;                 // row workgroups (tiles) per pair-window
+  static constexpr int CPX = (N2h + 1 + 7) / 8;        // columns per XCD
+  static constexpr int CWX = (CPX + kWPB - 1) / kWPB;  // column workgroups per XCD and pair-window
+  static constexpr int RWX = (NRW + 7) / 8;            // row workgroups per XCD and pair-window
+  static constexpr int kPerWave = lds_col_floats(N1) > lds_row_floats(N2h) ? lds_col_floats(N1) : lds_row_floats(N2h);
+  static constexpr int kLdsFloats = kPerWave * kWPB > lds_stage_floats(N2h) ? kPerWave * kWPB : lds_stage_floats(N2h);
+  static_assert(N1 % kTR == 0, "column lengths are multiples of 64");
+};
+
 template <class RXC, class RXR, int MODE>
 __global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(XCX_DUAL_WAVES, XCX_DUAL_WAVES)))
 void k_wpair_dual(WDualArgs a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   const Geom g = a.g;
-  constexpr int N1 = RXC::L;
-  constexpr int N2h = RXR::L;
-  constexpr int NR = N1 / kWRB;            // row waves per pair-window
-  constexpr int CPX = (N2h + 1 + 7) / 8;   // column slots per XCD
-  constexpr int RPX = 2 * (((NR + 1) / 2 + 7) / 8);   // row slots per XCD and pair-window (tile pairs)
-  constexpr int kPerWave = lds_col_floats(N1) > lds_row_floats(N2h) ? lds_col_floats(N1) : lds_row_floats(N2h);
-  cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave_in_group() * kPerWave);
+  using PG = PairGeom<RXC, RXR>;
+  constexpr int N1 = PG::N1, N2h = PG::N2h;
+  const int wave = wave_in_group();
+  cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave * PG::kPerWave);
   const int x = blockIdx.x & 7;
-  const int q = (blockIdx.x >> 3) * kWPB + wave_in_group();
+  const int wgq = (int)(blockIdx.x >> 3);
   const int Bm = a.Bc > a.Br ? a.Bc : a.Br;
-  // per-XCD work sequence: CPX*Bm column items (column-major: all pair-windows
-  // of one column k2 back to back, so a station column stays in this XCD's L2
-  // for the 8 pairs of its tile) interleaved CPX:RPX with RPX*Bm row items.
-  // (A persistent-wave loop over this sequence was tried: the loop-carried
-  // state pushes the kernel into scratch spills and it runs 4x slower.)
-  const int grp = q / (CPX + RPX), pos = q % (CPX + RPX);
+  const int grp = wgq / (PG::CWX + PG::RWX), pos = wgq % (PG::CWX + PG::RWX);
 #ifdef XCX_STAMPS
+  const int q = (int)blockIdx.x * kWPB + wave;
   StampArr xst;
   for (int i = 0; i < kNStamp; ++i) xst[i] = 0;
   xst[0] = stamp_nowait(0.f);
@@ -928,29 +1073,27 @@ void k_wpair_dual(WDualArgs a) {
       t[11] = __builtin_amdgcn_s_memrealtime();
       for (int i = 0; i < kNStamp; ++i) dst[(size_t)q * kNStamp + i] = t[i];
     }
-  } stamp_out{xst, a.stamps, q, pos < CPX ? 1 : 2};
+  } stamp_out{xst, a.stamps, q, pos < PG::CWX ? 1 : 2};
 #endif
-  if (pos < CPX) {
-    const int ci = grp * CPX + pos;
+  if (pos < PG::CWX) {
+    const int ci = (grp * PG::CWX + pos) * kWPB + wave;
     const int k2 = (ci / Bm) * 8 + x;
     const int pwl = ci % Bm;
     if (k2 > N2h || pwl >= a.Bc) return;
     pair_col_body<RXC, MODE>(lds, a.X, a.spec_pitch, a.pw_c[pwl], a.nstack, k2,
                               a.Tc + (size_t)pwl * N1 * (N2h + 1), a.tw_N1, a.tw_N, g XCX_ST_ARG);
   } else {
-    // adjacent 16-row tiles (2bp, 2bp+1) are consecutive items of the SAME XCD:
-    // the two 64-byte halves of every 128-byte output line are written from one
-    // XCD within microseconds of each other and merge in its L2
-    const int ri = grp * RPX + (pos - CPX);
-    const int pwl = ri / RPX;
-    const int rr = ri % RPX;
-    const int blk = 2 * ((rr >> 1) * 8 + x) + (rr & 1);
-    if (blk >= NR || pwl >= a.Br) return;
-    const cf* __restrict__ Tt = a.Tr + ((size_t)pwl * NR + blk) * (size_t)(N2h + 1) * kWRB;
+    const int ri = grp * PG::RWX + (pos - PG::CWX);
+    const int pwl = ri / PG::RWX;
+    const int wgblk = (ri % PG::RWX) * 8 + x;
+    if (wgblk >= PG::NRW || pwl >= a.Br) return;             // workgroup-uniform
+    const int blk = wgblk * kWPB + wave;
+    const cf* __restrict__ Tt = t_quarter(a.Tr + (size_t)pwl * N1 * (N2h + 1), blk, N2h);
+    float* stg = reinterpret_cast<float*>(lds_all);
     if (g.flags & XCX_F_UNBIAS)
-      pair_row_body<RXR, false, true>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, a.trash, g XCX_ST_ARG);
+      pair_row_body<RXR, false, true, true>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, a.trash, stg, g XCX_ST_ARG);
     else
-      pair_row_body<RXR, false, false>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, a.trash, g XCX_ST_ARG);
+      pair_row_body<RXR, false, false, true>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, a.trash, stg, g XCX_ST_ARG);
   }
 }
 
@@ -1022,35 +1165,31 @@ __global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(XCX
 void k_wpair_flow(WFlowArgs a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   const Geom g = a.g;
-  constexpr int N1 = RXC::L;
-  constexpr int N2h = RXR::L;
-  constexpr int NR = N1 / kWRB;
-  constexpr int CPX = (N2h + 1 + 7) / 8;
-  constexpr int RPX = 2 * (((NR + 1) / 2 + 7) / 8);
-  constexpr int kPerWave = lds_col_floats(N1) > lds_row_floats(N2h) ? lds_col_floats(N1) : lds_row_floats(N2h);
-  cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave_in_group() * kPerWave);
+  using PG = PairGeom<RXC, RXR>;
+  constexpr int N1 = PG::N1, N2h = PG::N2h;
+  const int wave = wave_in_group();
+  cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave * PG::kPerWave);
   const int B = a.B;
   const int x = blockIdx.x & 7;
-  const int wpg = ((CPX + RPX) * B + kWPB - 1) / kWPB;       // workgroups per (group, XCD)
+  const int wpg = (PG::CWX + PG::RWX) * B;                   // workgroups per (group, XCD)
   const int wg = (int)(blockIdx.x >> 3);
   const int grp_b = wg / wpg;                                 // group = batch index of the column items
-  const int q = (wg - grp_b * wpg) * kWPB + wave_in_group();
+  const int wgq = wg - grp_b * wpg;
   const int nbatch = (a.count + B - 1) / B;
-  const int grp = q / (CPX + RPX), pos = q % (CPX + RPX);
+  const int grp = wgq / (PG::CWX + PG::RWX), pos = wgq % (PG::CWX + PG::RWX);
   const int lane = tid_of<kWNT>();
-  // per-shard item counts of one pair-window (lane l < 8 holds shard l's)
-  const int ncx = (lane <= N2h) ? (N2h - lane) / 8 + 1 : 0;          // columns k2 = l, l+8, ...
-  int nrx = 0;
-#pragma unroll
-  for (int rr = 0; rr < RPX; ++rr) nrx += (2 * ((rr >> 1) * 8 + lane) + (rr & 1) < NR) ? 1 : 0;
+  // per-shard item counts of one pair-window (lane l < 8 holds shard l's): column waves with
+  // k2 = l mod 8, row waves of the tiles l mod 8
+  const int ncx = (lane <= N2h) ? (N2h - lane) / 8 + 1 : 0;
+  const int nrx = (lane < PG::NRW) ? ((PG::NRW - 1 - lane) / 8 + 1) * kWPB : 0;
 #ifdef XCX_STAMPS
   StampArr xst;
 #endif
-  if (pos < CPX) {
+  if (pos < PG::CWX) {
     const int b = grp_b;
     if (b >= nbatch) return;
     const int Bc = min(B, a.count - b * B);
-    const int ci = grp * CPX + pos;
+    const int ci = (grp * PG::CWX + pos) * kWPB + wave;
     const int k2 = (ci / B) * 8 + x;
     const int pwl = ci % B;
     if (k2 > N2h || pwl >= Bc) return;
@@ -1068,18 +1207,21 @@ void k_wpair_flow(WFlowArgs a) {
     const int b = grp_b - kFlowLag;
     if (b < 0 || b >= nbatch) return;
     const int Br = min(B, a.count - b * B);
-    const int ri = grp * RPX + (pos - CPX);
-    const int pwl = ri / RPX;
-    const int rr = ri % RPX;
-    const int blk = 2 * ((rr >> 1) * 8 + x) + (rr & 1);
-    if (blk >= NR || pwl >= Br) return;
+    const int ri = grp * PG::RWX + (pos - PG::CWX);
+    const int pwl = ri / PG::RWX;
+    const int wgblk = (ri % PG::RWX) * 8 + x;
+    if (wgblk >= PG::NRW || pwl >= Br) return;               // workgroup-uniform
+    const int blk = wgblk * kWPB + wave;
+    // a timed-out wait must not leave the workgroup's barriers one wave short: all four waves
+    // poll the same counters and agree
     if (!flow_wait8(a.cdone + (size_t)b * 8 * kFlowShardInts, ncx * Br, a.err)) return;
-    const cf* __restrict__ Tt = a.T + ((size_t)(b % a.R) * B * NR + (size_t)pwl * NR + blk) * (size_t)(N2h + 1) * kWRB;
+    const cf* __restrict__ Tt = t_quarter(a.T + ((size_t)(b % a.R) * B + pwl) * (size_t)N1 * (N2h + 1), blk, N2h);
     float* o = a.out + a.pw[b * B + pwl].out_off;
+    float* stg = reinterpret_cast<float*>(lds_all);
     if (g.flags & XCX_F_UNBIAS)
-      pair_row_body<RXR, true, true>(lds, Tt, o, blk, a.tw_N2h, a.tw_unt, a.trash, g XCX_ST_ARG);
+      pair_row_body<RXR, true, true, true>(lds, Tt, o, blk, a.tw_N2h, a.tw_unt, a.trash, stg, g XCX_ST_ARG);
     else
-      pair_row_body<RXR, true, false>(lds, Tt, o, blk, a.tw_N2h, a.tw_unt, a.trash, g XCX_ST_ARG);
+      pair_row_body<RXR, true, false, true>(lds, Tt, o, blk, a.tw_N2h, a.tw_unt, a.trash, stg, g XCX_ST_ARG);
     // every T load of this wave has returned (the values were consumed by the stores above)
     if (lane == 0)
       __hip_atomic_fetch_add(a.rdone + ((size_t)b * 8 + x) * kFlowShardInts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
