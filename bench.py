@@ -347,14 +347,17 @@ def main():
             host_tr = sd.raw.rows_to_host(0, S_h, (W_h - 1) * hop + n)
             prs = np.array([(i, j) for i in range(S_h) for j in range(i + 1, S_h)], np.int32)
             hplan = X.CCPlan(ctx, n, normalize=True)
-            hplan.pairs(host_tr, prs[:2], W_h, hop)
+            r = hplan.pairs(host_tr, prs, W_h, hop)          # steady state of a batch loop: the
+            del r                                            # page-locked result block is recycled
             t1 = time.perf_counter()
-            hplan.pairs(host_tr, prs, W_h, hop)
-            dt_h = time.perf_counter() - t1
+            for _ in range(3):
+                r = hplan.pairs(host_tr, prs, W_h, hop)
+                del r
+            dt_h = (time.perf_counter() - t1) / 3
             extras['pcie_inclusive'] = {
                 'value': len(prs) * W_h / dt_h, 'unit': 'pair-windows/s',
                 'sample': f'{len(prs) * W_h} pair-windows, host traces in ({host_tr.nbytes / 1e6:.0f} MB) and '
-                          f'full-lag CCFs out ({len(prs) * W_h * L * 4 / 1e6:.0f} MB) through host memory'}
+                          f'full-lag CCFs out ({len(prs) * W_h * L * 4 / 1e6:.0f} MB) into page-locked result arrays, per call'}
             hplan.close()
         except Exception as e:          # context number only
             extras['pcie_inclusive'] = {'error': str(e)}

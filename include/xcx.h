@@ -59,6 +59,10 @@ int xcx_last_error(char* buf, size_t len);
 int xcx_device_name(xcx_ctx* ctx, char* buf, size_t len);
 int xcx_malloc(xcx_ctx* ctx, size_t bytes, void** dptr);
 int xcx_free(xcx_ctx* ctx, void* dptr);
+/* page-locked host memory (hipHostMalloc): device-to-host copies into it run at PCIe speed; the
+ * Python mirrors return their result arrays in it (xcorr_amd.Context.pinned_empty) */
+int xcx_host_alloc(xcx_ctx* ctx, size_t bytes, void** hptr);
+int xcx_host_free(xcx_ctx* ctx, void* hptr);
 int xcx_memset(xcx_ctx* ctx, void* dptr, int value, size_t bytes);
 int xcx_memcpy_h2d(xcx_ctx* ctx, void* dst, const void* src, size_t bytes);
 int xcx_memcpy_d2h(xcx_ctx* ctx, void* dst, const void* src, size_t bytes);
@@ -182,6 +186,13 @@ int xcx_taper(xcx_ctx* ctx, float* x, long batch, long n, long nmax,
               int wtype, int on_device);
 int xcx_unbias(xcx_ctx* ctx, float* x, long batch, long npts, long idx_min,
                long idx_max, int on_device);
+/* Head of the post-correlation chain in ONE op (core/postprocess.py:133-136,
+ * `cc.unbias().demean().taper(max_length)`): rows are the lag slice [idx_min, idx_max) of CCFs of
+ * window length npts; x *= n/(n-|lag|) (if `unbias`), x -= mean(x), Hann (wtype 0) / ObsPy-cosine
+ * (wtype 1) flanks of taper_nmax samples (0 = none).  Bit-identical to xcx_unbias + xcx_demean +
+ * xcx_taper, two passes over the rows instead of five. */
+int xcx_post_prep(xcx_ctx* ctx, float* x, long batch, long npts, long idx_min, long idx_max,
+                  int unbias, long taper_nmax, int wtype, int on_device);
 int xcx_onebit(xcx_ctx* ctx, float* x, long batch, long n, int on_device);
 /* Running-absolute-mean temporal normalisation (Bensen et al. 2007 eq. 1; self-defined,
  * the reference has none): x[t] /= mean(|x[t-h .. t+h]|), the window truncated at the

@@ -221,3 +221,45 @@ def test_rms_along_last_axis(ctx):
     assert got.shape == (3, 4)
     assert relerr(got, np.sqrt(np.mean(np.square(x.astype(np.float64)), axis=-1))) < TOL
     assert np.array_equal(sig.absolute(x), np.abs(x))
+
+
+def test_post_prep_is_bitwise_the_three_ops(ctx):
+    """xcx_post_prep (fused unbias -> demean -> taper, f1) == xcx_unbias + xcx_demean + xcx_taper, bit for bit,
+    on full and clipped lag slices, device and host rows."""
+    rng = np.random.default_rng(31)
+    for npts, imin, imax, nmax in ((3000, 0, 5999, 250), (3000, 1000, 4500, 75), (500, 499, 999, 10), (2000, 0, 3999, 0)):
+        L = imax - imin
+        x = (rng.standard_normal((7, L)) * 0.01 + 0.003).astype(np.float32)
+        ref = ops.unbias(ctx, x, npts, imin, imax)
+        ref = ops.demean(ctx, ref)
+        if nmax:
+            ref = ops.taper(ctx, ref, nmax)
+        got = ops.post_prep(ctx, x, npts, imin, imax, unbiased=True, taper_nmax=nmax)
+        assert np.array_equal(got, ref)
+        d = ctx.array(x)
+        ops.post_prep(ctx, d, npts, imin, imax, unbiased=True, taper_nmax=nmax)
+        assert np.array_equal(d.to_host(), ref)
+        r2 = R.unbias(x.astype(np.float64), npts, imin, imax)
+        r2 = R.demean(r2)
+        if nmax:
+            r2 = r2 * R.window(L, 50., max_length=nmax / 50.)
+        assert relerr(got, r2) < TOL
+    nb = ops.post_prep(ctx, x, npts, imin, imax, unbiased=False, taper_nmax=0)
+    assert np.array_equal(nb, ops.demean(ctx, x))
+
+
+def test_postprocess_rows_device_resident(ctx):
+    """core.postprocess_rows: the whole chain on a DeviceArray (nothing crosses PCIe) equals the
+    host-array form and the oracle chain."""
+    from xcorr_amd.core.postprocess import postprocess_rows
+    rng = np.random.default_rng(32)
+    npts, fs = 3001, 50.
+    L = 2 * npts - 1
+    x = (rng.standard_normal((5, L)) * 0.01).astype(np.float32)
+    delay = rng.uniform(-0.03, 0.03, 5)
+    host = postprocess_rows(x, delay, fs, npts, 0, L, ctx=ctx)
+    d = ctx.array(x)
+    dev = postprocess_rows(d, delay, fs, npts, 0, L, ctx=ctx)
+    assert dev.shape == (5, L - 1) and np.array_equal(dev.to_host(), host)
+    ref = np.stack([R.postprocess_chain(x[i].astype(np.float64), npts, fs, 0, L, delay[i]) for i in range(5)])
+    assert relerr(host, ref) < 2 * TOL

@@ -24,3 +24,10 @@ t('taper', lambda: ops.taper(ctx, x, 250))
 t('timeshift', lambda: ops.timeshift(ctx, x, delay, 50., out=y))
 t('sosfiltfilt', lambda: ops.sosfiltfilt(ctx, y, sos))
 t('taper2', lambda: ops.taper(ctx, y, 75))
+x2 = ctx.array((np.random.default_rng(0).standard_normal((rows, L)) * 0.01).astype(np.float32))
+t('post_prep', lambda: ops.post_prep(ctx, x2, n, 0, L, unbiased=True, taper_nmax=250))
+from xcorr_amd.core.postprocess import postprocess_rows
+def chain():
+    r = postprocess_rows(x2, delay, 50., n, 0, L, ctx=ctx)
+    r.free()
+t('whole chain', chain, reps=2)

@@ -40,6 +40,8 @@ SIGNATURES = {
     'xcx_device_name': [_vp, C.c_char_p, _sz],
     'xcx_malloc': [_vp, _sz, C.POINTER(_vp)],
     'xcx_free': [_vp, _vp],
+    'xcx_host_alloc': [_vp, _sz, C.POINTER(_vp)],
+    'xcx_host_free': [_vp, _vp],
     'xcx_memset': [_vp, _vp, _i, _sz],
     'xcx_memcpy_h2d': [_vp, _vp, _vp, _sz],
     'xcx_memcpy_d2h': [_vp, _vp, _vp, _sz],
@@ -68,6 +70,7 @@ SIGNATURES = {
     'xcx_taper': [_vp, _vp, _l, _l, _l, _i, _i],
     'xcx_unbias': [_vp, _vp, _l, _l, _l, _l, _i],
     'xcx_onebit': [_vp, _vp, _l, _l, _i],
+    'xcx_post_prep': [_vp, _vp, _l, _l, _l, _l, _i, _l, _i, _i],
     'xcx_sosfiltfilt': [_vp, _vp, _l, _l, _vp, _i, _i],
     'xcx_sosfilt': [_vp, _vp, _l, _l, _vp, _i, _i],
     'xcx_sosfilt_zerophase': [_vp, _vp, _l, _l, _vp, _i, _i],

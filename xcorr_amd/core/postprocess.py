@@ -15,7 +15,40 @@ from .. import ops
 from ..engine import default_context
 from .init import CCDataset
 
-__all__ = ['postprocess']
+__all__ = ['postprocess', 'postprocess_rows']
+
+
+def postprocess_rows(rows, delay, sampling_rate, npts, index_min, index_max, filter_kwargs=None, ctx=None):
+    """The chain of core/postprocess.py:133-141 on CCF rows [R, L] of the lag slice
+    [index_min, index_max) -- device-resident: a :class:`DeviceArray` in gives a DeviceArray
+    [R, L - (L & 1)] out and nothing crosses PCIe (the rows are modified in place up to the
+    time shift); a numpy array is uploaded once and the result downloaded once.
+
+        unbias -> demean -> taper(5 s)      one fused op (xcx_post_prep), two passes over the rows
+        timeshift(delay[r])                 xcx_timeshift (Dirichlet-kernel convolution)
+        sosfiltfilt highpass -> taper(1.5 s)
+    """
+    import scipy.signal
+    from ..engine import DeviceArray
+    fk = {'frequency': 3., 'btype': 'highpass', 'order': 2, **(filter_kwargs or {})}
+    fs = float(sampling_rate)
+    ctx = ctx or (rows.ctx if isinstance(rows, DeviceArray) else default_context())
+    host = not isinstance(rows, DeviceArray)
+    d = ctx.array(np.ascontiguousarray(rows, dtype=np.float32)) if host else rows
+    if len(d.shape) != 2 or d.shape[1] != index_max - index_min:
+        raise ValueError('rows must be [R, index_max - index_min]')
+    ops.post_prep(ctx, d, npts, index_min, index_max, unbiased=True,
+                  taper_nmax=int(round(5. * fs)))                   # taper: timeshift phase wrapping
+    y = ops.timeshift(ctx, d, np.asarray(delay, np.float64).reshape(-1), fs)
+    sos = scipy.signal.butter(N=fk['order'], Wn=fk['frequency'], btype=fk['btype'], output='sos', fs=fs)
+    ops.sosfiltfilt(ctx, y, sos)
+    ops.taper(ctx, y, int(round(1.5 * fs)))                         # filter artefacts
+    if host:
+        out = y.to_host()
+        y.free()
+        d.free()
+        return out
+    return y
 
 
 def postprocess(ds, lag_lim=None, lag_min=None, lag_max=None, filter_kwargs=None, ctx=None):
@@ -29,7 +62,6 @@ def postprocess(ds, lag_lim=None, lag_min=None, lag_max=None, filter_kwargs=None
         return ds
     if lag_lim is not None:
         lag_min, lag_max = lag_lim
-    import scipy.signal
     fk = {'frequency': 3., 'btype': 'highpass', 'order': 2, **(filter_kwargs or {})}
     lag = ds.lag
     lag_min = lag.min() if lag_min is None else lag_min
@@ -49,13 +81,7 @@ def postprocess(ds, lag_lim=None, lag_min=None, lag_max=None, filter_kwargs=None
     rows = np.ascontiguousarray(ds.cc[valid][:, i0:i1], dtype=np.float32)
     delay = -(ds.pair_offset + ds.time_offset)[valid]
     ctx = ctx or default_context()
-    y = ops.unbias(ctx, rows, npts, imin, imax)
-    y = ops.demean(ctx, y)
-    y = ops.taper(ctx, y, int(round(5. * fs)))              # timeshift phase wrapping
-    y = ops.timeshift(ctx, y, delay, fs)
-    sos = scipy.signal.butter(N=fk['order'], Wn=fk['frequency'], btype=fk['btype'], output='sos', fs=fs)
-    y = ops.sosfiltfilt(ctx, y, sos)
-    y = ops.taper(ctx, y, int(round(1.5 * fs)))             # filter artefacts
+    y = postprocess_rows(rows, delay, fs, npts, imin, imax, filter_kwargs=fk, ctx=ctx)   # one H2D, one D2H
     n = y.shape[-1]
     out = CCDataset(ds.pair, ds.time, lag[i0:i0 + n],
                     {**la, 'index_min': imin, 'index_max': imin + n},

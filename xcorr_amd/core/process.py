@@ -6,9 +6,12 @@ Pair x window driver (xcorr/core/process.py:23-185).
 ``[index_min:index_max]``, optional bias correction at the end -- but instead
 of one ``util.cc.cc`` call per (pair, time) it collects every available window
 first and hands the whole batch to the GPU engine in one call
-(``CCPlan.cc``): the hot loop of core/process.py:82-165 becomes one batched
-launch sequence.
+(``CCPlan.pairs`` over the DISTINCT station windows): the hot loop of
+core/process.py:82-165 becomes one batched launch sequence in which every
+window is transformed once, however many pairs share it.
 """
+import hashlib
+
 import numpy as np
 
 from ..engine import CCPlan, default_context
@@ -60,7 +63,18 @@ def process(dataset, client, inventory=None, retry_missing=False,
         plan = CCPlan(ctx, npts, index_min=imin, index_max=imax,
                       normalize=dataset.cc_attrs['normalize'] == 1,
                       unbiased=False)
-        out = plan.cc(np.stack(xs), np.stack(ys))            # :155-162
+        # every distinct station window is transformed ONCE (the reference transforms both
+        # inputs of every pair): windows are identified by content, the pair list indexes them
+        uniq, index = [], {}
+
+        def slot(x):
+            key = (x.shape[0], hashlib.blake2b(np.ascontiguousarray(x).view(np.uint8), digest_size=16).digest())
+            if key not in index:
+                index[key] = len(uniq)
+                uniq.append(x)
+            return index[key]
+        pairs = np.array([(slot(a), slot(b)) for a, b in zip(xs, ys)], np.int32)
+        out = plan.pairs(np.stack(uniq), pairs, 1, npts)[:, 0]      # :155-162, batched
         plan.close()
         for k, (ip, it) in enumerate(todo):
             dataset.cc[ip, it] = out[k].astype(dataset.cc.dtype)

@@ -168,6 +168,45 @@ __global__ void k_unbias(float* __restrict__ x, long batch, long L, long npts, l
   }
 }
 
+// fused head of the post-correlation chain (core/postprocess.py:133-136): unbias -> demean ->
+// taper(hann flanks), one workgroup per row, the row read twice (second time from L2) and written
+// once instead of five passes over it.  Every intermediate is rounded to float32 exactly where the
+// three separate ops round (x * (float)w, mean in float64 rounded to float32, * (float)window), so
+// the result is bit-identical to xcx_unbias + xcx_demean + xcx_taper.
+__device__ inline float taper_weight(long i, long n, long nmax, int wtype) {
+  // right flank wins on overlap (window.py:105-106)
+  if (i >= n - nmax) {
+    const long e = i - (n - nmax);
+    return (float)((wtype == 0) ? 0.5 * (1.0 + cos(M_PI * (double)e / (double)nmax))
+                                : ((nmax > 1) ? 0.5 * (1.0 - cos(M_PI * (double)(nmax - 1 - e) / (double)(nmax - 1))) : 0.0));
+  }
+  if (i < nmax)
+    return (float)((wtype == 0) ? 0.5 * (1.0 - cos(M_PI * (double)i / (double)nmax))
+                                : ((nmax > 1) ? 0.5 * (1.0 - cos(M_PI * (double)i / (double)(nmax - 1))) : 0.0));
+  return 1.f;
+}
+
+__global__ __launch_bounds__(NT) void k_post_prep(float* __restrict__ x, long L, long npts, long idx_min, long nmax,
+                                                   int wtype, int do_unbias) {
+  __shared__ double red[NT];
+  float* __restrict__ row = x + (size_t)blockIdx.x * L;
+  const int tid = threadIdx.x;
+  auto unb = [=](long o, float v) -> float {
+    if (!do_unbias) return v;
+    long lag = idx_min + o - (npts - 1);
+    if (lag < 0) lag = -lag;
+    return v * (float)((double)npts / (double)(npts - lag));
+  };
+  double acc = 0.0;
+  for (long i = tid; i < L; i += NT) acc += (double)unb(i, row[i]);
+  const float mean = (float)(block_sum(acc, red) / (double)L);
+  for (long i = tid; i < L; i += NT) {
+    float v = unb(i, row[i]) - mean;
+    if (nmax > 0 && (i < nmax || i >= L - nmax)) v = v * taper_weight(i, L, nmax, wtype);
+    row[i] = v;
+  }
+}
+
 __global__ void k_onebit(float* __restrict__ x, long total) {
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long)gridDim.x * blockDim.x) {
@@ -301,6 +340,25 @@ extern "C" int xcx_unbias(xcx_ctx* ctx, float* x, long batch, long npts, long id
   int rc = st.begin(ctx, x, (size_t)batch * L * sizeof(float), on_device);
   if (rc) return rc;
   hipLaunchKernelGGL(k_unbias, dim3(grid_for(batch * L)), dim3(NT), 0, ctx->stream, st.dev, batch, L, npts, idx_min);
+  HIP_TRY(hipGetLastError());
+  return st.end();
+}
+
+extern "C" int xcx_post_prep(xcx_ctx* ctx, float* x, long batch, long npts, long idx_min, long idx_max,
+                             int unbias, long taper_nmax, int wtype, int on_device) {
+  if (!ctx || !x) return set_err(XCX_EINVAL, "null argument");
+  if (idx_max == 0) idx_max = 2 * npts - 1;
+  if (batch < 1 || npts < 1 || idx_min < 0 || idx_max > 2 * npts - 1 || idx_min >= idx_max)
+    return set_err(XCX_EINVAL, "bad lag slice");
+  const long L = idx_max - idx_min;
+  if (taper_nmax < 0 || taper_nmax > L) return set_err(XCX_EINVAL, "taper length nmax=%ld must be in [0, L=%ld]", taper_nmax, L);
+  if (wtype != 0 && wtype != 1) return set_err(XCX_EINVAL, "wtype must be 0 (hann) or 1 (obspy cosine)");
+  HIP_TRY(hipSetDevice(ctx->device));
+  Staged st;
+  int rc = st.begin(ctx, x, (size_t)batch * L * sizeof(float), on_device);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_post_prep, dim3((unsigned)batch), dim3(NT), 0, ctx->stream, st.dev, L, npts, idx_min, taper_nmax,
+                     wtype, unbias);
   HIP_TRY(hipGetLastError());
   return st.end();
 }

@@ -158,6 +158,24 @@ __global__ __launch_bounds__(kNT) void k_stats(
 // ---------------------------------------------------------------------------
 static int flow_check(xcx_ctx* ctx);
 
+// Host-pointer entry points (on_device = 0): the caller's buffer is pinned IN PLACE for the
+// duration of the call (hipHostRegister), so the DMA engines move it at PCIe speed (~55 GB/s
+// instead of ~9 GB/s through the runtime's pageable staging).  If the registration is refused
+// (read-only mapping, ulimit -l, already registered) the copy silently stays pageable.
+// XCX_PIN=0 turns it off.
+struct HostPin {
+  void* ptr = nullptr;
+  HostPin(const void* p, size_t bytes) {
+    static const bool on = !(getenv("XCX_PIN") && atoi(getenv("XCX_PIN")) == 0);
+    if (!on || !p || bytes < ((size_t)1 << 20)) return;       // small copies: not worth a syscall
+    if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) ptr = const_cast<void*>(p);
+    else (void)hipGetLastError();
+  }
+  ~HostPin() { if (ptr) (void)hipHostUnregister(ptr); }
+  HostPin(const HostPin&) = delete;
+  HostPin& operator=(const HostPin&) = delete;
+};
+
 extern "C" int xcx_device_count(int* count) {
   if (!count) return set_err(XCX_EINVAL, "count is null");
   int c = 0;
@@ -233,6 +251,20 @@ extern "C" int xcx_free(xcx_ctx* ctx, void* dptr) {
   HIP_TRY(hipSetDevice(ctx->device));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   HIP_TRY(hipFree(dptr));
+  return XCX_OK;
+}
+// page-locked host memory for result arrays the library's callers hand back to Python: a D2H into
+// it runs at PCIe speed (pageable destinations go through the runtime's staging at ~9 GB/s)
+extern "C" int xcx_host_alloc(xcx_ctx* ctx, size_t bytes, void** hptr) {
+  if (!ctx || !hptr) return set_err(XCX_EINVAL, "null argument");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipHostMalloc(hptr, bytes ? bytes : 1, hipHostMallocDefault));
+  return XCX_OK;
+}
+extern "C" int xcx_host_free(xcx_ctx* ctx, void* hptr) {
+  if (!ctx) return set_err(XCX_EINVAL, "null ctx");
+  if (!hptr) return XCX_OK;
+  HIP_TRY(hipHostFree(hptr));
   return XCX_OK;
 }
 extern "C" int xcx_memset(xcx_ctx* ctx, void* dptr, int value, size_t bytes) {
@@ -1185,6 +1217,7 @@ extern "C" int xcx_cc1d_stack_finish(xcx_plan* p, const int* pairs, int P, float
   p->acc_ld = ld_out;
   if ((rc = stack_tables(p, pairs, S, P, ld_out))) return rc;     // same rows of gramC, out offsets for this pitch
   float* dout = out;
+  HostPin pin_out(on_device ? nullptr : out, ((size_t)(P - 1) * (size_t)ld_out + (size_t)L) * sizeof(float));
   if (!on_device) {
     if ((rc = p->dout.ensure(ctx, (size_t)P * (size_t)ld_out * sizeof(float)))) return rc;
     dout = (float*)p->dout.ptr;
@@ -1220,6 +1253,9 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
   const float* dtr = traces;
   float* dout = out;
   const size_t nrows = stack ? (size_t)P : (size_t)P * W;
+  const size_t span_h = (size_t)(S - 1) * stride_s + (size_t)(W - 1) * stride_w + g.n;
+  HostPin pin_in(on_device ? nullptr : traces, span_h * sizeof(float));
+  HostPin pin_out(on_device ? nullptr : out, ((nrows - 1) * (size_t)ld_out + (size_t)L) * sizeof(float));
   if (!on_device) {
     const size_t span = (size_t)(S - 1) * stride_s + (size_t)(W - 1) * stride_w + g.n;
     if ((rc = p->dtraces.ensure(ctx, span * sizeof(float)))) return rc;
@@ -1423,6 +1459,9 @@ extern "C" int xcx_cc1d(xcx_plan* p, const float* x, const float* y, int batch,
   p->desc_key = 0;
   const float *dx = x, *dy = y;
   float* dout = out;
+  HostPin pin_x(on_device ? nullptr : x, (size_t)batch * n * sizeof(float));
+  HostPin pin_y(on_device ? nullptr : y, (size_t)batch * n * sizeof(float));
+  HostPin pin_o(on_device ? nullptr : out, (size_t)batch * L * sizeof(float));
   if (!on_device) {
     const size_t inb = (size_t)batch * n * sizeof(float);
     if ((rc = p->dtraces.ensure(ctx, 2 * inb))) return rc;

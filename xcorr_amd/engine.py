@@ -96,11 +96,16 @@ class Context:
         self.handle = h
         self.device = int(device)
         self._children = weakref.WeakSet()      # plans and arrays that must go first
+        self._pin_pool = {}                     # capacity -> [addresses] of idle page-locked blocks
 
     def close(self):
         if self.handle:
             for child in list(self._children):
                 child.close()
+            for blocks in self._pin_pool.values():
+                for addr in blocks:
+                    _ffi.lib().xcx_host_free(self.handle, C.c_void_p(addr))
+            self._pin_pool = {}
             _ffi.lib().xcx_destroy(self.handle)
             self.handle = None
 
@@ -122,6 +127,37 @@ class Context:
     def array(self, a, dtype=None):
         a = np.ascontiguousarray(a, dtype=dtype)
         return DeviceArray(self, a.shape, a.dtype).copy_from(a)
+
+    # --- page-locked result arrays ------------------------------------------
+    def pinned_empty(self, shape, dtype=np.float32):
+        """numpy array in page-locked host memory (xcx_host_alloc): the library's D2H into it runs at
+        PCIe speed.  Blocks are recycled through a small per-context pool when the array is
+        garbage-collected (page-locking 100 MB costs as much as copying it)."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        cap = max(1 << 20, 1 << (max(nbytes, 1) - 1).bit_length())        # pool classes: powers of two
+        pool = self._pin_pool.setdefault(cap, [])
+        if pool:
+            addr = pool.pop()
+        else:
+            p = C.c_void_p()
+            check(_ffi.lib().xcx_host_alloc(self.handle, cap, C.byref(p)))
+            addr = p.value
+        buf = (C.c_char * nbytes).from_address(addr)
+        arr = np.frombuffer(buf, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape)
+        ctx_ref = weakref.ref(self)
+
+        def _release(addr=addr, cap=cap):
+            c = ctx_ref()
+            if c is None or not c.handle:
+                return
+            lst = c._pin_pool.setdefault(cap, [])
+            if len(lst) < 4 and cap <= (1 << 32):
+                lst.append(addr)
+            else:
+                _ffi.lib().xcx_host_free(c.handle, C.c_void_p(addr))
+        weakref.finalize(buf, _release)
+        return arr
 
     def sync(self):
         check(_ffi.lib().xcx_sync(self.handle))
@@ -294,7 +330,7 @@ class CCPlan:
             traces = np.ascontiguousarray(traces, dtype=np.float32)
             if out is None:
                 shape = (P, self.L) if self.stack else (P, W, self.L)
-                out = np.empty(shape, dtype=np.float32)
+                out = self.ctx.pinned_empty(shape)
         _check_out(out, nrows, int(ld_out) or self.L, self.L)
         check(_ffi.lib().xcx_cc1d_pairs(
             self.handle, ptr(traces), S, W, stride_s, stride_w, ptr(pairs), P,
@@ -320,7 +356,7 @@ class CCPlan:
         pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
         P = len(pairs)
         if out is None:
-            out = np.empty((P, self.L), dtype=np.float32)
+            out = self.ctx.pinned_empty((P, self.L))
         on_dev = isinstance(out, DeviceArray)
         _check_out(out, P, int(ld_out) or self.L, self.L)
         nw = C.c_longlong(0)
@@ -341,7 +377,7 @@ class CCPlan:
             if on_dev:
                 out = self.ctx.empty((batch, self.L))
             else:
-                out = np.empty(x.shape[:-1] + (self.L,), dtype=np.float32)
+                out = self.ctx.pinned_empty(x.shape[:-1] + (self.L,))
         _check_out(out, batch, self.L, self.L)
         check(_ffi.lib().xcx_cc1d(self.handle, ptr(x), ptr(y), batch, ptr(out),
                                   int(on_dev)))
