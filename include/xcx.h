@@ -186,6 +186,14 @@ int xcx_taper(xcx_ctx* ctx, float* x, long batch, long n, long nmax,
               int wtype, int on_device);
 int xcx_unbias(xcx_ctx* ctx, float* x, long batch, long npts, long idx_min,
                long idx_max, int on_device);
+/* signal/detrend.py:87-110 with skipna=True (the reference's default): mean (linear = 0) or
+ * least-squares line (linear != 0) fitted to the finite samples only; NaN samples stay NaN. */
+int xcx_detrend_nan(xcx_ctx* ctx, float* x, long batch, long n, int linear, int on_device);
+/* signal/window.py:92-106 for any window type: x[:, :nmax] *= flanks[0:nmax],
+ * x[:, -nmax:] *= flanks[nmax:2 nmax] (right flank wins on overlap); flanks is HOST memory
+ * (scipy.signal.windows.<wtype>(2 nmax, False) cast to float32). */
+int xcx_taper_table(xcx_ctx* ctx, float* x, long batch, long n, const float* flanks, long nmax,
+                    int on_device);
 /* Head of the post-correlation chain in ONE op (core/postprocess.py:133-136,
  * `cc.unbias().demean().taper(max_length)`): rows are the lag slice [idx_min, idx_max) of CCFs of
  * window length npts; x *= n/(n-|lag|) (if `unbias`), x -= mean(x), Hann (wtype 0) / ObsPy-cosine

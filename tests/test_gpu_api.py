@@ -246,3 +246,96 @@ def test_column_views_select_window_blocks(ctx):
     assert d.ptr                                   # the view frees nothing
     with pytest.raises(ValueError):
         d.columns_from(T)
+
+
+def test_detrend_skipna_and_window_types(ctx):
+    """signal.detrend(skipna=True) (signal/detrend.py:87-110: fit on the finite samples, NaN stays
+    NaN) and taper with any scipy window type (signal/window.py:92)."""
+    import scipy.signal.windows as W
+    import scipy.stats
+    rng = np.random.default_rng(41)
+    x = (rng.standard_normal((6, 4001)) + 2.0 + 1e-3 * np.arange(4001)).astype(np.float32)
+    x[1, 17] = np.nan
+    x[2, 100:300] = np.nan
+    x[5, :] = np.nan
+    got = sig.detrend(x, type='constant')                        # skipna=True is the default
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')                          # row 5 is all NaN
+        ref = x.astype(np.float64) - np.nanmean(x.astype(np.float64), axis=-1, keepdims=True)
+    ok = ~np.isnan(x)
+    assert np.array_equal(np.isnan(got), np.isnan(x))
+    assert np.abs(got[ok] - ref[ok]).max() < TOL * 5
+    got = sig.detrend(x, type='linear')
+    t = np.arange(4001, dtype=np.float64)
+    for r in range(5):
+        m = ok[r]
+        sl = scipy.stats.linregress(t[m], x[r, m].astype(np.float64))
+        assert np.abs(got[r, m] - (x[r, m] - (sl.slope * t[m] + sl.intercept))).max() < TOL * 5
+        assert np.all(np.isnan(got[r, ~m]))
+    assert np.all(np.isnan(got[5]))
+    # skipna=False: a NaN poisons its row (x.mean(skipna=False))
+    g2 = sig.detrend(x, type='constant', skipna=False)
+    assert np.all(np.isnan(g2[1])) and not np.any(np.isnan(g2[0]))
+    # window types
+    y = rng.standard_normal((3, 3000)).astype(np.float32)
+    for wt in ('hann', 'hamming', 'blackman', 'bartlett', 'cosine'):
+        got = sig.taper(y, wtype=wt, max_length=5., sampling_rate=50.)
+        w = np.ones(3000)
+        win = getattr(W, wt)(500, False)
+        w[:250], w[-250:] = win[:250], win[-250:]
+        assert relerr(got, y * w) < TOL, wt
+        assert np.allclose(sig.window(3000, 50., wtype=wt, max_length=5.), w)
+    with pytest.raises(ValueError):
+        sig.taper(y, wtype='no_such_window', max_length=5., sampling_rate=50.)
+
+
+def test_dataarray_accessor_every_method(ctx):
+    """B4 seam: every method of the re-registered ``.signal`` accessor on real xarray objects
+    (xcorr/signal/accessor.py:60-321).  Runs wherever xarray is importable."""
+    xr = pytest.importorskip('xarray')
+    import xcorr_amd.signal.accessor  # noqa: F401  (registers .signal)
+    rng = np.random.default_rng(43)
+    n, fs = 1000, 50.
+    lag = ucc.lag(n, 1 / fs)
+    a = rng.standard_normal((2, 3, n)).astype(np.float32)
+    t = np.arange(n) / fs
+    da = xr.DataArray(a, dims=('pair', 'time', 't'), coords={'t': ('t', t, {'sampling_rate': fs})},
+                      name='x', attrs={'long_name': 'x', 'units': '-'})
+    assert relerr(da.signal.demean().values, R.demean(a)) < TOL
+    assert relerr(da.signal.detrend(type='linear').values, R.detrend_linear(a)) < TOL
+    assert relerr(da.signal.norm1d().values, R.norm1d(a)) < TOL
+    assert relerr(da.signal.taper(max_length=2.).values, R.taper(a, fs, max_length=2.)) < TOL
+    assert relerr(da.signal.filter(3., btype='highpass', order=2).values,
+                  R.sosfiltfilt(R.butter_sos(2, 3., 'highpass', fs), a)) < TOL
+    assert np.array_equal(da.signal.abs().values, np.abs(a)) and np.array_equal(da.signal.absolute().values, np.abs(a))
+    assert relerr(da.signal.rms().values, np.sqrt((a.astype(np.float64) ** 2).mean(-1))) < TOL
+    assert relerr(np.abs(da.signal.hilbert().values), R.envelope(a)) < 5 * TOL
+    assert relerr(da.signal.envelope().values, R.envelope(a)) < 5 * TOL
+    cc = da.signal.correlate1d(da)
+    assert cc.shape[-1] == 2 * n - 1 and abs(float(cc.values[0, 0, n - 1]) - 1.0) < TOL
+    ts = da.signal.timeshift(delay=0.013)
+    assert relerr(ts.values, R.timeshift(a.astype(np.float64), 0.013, fs)) < 5 * TOL
+    sm = (t > 2) & (t < 6)
+    nm = (t > 10) & (t < 18)
+    r = da.signal.snr(xr.DataArray(sm, dims='t'), xr.DataArray(nm, dims='t'))
+    ro, _, _, _ = R.snr(a, sm, nm)
+    assert r.dims == ('pair', 'time') and relerr(r.values, ro) < TOL
+    ext = da.signal.snr(xr.DataArray(sm, dims='t'), xr.DataArray(nm, dims='t'), extend=True)
+    assert set(ext.data_vars) == {'snr', 's', 'n', 't_s_max'}
+    w = da.t.signal.window(max_length=2.)
+    assert np.allclose(w.values, R.window(n, fs, max_length=2.))
+    ccd = xr.DataArray(rng.standard_normal((1, 2, 2 * n - 1)).astype(np.float32), dims=('pair', 'time', 'lag'),
+                       coords={'lag': ('lag', lag, {'sampling_rate': fs, 'delta': 1 / fs, 'npts': n, 'index_min': 0,
+                                                    'index_max': 2 * n - 1})}, attrs={'unbiased': np.byte(0)})
+    uw = ccd.signal.unbias_weights()
+    assert np.allclose(uw.values, R.weight_full(n))
+    ub = ccd.signal.unbias()
+    assert ub.attrs['unbiased'] == 1 and relerr(ub.values, ccd.values * R.weight_full(n)) < TOL
+    assert relerr(da.signal.fft().signal.ifft().values.real, a) < 5 * TOL
+    assert relerr(da.signal.rfft().signal.irfft().values, a) < 5 * TOL
+    sp = da.isel(pair=0, time=0).signal.spectrogram(duration=1., padding_factor=2)
+    assert sp.shape[-1] == n
+    b2 = xr.DataArray(np.abs(rng.standard_normal((8, 64))).astype(np.float32), dims=('f', 'l'))
+    assert relerr(b2.signal.norm2d().values, R.norm2d(b2.values)) < TOL
+    assert b2.signal.correlate2d(b2).shape == (15, 127)

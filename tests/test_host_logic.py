@@ -168,3 +168,29 @@ def test_output_buffer_validation_is_host_side():
     ro.flags.writeable = False
     with pytest.raises(ValueError, match='read-only'):
         _check_out(ro, 5, ld, L)
+
+
+def test_init_reference_signature():
+    """core.init with the reference's argument order (core/init.py:25-40): timestamps, preprocess,
+    attrs checks, and the production lag slice of scripts/cc.py:25-29."""
+    pre = {'HHZ': [('detrend', {'type': 'demean'}), ('filter', {'type': 'highpass', 'freq': .05})]}
+    att = {'institution': 'i', 'author': 'a', 'source': 's', 'title': 'T'}
+    ds = core.init('NL.A..HHZ-NL.B..HHZ', '2020-01-01', '2020-01-02', pre, att, 50.,
+                   window_length=86400., window_overlap=.875, clip_lag=(0., 9 * 3600.))
+    assert len(ds.time) == 8 and ds.time_is_datetime and ds.time[1] - ds.time[0] == 10800.
+    la = ds.lag_attrs
+    assert (la['npts'], la['index_min'], la['index_max']) == (4320000, 4319999, 5939999)
+    assert ds.lag[0] == 0.0 and abs(ds.lag[-1] - (9 * 3600. - 0.02)) < 1e-6 and ds.cc.shape == (1, 8, 1620000)
+    assert ds.attrs['title'] == 'T Cross-correlations' and ds.pair_attrs['preprocess'] is pre
+    with pytest.raises(TypeError):
+        core.init('A-B', 0., 1., pre, 'not a dict', 50.)
+    for missing in ('institution', 'author', 'source'):
+        with pytest.raises(KeyError):
+            core.init('A-B', 0., 1., pre, {k: v for k, v in att.items() if k != missing}, 50.)
+    with pytest.raises(TypeError):
+        core.init(17, 0., 1., pre, att, 50.)
+    with pytest.raises(TypeError):
+        core.init('A-B', 0., 1., pre, att, 50., clip_lag=(0, 10.))          # int start (core/init.py:183-187)
+    # the build's earlier numeric form keeps working
+    old = core.init('A-B', 0., 86400., 50., 3600., .5)
+    assert len(old.time) == 48 and old.time_attrs['window_overlap'] == .5 and not old.time_is_datetime

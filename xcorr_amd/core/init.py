@@ -36,7 +36,8 @@ class CCDataset:
         import xarray as xr
         ds = xr.Dataset()
         ds.coords['pair'] = self.pair
-        ds.coords['time'] = self.time
+        ds.coords['time'] = (self.time * 1e9).astype('datetime64[ns]') if getattr(self, 'time_is_datetime', False) \
+            else self.time
         ds.coords['lag'] = ('lag', self.lag, self.lag_attrs)
         ds['cc'] = (('pair', 'time', 'lag'), self.cc, self.cc_attrs)
         ds['status'] = (('pair', 'time'), self.status)
@@ -46,21 +47,76 @@ class CCDataset:
         return ds
 
 
-def init(pair, starttime, endtime, sampling_rate, window_length=86400.,
-         window_overlap=.875, clip_lag=None, unbiased_cc=False, closed='left',
-         dtype=np.float32, normalize=True):
-    """Build the container (core/init.py:25-327, numerics-relevant part).
+def _seconds(t):
+    """float seconds (POSIX) of a float / ISO string / datetime64 / pandas.Timestamp / datetime."""
+    if isinstance(t, (int, float, np.integer, np.floating)):
+        return float(t), False
+    if isinstance(t, np.datetime64):
+        return float((t - np.datetime64(0, 's')) / np.timedelta64(1, 'ns')) * 1e-9, True
+    try:
+        import pandas as pd
+        ts = pd.Timestamp(t)
+        if ts.tzinfo is None:
+            ts = ts.tz_localize('UTC')
+        return ts.timestamp(), True
+    except ModuleNotFoundError:
+        return float(np.datetime64(t).astype('datetime64[ns]').astype(np.int64)) * 1e-9, True
 
-    pair : str or list of str (the reference holds exactly one pair per
-        dataset, core/init.py:154; a list is allowed here so that one
-        container feeds the batched engine).
-    starttime, endtime : seconds (float) relative to any epoch; window centres
-        are ``arange(start, end, window_length*(1-window_overlap))`` like
-        ``pd.date_range(freq=...)`` at core/init.py:163-168 (`closed` =
-        'left' drops the end point, 'right' the start, None keeps both).
-    clip_lag : None or (a, b) seconds -> ``argmin|lag-a| : argmin|lag-b|``
-        (core/init.py:176-196, end exclusive).
+
+def init(pair, starttime, endtime, preprocess=None, attrs=None, sampling_rate=None,
+         window_length=86400., window_overlap=.875, clip_lag=None, unbiased_cc=False,
+         closed='left', dtype=np.float32, inventory=None, stationary_poi=None,
+         hash_waveforms=False, normalize=True):
+    """Build the container -- the reference's signature (core/init.py:25-40):
+
+        init(pair, starttime, endtime, preprocess, attrs, sampling_rate, window_length=86400.,
+             window_overlap=.875, clip_lag=None, unbiased_cc=False, closed='left',
+             dtype=np.float32, inventory=None, stationary_poi=None, hash_waveforms=False)
+
+    pair : str (the reference holds exactly one pair per dataset, core/init.py:115-116,154; a
+        list is also accepted here so that one container feeds the batched engine).
+    starttime, endtime : pandas.Timestamp / ISO string / numpy.datetime64 / datetime, or plain
+        seconds.  Window centres are ``date_range(start, end, freq=window_length*(1-overlap))``
+        (core/init.py:163-168; `closed` = 'left' drops the end point, 'right' the start, None
+        keeps both).  The time axis is held in float seconds; ``to_xarray`` turns it back into
+        datetime64 when it came from timestamps.
+    preprocess : dict of operation lists per channel (kept verbatim in the pair attrs; the sha256
+        integrity hash of stream/process.py:557-566 belongs to the storage layer, out of scope).
+    attrs : dict with 'institution', 'author', 'source' (same TypeError / KeyError as
+        core/init.py:106-113 when given).
+    clip_lag : None or (a, b) seconds -> ``argmin|lag-a| : argmin|lag-b|`` (core/init.py:176-196,
+        end exclusive); a single float c means (-|c|, |c|) (the reference raises there,
+        ``tuple(-c, c)``: SURVEY a12).
+    inventory, stationary_poi : pair geodesy (util/receiver.py) is out of scope: accepted, unused.
+    hash_waveforms : accepted; waveform hashing is storage-integrity plumbing, not built.
+
+    Legacy numeric form of this build, still accepted:
+        init(pair, start_s, end_s, sampling_rate, window_length, window_overlap, ...).
     """
+    if isinstance(preprocess, (int, float, np.integer, np.floating)) and not isinstance(preprocess, bool):
+        # legacy positional form: (pair, t0, t1, sampling_rate[, window_length[, window_overlap]])
+        legacy_wl = attrs if isinstance(attrs, (int, float)) else None
+        legacy_ov = sampling_rate if isinstance(sampling_rate, (int, float)) and legacy_wl is not None else None
+        sampling_rate, preprocess, attrs = float(preprocess), None, None
+        if legacy_wl is not None:
+            window_length = float(legacy_wl)
+        if legacy_ov is not None:
+            window_overlap = float(legacy_ov)
+    if sampling_rate is None:
+        raise TypeError("init() missing required argument: 'sampling_rate'")
+    if attrs is not None:
+        if not isinstance(attrs, dict):
+            raise TypeError('attrs should be a dictionary')
+        if 'institution' not in attrs:
+            raise KeyError("attrs['institution'] = 'Institution, department'!")
+        if 'author' not in attrs:
+            raise KeyError("attrs['author'] = 'Name - E-mail'!")
+        if 'source' not in attrs:
+            raise KeyError("attrs['source'] = 'Data source description'!")
+    if not isinstance(pair, (str, list, tuple)):
+        raise TypeError("pair should be receiver pair string!")
+    starttime, dt0 = _seconds(starttime)
+    endtime, dt1 = _seconds(endtime)
     pairs = [pair] if isinstance(pair, str) else list(pair)
     delta = 1. / sampling_rate
     npts = int(window_length * sampling_rate)              # core/init.py:120
@@ -77,7 +133,10 @@ def init(pair, starttime, endtime, sampling_rate, window_length=86400.,
                '`tuple` with length 2 specifying start and end.')
         if isinstance(clip_lag, float):
             clip_lag = (-abs(clip_lag), abs(clip_lag))
-        elif not (isinstance(clip_lag, tuple) and len(clip_lag) == 2):
+        elif isinstance(clip_lag, tuple) and len(clip_lag) == 2:
+            if not isinstance(clip_lag[0], float):            # core/init.py:183-187 (checks [0] twice)
+                raise TypeError(msg)
+        else:
             raise TypeError(msg)
         nmin = int(np.argmin(abs(lag - clip_lag[0])))
         nmax = int(np.argmin(abs(lag - clip_lag[1])))
@@ -98,5 +157,18 @@ def init(pair, starttime, endtime, sampling_rate, window_length=86400.,
     }
     time_attrs = {'window_length': window_length,
                   'window_overlap': window_overlap, 'closed': closed}
-    return CCDataset(pairs, time, lag[nmin:nmax], lag_attrs, cc_attrs,
-                     time_attrs, dtype=dtype)
+    ds = CCDataset(pairs, time, lag[nmin:nmax], lag_attrs, cc_attrs,
+                   time_attrs, dtype=dtype)
+    ds.time_is_datetime = bool(dt0 or dt1)
+    ds.pair_attrs = {'long_name': 'Cross-correlation receiver pair', 'standard_name': 'receiver_pair',
+                     'units': '-', 'preprocess': preprocess if preprocess is not None else {}}
+    if attrs is not None:                                     # global attributes of core/init.py:127-151
+        ds.attrs = {
+            'title': ((attrs['title'] if 'title' in attrs else '') + ' Cross-correlations').strip(),
+            'institution': attrs['institution'], 'author': attrs['author'], 'source': attrs['source'],
+            'history': '', 'comment': attrs['comment'] if 'comment' in attrs else 'n/a',
+            'references': ('Bendat, J. Samuel, & Piersol, A. Gerald. (1971). Random data : analysis and '
+                           'measurement procedures. New York (N.Y.): Wiley-Interscience.'),
+            'Conventions': 'CF-1.9',
+        }
+    return ds

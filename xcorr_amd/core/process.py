@@ -104,8 +104,8 @@ def process_batched(traces, sampling_rate, window_length, window_overlap=0.5,
     W = (T - n) // hop + 1
     if pairs is None:
         pairs = [(i, j) for i in range(S) for j in range(i + 1, S)]
-    lay = init('x', 0., 1., sampling_rate, window_length, window_overlap,
-               clip_lag=clip_lag)
+    lay = init('x', 0., 1., sampling_rate=sampling_rate, window_length=window_length,
+               window_overlap=window_overlap, clip_lag=clip_lag)
     imin, imax = lay.lag_attrs['index_min'], lay.lag_attrs['index_max']
     ctx = ctx or default_context()
     plan = CCPlan(ctx, n, index_min=imin, index_max=imax, normalize=normalize,

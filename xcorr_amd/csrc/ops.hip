@@ -168,6 +168,55 @@ __global__ void k_unbias(float* __restrict__ x, long batch, long L, long npts, l
   }
 }
 
+// detrend with the reference's NaN handling (signal/detrend.py:87-110, skipna=True): the mean /
+// least-squares line is fitted to the finite samples only (scipy.stats.linregress over t[~nan],
+// y[~nan]) and subtracted everywhere; NaN samples stay NaN.  One workgroup per row, float64 sums.
+__global__ __launch_bounds__(NT) void k_detrend_nan(float* __restrict__ x, long n, int linear) {
+  __shared__ double red[NT];
+  float* __restrict__ row = x + (size_t)blockIdx.x * n;
+  const int tid = threadIdx.x;
+  double c = 0.0, sy = 0.0, st = 0.0;
+  for (long i = tid; i < n; i += NT) {
+    const float v = row[i];
+    if (v == v) { c += 1.0; sy += (double)v; st += (double)i; }
+  }
+  c = block_sum(c, red); sy = block_sum(sy, red); st = block_sum(st, red);
+  if (c == 0.0) return;                                   // all-NaN row stays as it is
+  const double ybar = sy / c, tbar = st / c;
+  double m = 0.0;
+  if (linear) {
+    double stt = 0.0, sty = 0.0;
+    for (long i = tid; i < n; i += NT) {
+      const float v = row[i];
+      if (v == v) { const double dt = (double)i - tbar; stt += dt * dt; sty += dt * ((double)v - ybar); }
+    }
+    stt = block_sum(stt, red); sty = block_sum(sty, red);
+    m = (stt > 0.0) ? sty / stt : 0.0;
+  }
+  const double b = ybar - m * tbar;
+  if (linear) {
+    for (long i = tid; i < n; i += NT) row[i] = (float)((double)row[i] - (m * (double)i + b));
+  } else {
+    const float mean = (float)ybar;
+    for (long i = tid; i < n; i += NT) row[i] = row[i] - mean;
+  }
+}
+
+// taper with an arbitrary flank table (any scipy.signal.windows type, signal/window.py:92-106):
+// w[0:nmax] = tab[0:nmax], w[-nmax:] = tab[nmax:2 nmax], ones between; the right flank wins on overlap
+__global__ void k_taper_table(float* __restrict__ x, long batch, long n, long nmax, const float* __restrict__ tab) {
+  const long per = 2 * nmax;
+  const long total = batch * per;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    const long r = idx / per, q = idx % per;
+    long i;
+    if (q < nmax) { i = q; if (i >= n - nmax) continue; }
+    else { i = n - nmax + (q - nmax); if (i < 0) continue; }
+    float* p = x + (size_t)r * n + i;
+    *p = *p * tab[q];
+  }
+}
+
 // fused head of the post-correlation chain (core/postprocess.py:133-136): unbias -> demean ->
 // taper(hann flanks), one workgroup per row, the row read twice (second time from L2) and written
 // once instead of five passes over it.  Every intermediate is rounded to float32 exactly where the
@@ -342,6 +391,39 @@ extern "C" int xcx_unbias(xcx_ctx* ctx, float* x, long batch, long npts, long id
   hipLaunchKernelGGL(k_unbias, dim3(grid_for(batch * L)), dim3(NT), 0, ctx->stream, st.dev, batch, L, npts, idx_min);
   HIP_TRY(hipGetLastError());
   return st.end();
+}
+
+extern "C" int xcx_detrend_nan(xcx_ctx* ctx, float* x, long batch, long n, int linear, int on_device) {
+  if (!ctx || !x) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || n < 1) return set_err(XCX_EINVAL, "batch and n must be >= 1");
+  HIP_TRY(hipSetDevice(ctx->device));
+  Staged st;
+  int rc = st.begin(ctx, x, (size_t)batch * n * sizeof(float), on_device);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_detrend_nan, dim3((unsigned)batch), dim3(NT), 0, ctx->stream, st.dev, n, linear ? 1 : 0);
+  HIP_TRY(hipGetLastError());
+  return st.end();
+}
+
+extern "C" int xcx_taper_table(xcx_ctx* ctx, float* x, long batch, long n, const float* flanks, long nmax, int on_device) {
+  if (!ctx || !x || !flanks) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || n < 1) return set_err(XCX_EINVAL, "batch and n must be >= 1");
+  if (nmax < 1 || nmax > n) return set_err(XCX_EINVAL, "taper length nmax=%ld must be in [1, n=%ld]", nmax, n);
+  HIP_TRY(hipSetDevice(ctx->device));
+  float* dtab = nullptr;                                   // the table is host memory in both modes
+  HIP_TRY(hipMalloc((void**)&dtab, sizeof(float) * 2 * (size_t)nmax));
+  if (hipMemcpyAsync(dtab, flanks, sizeof(float) * 2 * (size_t)nmax, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+    (void)hipFree(dtab);
+    return set_err(XCX_EHIP, "window table upload failed");
+  }
+  Staged st;
+  int rc = st.begin(ctx, x, (size_t)batch * n * sizeof(float), on_device);
+  if (rc) { (void)hipFree(dtab); return rc; }
+  hipLaunchKernelGGL(k_taper_table, dim3(grid_for(batch * 2 * nmax)), dim3(NT), 0, ctx->stream, st.dev, batch, n, nmax, dtab);
+  rc = st.end();
+  (void)hipStreamSynchronize(ctx->stream);
+  (void)hipFree(dtab);
+  return rc;
 }
 
 extern "C" int xcx_post_prep(xcx_ctx* ctx, float* x, long batch, long npts, long idx_min, long idx_max,

@@ -13,7 +13,7 @@ from . import _ffi
 from ._ffi import check, ptr
 from .engine import DeviceArray, default_context
 
-__all__ = ['copy', 'norm1d', 'demean', 'detrend_linear', 'taper', 'unbias', 'post_prep',
+__all__ = ['copy', 'norm1d', 'demean', 'detrend_linear', 'taper', 'taper_table', 'detrend_nan', 'unbias', 'post_prep',
            'onebit', 'sosfiltfilt', 'sosfilt', 'sosfilt_zerophase', 'timeshift', 'snr', 'correlate2d',
            'fft', 'ifft', 'rfft', 'irfft', 'hilbert', 'decimate', 'lanczos', 'block_rms', 'spectrogram', 'ram_normalize']
 
@@ -86,6 +86,26 @@ def unbias(ctx, x, npts, index_min=0, index_max=0):
         raise ValueError('last dimension does not match the lag slice')
     check(_ffi.lib().xcx_unbias(ctx.handle, ptr(buf), b, int(npts),
                                 int(index_min), int(index_max), dev))
+    return buf
+
+
+def detrend_nan(ctx, x, linear=False):
+    """detrend with skipna=True (signal/detrend.py:87-110): fit on the finite samples, NaN stays NaN."""
+    ctx = _ctx(ctx, x)
+    buf, b, n, dev, _ = _prep(x)
+    check(_ffi.lib().xcx_detrend_nan(ctx.handle, ptr(buf), b, n, int(bool(linear)), dev))
+    return buf
+
+
+def taper_table(ctx, x, flanks):
+    """Taper with explicit flanks: flanks = window(2*nmax) (float32, host): first half on the left,
+    second half on the right (signal/window.py:92-106 for any scipy window)."""
+    ctx = _ctx(ctx, x)
+    buf, b, n, dev, _ = _prep(x)
+    fl = np.ascontiguousarray(flanks, dtype=np.float32)
+    if fl.ndim != 1 or fl.size % 2:
+        raise ValueError('flanks must hold 2*nmax samples')
+    check(_ffi.lib().xcx_taper_table(ctx.handle, ptr(buf), b, n, ptr(fl), fl.size // 2, dev))
     return buf
 
 

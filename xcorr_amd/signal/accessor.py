@@ -93,3 +93,30 @@ class SignalAccessor():
 
     def abs(self):
         return _f.absolute(self._da)
+
+    absolute = abs
+
+    @wraps(_f.snr)
+    def snr(self, signal, noise, **kwargs):
+        return _f.snr(self._da, signal, noise, **kwargs)
+
+    def unbias_weights(self, name=None):
+        """Unbias weights of the DataArray's lag coordinate (signal/unbias.py:106-145): the
+        coordinate attrs ``npts, index_min, index_max`` select ``weight(npts)[index_min:index_max]``."""
+        la = self._da.attrs if 'npts' in self._da.attrs else self._da[self._da.dims[-1]].attrs
+        for attr in ('npts', 'index_min', 'index_max'):
+            if attr not in la:
+                raise ValueError(f'Lag has no attribute "{attr}"!')
+        w = _f.unbias_weights(la['npts'], la['index_min'], la['index_max'])
+        dim = self._da.dims[-1]
+        return xr.DataArray(w.astype(self._da.dtype), dims=(dim,), coords={dim: self._da[dim]}, name=name or 'w',
+                            attrs={'long_name': 'Unbiased CC estimate scale factor', 'units': '-'})
+
+    def window(self, **kwargs):
+        """Taper window along the DataArray's (1-D) coordinate (signal/window.py:27-116)."""
+        coord = self._da
+        if 'sampling_rate' not in coord.attrs:
+            raise ValueError('x has no attribute "sampling_rate"!')
+        w = _f.window(coord.size, coord.attrs['sampling_rate'], **kwargs)
+        return xr.DataArray(w, dims=coord.dims, coords=coord.coords, name='win',
+                            attrs={'long_name': 'Window', 'units': '-'})

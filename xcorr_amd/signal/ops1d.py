@@ -109,14 +109,19 @@ norm = norm1d
 # -- a7: signal/detrend.py:31-145 ----------------------------------------------
 def detrend(x, dim=None, type=None, skipna=True):
     """Remove the mean ('constant') or the least-squares line ('linear')
-    (signal/detrend.py:87-110).  NaN handling (`skipna`) is not supported on
-    the GPU path: rows must be finite."""
+    (signal/detrend.py:87-110).  ``skipna=True`` (the reference's default) fits on the finite
+    samples only and leaves NaN samples NaN; ``skipna=False`` lets a NaN poison its row, like
+    ``x.mean(skipna=False)`` / ``linregress`` on data with NaN."""
     type = type or _types[0]
     if not isinstance(type, str):
         raise TypeError('type should be a string')
     if type not in _types:
         raise KeyError(f'type should be any of "{"|".join(_types)}"')
-    fn = _ops.detrend_linear if type == 'linear' else _ops.demean
+    if skipna:
+        def fn(c, v):
+            return _ops.detrend_nan(c, v, linear=(type == 'linear'))
+    else:
+        fn = _ops.detrend_linear if type == 'linear' else _ops.demean
     if _is_da(x):
         dim = _check_dim(x, dim)
         return _apply_da(x, dim, lambda v: fn(None, v))
@@ -152,25 +157,35 @@ def window(npts, sampling_rate, wtype='hann', max_percentage=None,
     first/last ``nmax`` samples of a periodic Hann window of length 2*nmax.
     Host-side coordinate helper (float64), like the reference."""
     wtype = wtype or 'hann'
-    if wtype != 'hann':
-        raise ValueError('only wtype="hann" is built on the GPU path')
     side = side or 'both'
     if side not in ('left', 'right', 'both'):
         raise ValueError('side should be either "left", "right" or "both"!')
     nmax = _nmax(npts, sampling_rate, max_percentage, max_length)
-    i = np.arange(nmax, dtype=np.float64)
+    win = _flanks(wtype, nmax)
     w = np.ones(npts, dtype=np.float64)
-    w[0:nmax] = 0.5 * (1.0 - np.cos(np.pi * i / nmax))
-    w[npts - nmax:] = 0.5 * (1.0 + np.cos(np.pi * i / nmax))
+    w[0:nmax] = win[0:nmax]
+    w[npts - nmax:] = win[nmax:]
     return w
+
+
+def _flanks(wtype, nmax):
+    """``scipy.signal.windows.<wtype>(2*nmax, False)`` (signal/window.py:92), float64."""
+    import scipy.signal.windows as _w
+    if not hasattr(_w, wtype):
+        raise ValueError(f'unknown window type "{wtype}"')
+    return np.asarray(getattr(_w, wtype)(2 * nmax, False), dtype=np.float64)
 
 
 def taper(x, wtype=None, max_percentage=None, max_length=None, side=None,
           dim=None, sampling_rate=None):
-    """x * window (signal/taper.py:67-69)."""
+    """x * window (signal/taper.py:67-69); any ``scipy.signal.windows`` type (Hann flanks are
+    generated on the device, other types come from a host table)."""
     wtype = wtype or 'hann'
-    if wtype != 'hann':
-        raise ValueError('only wtype="hann" is built on the GPU path')
+
+    def run(v, nmax):
+        if wtype == 'hann':
+            return _ops.taper(None, v, nmax)
+        return _ops.taper_table(None, v, _flanks(wtype, nmax).astype(np.float32))
     if _is_da(x):
         dim = _check_dim(x, dim)
         if 'sampling_rate' not in x[dim].attrs:
@@ -178,12 +193,12 @@ def taper(x, wtype=None, max_percentage=None, max_length=None, side=None,
         fs = x[dim].attrs['sampling_rate']
         nmax = _nmax(x[dim].size, fs, max_percentage, max_length,
                      float(np.max(x[dim].values)))
-        return _apply_da(x, dim, lambda v: _ops.taper(None, v, nmax))
+        return _apply_da(x, dim, lambda v: run(v, nmax))
     if sampling_rate is None:
         raise ValueError('x has no attribute "sampling_rate"!')
     x = np.asarray(x)
     nmax = _nmax(x.shape[-1], sampling_rate, max_percentage, max_length)
-    return _ops.taper(None, x, nmax)
+    return run(x, nmax)
 
 
 # -- a9: signal/filter.py:27-120 -------------------------------------------------
@@ -334,6 +349,26 @@ def snr(x, signal, noise, dim=None, power=False, decibels=False, extend=False, e
     """Signal-to-noise ratio along the last axis: max|x| (or of the Hilbert envelope,
     ``envelope=True``) in the `signal` mask over the rms of x in the `noise` mask
     (signal/snr.py:107-116).  ``extend=True`` returns (snr, s, n, argmax)."""
+    if _is_da(x):
+        # signal/snr.py:85-165: masks along `dim`; returns the snr DataArray, or with extend=True a
+        # Dataset {snr, s, n, <dim>_s_max} like the reference
+        dim = _check_dim(x, dim)
+        xt = x.transpose(..., dim)
+        sm = np.asarray(signal.values if _is_da(signal) else signal, dtype=bool)
+        nm = np.asarray(noise.values if _is_da(noise) else noise, dtype=bool)
+        r, s_, n_, a_ = snr(np.ascontiguousarray(xt.values, dtype=np.float32), sm, nm, power=power,
+                            decibels=decibels, extend=True, envelope=envelope)
+        lead = {d: xt[d] for d in xt.dims[:-1] if d in xt.coords}
+        da = xr.DataArray(np.asarray(r).reshape(xt.shape[:-1]), dims=xt.dims[:-1], coords=lead, name='snr')
+        if not extend:
+            return da
+        ds = xr.Dataset()
+        ds['snr'] = da
+        ds['s'] = xr.DataArray(np.asarray(s_).reshape(xt.shape[:-1]), dims=xt.dims[:-1], coords=lead)
+        ds['n'] = xr.DataArray(np.asarray(n_).reshape(xt.shape[:-1]), dims=xt.dims[:-1], coords=lead)
+        ds[f'{dim}_s_max'] = xr.DataArray(xt[dim].values[np.asarray(a_).reshape(xt.shape[:-1])],
+                                          dims=xt.dims[:-1], coords=lead)
+        return ds
     x = np.asarray(x)
     s, n, a = _ops.snr(None, x, np.asarray(signal), np.asarray(noise))
     if envelope:
