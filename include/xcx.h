@@ -270,6 +270,15 @@ int xcx_ifft(xcx_ctx* ctx, const float* in, float* out, long batch, long n, int 
 int xcx_rfft(xcx_ctx* ctx, const float* x, float* out, long batch, long size, int on_device);
 int xcx_irfft(xcx_ctx* ctx, const float* in, float* x, long batch, long m, int on_device);
 
+/* Fourier resampling with ObsPy's Trace.resample semantics (registry entry 'resample' of
+ * xcorr/stream/process.py:29-94, chain scripts/cc.py:46-113; unverified vs obspy):
+ *   y = irfft(interp(rfft(x) * window_half), num) * num / npts,   x [batch][npts] -> y [batch][num],
+ * the spectrum linearly interpolated at bin positions j * ratio (ratio = npts * new_rate /
+ * (num * old_rate)), clamped at the last bin like numpy.interp.  window_half: HOST float32
+ * [npts/2 + 1] (ifftshift(get_window(w, npts))[:npts/2+1]) or NULL.  npts, num <= 245760. */
+int xcx_resample(xcx_ctx* ctx, const float* x, float* y, long batch, long npts, long num,
+                 double ratio, const float* window_half, int on_device);
+
 /* Analytic signal of every row, scipy.signal.hilbert semantics (xcorr/signal/hilbert.py:69):
  * x [batch][n] real -> out [batch][n] complex, or with envelope != 0 its modulus
  * [batch][n] real (hilbert.py:120; the `envelope=True` branch of signal/snr.py:109).

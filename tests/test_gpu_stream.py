@@ -131,3 +131,32 @@ def test_filter_zerophase_is_obspys_two_pass_form(ctx, raw):
     sos = stream.butter_sos('bandpass', 250., 4, freqmin=1., freqmax=20.)
     assert relerr(ops.sosfilt_zerophase(ctx, xl, sos), R.sosfilt_zerophase(sos, xl)) < 2 * TOL
     assert relerr(ops.sosfilt_zerophase(ctx, d, sos).to_host(), R.sosfilt_zerophase(sos, x)) < 2 * TOL
+
+
+@pytest.mark.parametrize('new_rate', [50., 100., 62.5, 40., 500.])
+def test_fourier_resample(ctx, raw, new_rate):
+    """stream.resample = ObsPy Trace.resample (Fourier method; registry entry 'resample',
+    xcorr/stream/process.py:29-94) against the numpy restatement; odd / even lengths, integer and
+    non-integer factors, window types, the anti-alias option, device rows, the operation list."""
+    for npts in (20000, 20001, 7919):
+        x = raw[:3, :npts]
+        y, fs = stream.resample(x, 250., new_rate, ctx=ctx)
+        ref = R.resample_fourier(x, 250., new_rate)
+        assert fs == new_rate and y.shape == ref.shape == (3, int(npts / (250. / new_rate)))
+        assert relerr(y, ref) < TOL
+    x = raw[:2, :12000]
+    for w in (None, 'blackman'):
+        assert relerr(stream.resample(x, 250., new_rate, window=w, ctx=ctx)[0], R.resample_fourier(x, 250., new_rate, window=w)) < TOL
+    d = ctx.array(x)
+    import scipy.signal
+    wh = np.fft.ifftshift(scipy.signal.get_window('hann', 12000))[:6001]
+    yd = ops.resample(ctx, d, int(12000 / (250. / new_rate)), 1.0, wh)       # 12000 / factor is whole: bins coincide
+    assert relerr(yd.to_host(), R.resample_fourier(x, 250., new_rate)) < TOL
+    if new_rate <= 100.:
+        yf, _ = stream.resample(x, 250., new_rate, no_filter=False, ctx=ctx)
+        xf = R.sosfilt(stream.cheby2_lowpass_sos(0.5 * new_rate, 250.), x.astype(np.float64))
+        assert relerr(yf, R.resample_fourier(xf, 250., new_rate)) < 5 * TOL
+        y2, fs2 = stream.apply_operations(x, 250., [('resample', {'sampling_rate': new_rate})], ctx=ctx)
+        assert fs2 == new_rate and relerr(y2, R.resample_fourier(x, 250., new_rate)) < TOL
+    with pytest.raises(ValueError):
+        stream.resample(raw[:1, :1001], 250., 100., strict_length=True, ctx=ctx)

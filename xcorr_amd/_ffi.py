@@ -83,6 +83,7 @@ SIGNATURES = {
     'xcx_ifft': [_vp, _vp, _vp, _l, _l, _i],
     'xcx_rfft': [_vp, _vp, _vp, _l, _l, _i],
     'xcx_irfft': [_vp, _vp, _vp, _l, _l, _i],
+    'xcx_resample': [_vp, _vp, _vp, _l, _l, _l, C.c_double, _vp, _i],
     'xcx_hilbert': [_vp, _vp, _vp, _l, _l, _i, _i],
     'xcx_decimate': [_vp, _vp, _vp, _l, _l, _l, _vp, _i, _i],
     'xcx_lanczos': [_vp, _vp, _vp, _l, _l, _l, C.c_double, C.c_double, _i, _i],

@@ -15,7 +15,7 @@ from .engine import DeviceArray, default_context
 
 __all__ = ['copy', 'norm1d', 'demean', 'detrend_linear', 'taper', 'taper_table', 'detrend_nan', 'unbias', 'post_prep',
            'onebit', 'sosfiltfilt', 'sosfilt', 'sosfilt_zerophase', 'timeshift', 'snr', 'correlate2d',
-           'fft', 'ifft', 'rfft', 'irfft', 'hilbert', 'decimate', 'lanczos', 'block_rms', 'spectrogram', 'ram_normalize']
+           'fft', 'ifft', 'rfft', 'irfft', 'hilbert', 'decimate', 'resample', 'lanczos', 'block_rms', 'spectrogram', 'ram_normalize']
 
 
 def _prep(x):
@@ -325,6 +325,22 @@ def decimate(ctx, x, factor, sos=None):
         s2 = _sos(sos)
         K = s2.shape[0]
     check(_ffi.lib().xcx_decimate(ctx.handle, ptr(src), ptr(y), batch, n, int(factor), ptr(s2), K, dev))
+    return y
+
+
+def resample(ctx, x, num, ratio, window_half=None):
+    """Fourier resampling of every row to `num` samples (ObsPy Trace.resample core, xcx_resample):
+    irfft(interp(rfft(x) * window_half, bins j*ratio), num) * num / npts."""
+    ctx = _ctx(ctx, x)
+    src, dev, lead, n = _rows(x)
+    batch = int(np.prod(lead)) if lead else 1
+    y = _out(ctx, src, dev, tuple(lead) + (int(num),))
+    wh = None
+    if window_half is not None:
+        wh = np.ascontiguousarray(window_half, dtype=np.float32)
+        if wh.shape != (n // 2 + 1,):
+            raise ValueError('window_half must hold npts//2 + 1 samples')
+    check(_ffi.lib().xcx_resample(ctx.handle, ptr(src), ptr(y), batch, n, int(num), float(ratio), ptr(wh), dev))
     return y
 
 

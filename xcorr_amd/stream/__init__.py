@@ -8,8 +8,8 @@ ObsPy is not vendored by the reference and not installable here: the ObsPy-backe
 ops are restated from ObsPy's documented behaviour and are **unverified against
 obspy itself** (SURVEY 8c).  ``running_rms`` is the reference's own code.
 """
-from .ops import (detrend, filter, taper, decimate, interpolate, running_rms,   # noqa: F401
+from .ops import (detrend, filter, taper, decimate, resample, interpolate, running_rms,   # noqa: F401
                   butter_sos, cheby2_lowpass_sos, cosine_taper_length, apply_operations)
 
-__all__ = ['detrend', 'filter', 'taper', 'decimate', 'interpolate', 'running_rms',
+__all__ = ['detrend', 'filter', 'taper', 'decimate', 'resample', 'interpolate', 'running_rms',
            'butter_sos', 'cheby2_lowpass_sos', 'cosine_taper_length', 'apply_operations']

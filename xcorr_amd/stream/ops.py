@@ -87,6 +87,40 @@ def decimate(x, sampling_rate, factor, no_filter=False, ctx=None):
     return _ops.decimate(ctx, x, factor, sos), sampling_rate / float(factor)
 
 
+def resample(x, sampling_rate, new_sampling_rate, window='hann', no_filter=True, strict_length=False, ctx=None):
+    """``Trace.resample(sampling_rate, window='hann', no_filter=True, strict_length=False)``: Fourier
+    method -- rfft, frequency-domain window ``ifftshift(get_window(window, npts))`` (or a callable
+    of ``fftfreq(npts)`` / an array of npts samples / None), linear interpolation of the spectrum
+    onto the new frequency grid, irfft to ``num = int(npts / factor)`` samples, scaled by
+    num / npts.  ``no_filter=False`` first applies the Chebyshev-II anti-alias low-pass of
+    ``decimate`` (factor <= 16).  Returns (y, new_sampling_rate).  npts <= 245 760."""
+    npts = x.shape[-1]
+    factor = sampling_rate / float(new_sampling_rate)
+    if strict_length and npts % factor != 0.0:
+        raise ValueError('End time of trace would change and strict_length=True.')
+    if not no_filter:
+        if factor > 16:
+            raise ArithmeticError('Automatic filter design is unstable for resampling factors (current sampling '
+                                  'rate/new sampling rate) above 16. Manual resampling is necessary.')
+        x = _ops.sosfilt(ctx, x if not isinstance(x, np.ndarray) else x.copy(),
+                         cheby2_lowpass_sos(sampling_rate * 0.5 / float(factor), sampling_rate))
+    num = int(npts / factor)
+    wh = None
+    if window is not None:
+        if callable(window):
+            large_w = np.asarray(window(np.fft.fftfreq(npts)), dtype=np.float64)
+        elif isinstance(window, np.ndarray):
+            if window.shape != (npts,):
+                raise ValueError('Window has to be the same shape as the data.')
+            large_w = window.astype(np.float64)
+        else:
+            large_w = np.fft.ifftshift(scipy.signal.get_window(str(window), npts))
+        wh = large_w[:npts // 2 + 1]
+    # bin position of new frequency j: (j * new_rate / num) / (old_rate / npts)
+    ratio = (float(new_sampling_rate) / num) / (float(sampling_rate) / npts)
+    return _ops.resample(ctx, x, num, ratio, wh), float(new_sampling_rate)
+
+
 def interpolate(x, sampling_rate, new_sampling_rate, method='lanczos', a=20, starttime_offset=0.0, npts=None,
                 ctx=None):
     """``Trace.interpolate(sampling_rate, method='lanczos', a=...)``: new sample i sits at
@@ -118,7 +152,7 @@ def running_rms(x, sampling_rate, window=1., ctx=None):
     return _ops.block_rms(ctx, x, win, step, nwin), 1.0 / window
 
 
-_OPS = {'detrend': detrend, 'filter': filter, 'taper': taper, 'decimate': decimate,
+_OPS = {'detrend': detrend, 'filter': filter, 'taper': taper, 'decimate': decimate, 'resample': resample,
         'interpolate': interpolate, 'running_rms': running_rms}
 
 
@@ -140,6 +174,9 @@ def apply_operations(x, sampling_rate, operations, ctx=None):
             x = filter(x, sampling_rate, ctx=ctx, **p)
         elif name == 'decimate':
             x, sampling_rate = decimate(x, sampling_rate, ctx=ctx, **p)
+        elif name == 'resample':
+            new_rate = p.pop('sampling_rate')
+            x, sampling_rate = resample(x, sampling_rate, new_rate, ctx=ctx, **p)
         elif name == 'interpolate':
             new_rate = p.pop('sampling_rate')
             x, sampling_rate = interpolate(x, sampling_rate, new_rate, ctx=ctx, **p)
