@@ -339,3 +339,42 @@ def test_dataarray_accessor_every_method(ctx):
     b2 = xr.DataArray(np.abs(rng.standard_normal((8, 64))).astype(np.float32), dims=('f', 'l'))
     assert relerr(b2.signal.norm2d().values, R.norm2d(b2.values)) < TOL
     assert b2.signal.correlate2d(b2).shape == (15, 127)
+
+
+def test_lazy_single_process_writes_resumes_and_skips(ctx, tmp_path):
+    """core.lazy.single_process (core/lazy.py:26-82): process a (pair, day) file, write it, and on the next
+    call skip it; a file with missing steps is resumed with retry_missing and only the new steps run."""
+    from xcorr_amd import io
+    from xcorr_amd.core import lazy
+    fs, wl = 50., 60.
+    t0 = 1580688000.0                                            # 2020-02-03T00:00:00Z
+    rng = np.random.default_rng(5)
+    T = int(600 * fs)
+    tr = {'NL.A..HHZ': rng.standard_normal(T).astype(np.float32), 'NL.B..HHZ': rng.standard_normal(T).astype(np.float32)}
+    pair = 'NL.A..HHZ-NL.B..HHZ'
+    args = dict(preprocess={}, attrs={'institution': 'i', 'author': 'a', 'source': 's'}, sampling_rate=fs,
+                window_length=wl, window_overlap=.5, clip_lag=(-5., 5.))
+
+    class Counting(core.ArrayClient):
+        calls = 0
+
+        def get_pair_processed_waveforms(self, **kw):
+            Counting.calls += 1
+            return super().get_pair_processed_waveforms(**kw)
+    # the record covers only the first 10 minutes of the "day" (step = 20 min): later windows are missing
+    cl = Counting(tr, fs, t0=t0)
+    assert lazy.single_process(pair, t0, args, cl, str(tmp_path), step=1200.) is True
+    ds = io.read(io.ncfile(pair, t0, str(tmp_path)))
+    n_ok, n_missing = int((ds.status == 1).sum()), int((ds.status == -1).sum())
+    assert n_ok >= 17 and n_missing >= 18 and n_ok + n_missing == ds.status.size
+    ref = R.cc(tr['NL.A..HHZ'][1500:4500], tr['NL.B..HHZ'][1500:4500], normalize=True, dtype=np.float64)
+    k = int(np.flatnonzero(ds.status[0] == 1)[1])
+    la = ds.lag_attrs
+    assert relerr(ds.cc[0, k], ref[la['index_min']:la['index_max']]) < TOL
+    # resume with the full record: only the missing steps are fetched again
+    tr2 = {k2: np.concatenate([v, rng.standard_normal(T).astype(np.float32)]) for k2, v in tr.items()}
+    Counting.calls = 0
+    assert lazy.single_process(pair, t0, args, Counting(tr2, fs, t0=t0), str(tmp_path), step=1200.) is True
+    assert Counting.calls == n_missing
+    ds2 = io.read(io.ncfile(pair, t0, str(tmp_path)))
+    assert (ds2.status == 1).sum() > n_ok and np.array_equal(ds2.cc[0, k], ds.cc[0, k])

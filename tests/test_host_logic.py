@@ -1,4 +1,6 @@
 """CPU: host-side mirrors of the reference interface (no GPU work)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -194,3 +196,52 @@ def test_init_reference_signature():
     # the build's earlier numeric form keeps working
     old = core.init('A-B', 0., 86400., 50., 3600., .5)
     assert len(old.time) == 48 and old.time_attrs['window_overlap'] == .5 and not old.time_is_datetime
+
+
+def test_io_roundtrip_naming_and_skip_if_done(tmp_path):
+    """f4 plumbing (io/write.py:31-184, io/filesystem.py:88-95, core/lazy.py:52-58): file scheme,
+    write-through-temporary, empty datasets are not written, hash-checked read, and the resume logic
+    returns early (no GPU) when every step of the file is processed."""
+    import warnings
+    from xcorr_amd import io
+    from xcorr_amd.core import lazy
+    pair = 'NL.A..HHZ-NL.B..HHZ'
+    att = {'institution': 'i', 'author': 'a', 'source': 's'}
+    args = dict(preprocess={'HHZ': [('detrend', {'type': 'demean'})]}, attrs=att, sampling_rate=50.,
+                window_length=600., window_overlap=.5, clip_lag=(-10., 10.))
+    ds = core.init(pair, '2020-02-03', '2020-02-04', **args)
+    path = io.ncfile(pair, ds.time[0], str(tmp_path))
+    assert path.endswith(os.path.join('2020', pair, pair + '.2020.034.nc'))
+    assert io.ncfile(pair, np.datetime64('2021-12-31T10:00'), None) == os.path.join('2021', pair, pair + '.2021.365.nc')
+    with pytest.raises(TypeError):
+        io.ncfile(17, 0.)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        assert io.write(ds, path) is False and not os.path.exists(path) and 'no data' in str(w[0].message)
+    assert io.read(path) is None
+    ds.cc[...] = np.random.default_rng(0).standard_normal(ds.cc.shape).astype(np.float32)
+    ds.status[...] = 1
+    ds.status[0, 3] = -1
+    ds.pair_offset[0, 2] = 0.004
+    assert io.write(ds, path) is True and not [f for f in os.listdir(os.path.dirname(path)) if f.endswith('.tmp')]
+    r = io.read(path)
+    assert np.array_equal(r.cc, ds.cc) and np.array_equal(r.status, ds.status) and np.array_equal(r.pair_offset, ds.pair_offset)
+    assert np.array_equal(r.time, ds.time) and np.allclose(r.lag, ds.lag) and list(r.pair) == [pair] and r.time_is_datetime
+    assert r.lag_attrs['index_min'] == ds.lag_attrs['index_min'] and r.lag_attrs['npts'] == 30000
+    assert r.cc_attrs['normalize'] == 1 and r.time_attrs['window_overlap'] == .5 and r.attrs['institution'] == 'i'
+    assert io.validate(r)
+    # corrupt one data byte: the stored sha256 no longer matches
+    raw = bytearray(open(path, 'rb').read())
+    raw[len(raw) // 2] ^= 0xff                          # the middle of the file lies inside cc
+    open(path, 'wb').write(raw)
+    with pytest.raises(ValueError, match='sha256'):
+        io.read(path)
+    assert io.read(path, quick_and_dirty=True) is not None
+    # resume: a fully processed day is skipped without initialising anything
+    ds.status[...] = 1
+    io.write(ds, path)
+
+    class NoClient:
+        def get_pair_processed_waveforms(self, **kw):
+            raise AssertionError('a finished file must not be reprocessed')
+    assert lazy.single_process(pair, '2020-02-03', args, NoClient(), str(tmp_path)) is True

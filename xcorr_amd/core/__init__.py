@@ -2,6 +2,7 @@
 from .init import init, CCDataset  # noqa: F401
 from .process import process, process_batched  # noqa: F401
 from .client import ArrayClient  # noqa: F401
-from .postprocess import postprocess  # noqa: F401
+from .postprocess import postprocess, postprocess_rows  # noqa: F401
+from . import lazy  # noqa: F401
 
-__all__ = ['init', 'process', 'process_batched', 'postprocess', 'CCDataset', 'ArrayClient']
+__all__ = ['init', 'process', 'process_batched', 'postprocess', 'postprocess_rows', 'lazy', 'CCDataset', 'ArrayClient']
