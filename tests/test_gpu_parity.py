@@ -85,8 +85,14 @@ def test_sizes_and_planner(ctx, n):
 
 def test_unsupported_and_invalid_arguments(ctx):
     from xcorr_amd._ffi import XcxError
+    # beyond the largest single transform: a segmented plan, except for flags it cannot serve
+    big = X.CCPlan(ctx, 400000)
+    assert big.N == 368640 and big.L == 799999
+    big.close()
     with pytest.raises(XcxError, match='no supported transform length'):
-        X.CCPlan(ctx, 400000)
+        X.CCPlan(ctx, 400000, stack=True)
+    with pytest.raises(XcxError, match='no supported transform length'):
+        X.CCPlan(ctx, 400000, nfft=1000000)
     with pytest.raises(XcxError, match='lag slice'):
         X.CCPlan(ctx, 100, index_min=150, index_max=100)
     with pytest.raises(XcxError, match='n must be'):

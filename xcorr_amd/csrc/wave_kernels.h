@@ -59,6 +59,12 @@ XCX_DEV unsigned long long stamp_nowait(float pin) {
 #define XCX_STAMP_NW(i, pin)
 #endif
 
+#ifdef XCX_ABLATE_WIDE
+#define XCX_ABLATE_WIDE_X 1
+#define XCX_ABLATE_WIDE_TS 1
+#define XCX_ABLATE_WIDE_TL 1
+#endif
+
 // minimum waves per SIMD the register allocator must leave room for
 #ifndef XCX_COL_WAVES
 #define XCX_COL_WAVES 1
@@ -396,7 +402,12 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
   // last-stage slots rotated so that lane l holds the residues res = l (mod 64): every T store
   // instruction then writes ONE aligned 512-byte run of a 64-row tile (four whole lines) instead
   // of the tail of one tile and the head of the next
-  const int ltid = ColRot<RX>::ok ? ((tid_of<kWNT>() - shift) & (kWNT - 1)) : tid_of<kWNT>();
+  // With NSL = 64 the stores go out as lane PAIRS (below): lanes 0..31 are given the even residues
+  // 0, 2, .., 62 and lanes 32..63 the odd ones, so that one v_permlane32_swap per register pair hands
+  // lane L rows (2L, 2L+1) of an even tile and lane 32+L the same rows of the next tile.
+  constexpr bool kPairStore = ColRot<RX>::ok && (CG::RL % 2 == 0) && (CG::Last::IT == 1) && (CG::NSL == kTR);
+  const int rlane = kPairStore ? (2 * (tid_of<kWNT>() & 31) + (tid_of<kWNT>() >> 5)) : tid_of<kWNT>();   // residue mod 64
+  const int ltid = ColRot<RX>::ok ? ((rlane - shift) & (kWNT - 1)) : tid_of<kWNT>();
   cf f0[CG::Last::IT];
 #pragma unroll
   for (int it = 0; it < CG::Last::IT; ++it) {
@@ -406,6 +417,25 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
     f0[it] = twN_lookup(twN, (unsigned)((j - k) * CG::RL + k) * kk);
   }
   const cf gstep = twN_lookup(twN, (unsigned)CG::NSL * kk);
+#if defined(XCX_ABLATE_MATH) && defined(XCX_ABLATE_WIDE_X)
+  // bandwidth experiment (values are garbage in this build anyway): the same 2 x 12 KB of column
+  // data as 16-byte loads, two adjacent points per lane
+  int ncall = 0;
+  float4 wa = make_float4(0.f, 0.f, 0.f, 0.f), wb = wa;
+  auto in = [&](int, int) -> cf {
+    cf r;
+    if ((ncall & 1) == 0) {
+      const unsigned e = 2u * (unsigned)tid_of<kWNT>() + 128u * (unsigned)(ncall >> 1);
+      wa = *reinterpret_cast<const float4*>(uoff(A, e));
+      wb = *reinterpret_cast<const float4*>(uoff(Bp, e));
+      r = cmulc(make_float2(wa.x, wa.y), make_float2(wb.x, wb.y));
+    } else {
+      r = cmulc(make_float2(wa.z, wa.w), make_float2(wb.z, wb.w));
+    }
+    ++ncall;
+    return r;
+  };
+#else
   auto in = [=](int k1, int) -> cf {
 #ifdef XCX_SKIP_XLD
     k1 &= 15;                                    // ablation: every load hits the same 128 bytes
@@ -421,8 +451,14 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
       return acc;
     }
   };
+#endif
   cf* __restrict__ Tc = T + k2 * kTR;
   const int trow = (N2h + 1) * kTR;           // float2 per 64-row tile
+  // Pair stores (round 2): every lane ends up with two adjacent rows of one tile and stores 16 bytes;
+  // a wave instruction writes two aligned 512-byte runs, lanes 0..31 one tile and lanes 32..63 the
+  // next, in lane order.  (The lane ORDER matters: the same 16-byte stores with even / odd lanes
+  // alternating between the two runs were no faster than 8-byte stores; in lane order the
+  // no-arithmetic build lost 9 of 80 ms, profiles/r02_ablation.txt.)
   auto epi = [=](int it, int j0, int, cf (&v)[CG::RL]) {
     cf g8 = gstep, f = f0[it];
     if constexpr (CG::RL > 8) g8 = csq(csq(csq(gstep)));
@@ -431,27 +467,67 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
     const unsigned off0 = (unsigned)((res0 >> 6) * trow + (res0 & 63));
     const int twrap = (N1 - res0 + CG::NSL - 1) / CG::NSL;            // first t whose residue wraps
     const unsigned wrapsz = (unsigned)(N1 / kTR) * (unsigned)trow;
-    static_for<CG::RL>([&](auto tc) {
+    static_for<CG::RL>([&](auto tc) {                                 // four-step factors, in place
       constexpr int t = decltype(tc)::value;
       if constexpr (t > 0) {
         if constexpr (t % 8 == 0) { f = f0[it]; static_for<t / 8>([&](auto) { f = cmul(f, g8); }); }
         else f = cmul(f, gstep);
       }
-      // res = (j0 + shift + t NSL) mod N1; with NSL a multiple of 64 the tile offset advances by a
-      // constant per t and wraps once: offset = off0 + t dstep - (t >= twrap ? wrapsz : 0)
-      if constexpr (CG::NSL % kTR == 0) {
-        constexpr unsigned dstep = (unsigned)(CG::NSL / kTR);
-        const unsigned o = off0 + (unsigned)t * dstep * (unsigned)trow - ((t >= twrap) ? wrapsz : 0u);
+      v[t] = cmulc(v[t], f);
+    });
+    if constexpr (kPairStore) {
+      // NSL = 64: lane l holds residue l of the RL = N1/64 tiles a_l + t, a_l = a0 + (l < shift % 64)
+      // (the slot rotation wraps at lane shift % 64).  First bring every lane to the same tile
+      // numbering (w[tau] = tile a0 + tau), then swap within lane pairs.
+      constexpr int NT = CG::RL;
+      const int lane = tid_of<kWNT>();
+      const int a0 = shift >> 6;
+      // lane's residue is rlane (mod 64) in the tiles a0 + (rlane < shift % 64) + t: bring every lane
+      // to the same tile numbering first (w[tau] = tile a0 + tau)
+      const bool ahead = rlane < (shift & 63);
+      const int up = lane >> 5;
+      cf w[NT];
+      static_for<NT>([&](auto tc) {
+        constexpr int tau = decltype(tc)::value;
+        w[tau] = ahead ? v[(tau + NT - 1) % NT] : v[tau];
+      });
+      static_for<NT / 2>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        // lanes [0,32) of w[2u] / w[2u+1]: rows 2L of tiles 2u / 2u+1; lanes [32,64): rows 2L+1.
+        // swap(upper half of the first, lower half of the second):
+        //   first  -> lanes [0,32): tile 2u row 2L    | lanes [32,64): tile 2u+1 row 2L
+        //   second -> lanes [0,32): tile 2u row 2L+1  | lanes [32,64): tile 2u+1 row 2L+1
+        const auto sx = __builtin_amdgcn_permlane32_swap(__float_as_uint(w[2 * u].x), __float_as_uint(w[2 * u + 1].x), false, false);
+        const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(w[2 * u].y), __float_as_uint(w[2 * u + 1].y), false, false);
+        int tile = a0 + 2 * u + up;
+        if (tile >= NT) tile -= NT;
+        const unsigned o = (unsigned)tile * (unsigned)trow + 2u * (unsigned)(lane & 31);
 #ifdef XCX_SKIP_TST
         if (N2h == -1)                             // ablation: never true at run time
 #endif
-        *uoff(Tc, o) = cmulc(v[t], f);
-      } else {
-        int res = j0 + t * CG::NSL + shift;
-        if (res >= N1) res -= N1;
-        *uoff(Tc, (unsigned)((res >> 6) * trow + (res & 63))) = cmulc(v[t], f);
-      }
-    });
+        *reinterpret_cast<float4*>(uoff(Tc, o)) =
+            make_float4(__uint_as_float(sx[0]), __uint_as_float(sy[0]), __uint_as_float(sx[1]), __uint_as_float(sy[1]));
+      });
+      (void)off0; (void)twrap; (void)wrapsz;
+    } else {
+      static_for<CG::RL>([&](auto tc) {
+        constexpr int t = decltype(tc)::value;
+        // res = (j0 + shift + t NSL) mod N1; with NSL a multiple of 64 the tile offset advances by a
+        // constant per t and wraps once: offset = off0 + t dstep - (t >= twrap ? wrapsz : 0)
+        if constexpr (CG::NSL % kTR == 0) {
+          constexpr unsigned dstep = (unsigned)(CG::NSL / kTR);
+          const unsigned o = off0 + (unsigned)t * dstep * (unsigned)trow - ((t >= twrap) ? wrapsz : 0u);
+#ifdef XCX_SKIP_TST
+          if (N2h == -1)
+#endif
+          *uoff(Tc, o) = v[t];
+        } else {
+          int res = j0 + t * CG::NSL + shift;
+          if (res >= N1) res -= N1;
+          *uoff(Tc, (unsigned)((res >> 6) * trow + (res & 63))) = v[t];
+        }
+      });
+    }
   };
   wave_col_fft<RX, true>(lds, tw_sub, in, epi, ltid XCX_ST_ARG);
   XCX_STAMP_NW(7, gstep.x);                          // T stores issued
@@ -614,9 +690,26 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
     const int jp = (j == 0) ? 0 : (S - j);
     const bool single = jp == j;
     cf av[R], bv[R];
+#if defined(XCX_ABLATE_MATH) && defined(XCX_ABLATE_WIDE_TL)
+    // bandwidth experiment: this wave's 16 KB share of the tile as 16-byte loads, 1 KB per instruction
+    {
+      const cf* __restrict__ Tw = Tt - (blk & 3) * kWRB;                 // tile base
+      static_assert(R % 2 == 0, "pairs");
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const unsigned e = ((unsigned)(blk & 3) * 2u * (unsigned)R + (unsigned)(it * R + u)) * 128u + 2u * (unsigned)lane;
+        const unsigned emax = (unsigned)(N2h + 1) * kTR - 2u;
+        const float4 q = *reinterpret_cast<const float4*>(uoff(Tw, e < emax ? e : (emax & ~1u)));
+        if (u < R / 2) { av[2 * u] = make_float2(q.x, q.y); av[2 * u + 1] = make_float2(q.z, q.w); }
+        else { bv[2 * (u - R / 2)] = make_float2(q.x, q.y); bv[2 * (u - R / 2) + 1] = make_float2(q.z, q.w); }
+      }
+    }
+    if (false) {
+#else
 #pragma unroll
     for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(uoff(Tt, (unsigned)((j + S * t) * kTR + r)));
     if (!single) {
+#endif
 #pragma unroll
       for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(uoff(Tt, (unsigned)((jp + S * t) * kTR + r)));
     } else if (j == 0) {
