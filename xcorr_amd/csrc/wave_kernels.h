@@ -16,10 +16,10 @@
 // Layouts (all chosen so that every global access of a wave instruction is a
 // run of full 128-byte lines):
 //   Tf / X : [k2 in 0..N2h][N1]        column-major, Nyquist = column N2h
-//   T      : [res >> 6][k2 in 0..N2h][res & 63]   64-row tiles, where
-//            res = (m1 + shift) mod N1 is the OUTPUT residue of row m1
-//            (slots k2 = 0 and N2h are real: only .x is consumed); a row wave
-//            owns the 16-row quarter (res >> 4) & 3 of a tile
+//   T      : [res >> 6][(res >> 4) & 3][k2 in 0..N2h][res & 15]   64-row tiles of
+//            four contiguous 16-row quarters, where res = (m1 + shift) mod N1 is
+//            the OUTPUT residue of row m1 (slots k2 = 0 and N2h are real: only
+//            .x is consumed); a row wave owns one quarter
 //
 // The C2R row kernel reads each T element exactly once: butterflies j and
 // S-j of its first stage are computed by the same lane, which therefore holds
@@ -73,15 +73,18 @@ XCX_DEV unsigned long long stamp_nowait(float pin) {
 #define XCX_ROW_WAVES 1
 #endif
 constexpr int kWRB = 16;     // rows per wave
-constexpr int kTR = 64;      // rows per T tile: T = [res >> 6][k2 in 0..N2h][res & 63]; a column wave (one k2)
-                             // stores 64 consecutive residues = 512 contiguous bytes per instruction, and the four
-                             // row waves of a workgroup read the four 16-row quarters of one tile
+constexpr int kTR = 64;      // rows per T tile: T = [res >> 6][(res >> 4) & 3][k2 in 0..N2h][res & 15]: the four
+                             // row waves of a workgroup own the four 16-row quarters of one tile, and a quarter
+                             // ([k2][16 rows], 15.5 KB) is contiguous so that its wave streams it with 16-byte loads
 constexpr int kWNT = 64;     // one wave
 constexpr int kWPB = 4;      // independent waves packed into one 256-thread workgroup
 
 // per-wave LDS footprints (floats), 16-byte aligned
 constexpr int lds_col_floats(int L) { return (L + (L >> 3) + 1 + 3) & ~3; }
-constexpr int lds_row_floats(int L) { return ((L + (L >> 3) + 1) * 16 + 3) & ~3; }
+constexpr int lds_row_exch_floats(int L) { return ((L + (L >> 3) + 1) * 16 + 3) & ~3; }
+// ... or the transpose buffer of the wide T loads: up to 8 wave loads of 1 KB (64 k2 x 16 rows x 8 B)
+constexpr int lds_row_wide_floats(int L) { return ((L + 1 + 7) / 8 < 8 ? (L + 1 + 7) / 8 : 8) * 256; }
+constexpr int lds_row_floats(int L) { return lds_row_exch_floats(L) > lds_row_wide_floats(L) ? lds_row_exch_floats(L) : lds_row_wide_floats(L); }
 constexpr int lds_frow_floats(int L) { return L * 16 * 2; }
 // wave-uniform BY CONSTRUCTION: readfirstlane tells the compiler so, and everything derived from it
 // (work item, descriptor, column / tile base pointers) lives in SGPRs -- descriptor loads become
@@ -89,9 +92,9 @@ constexpr int lds_frow_floats(int L) { return L * 16 * 2; }
 // per-lane 64-bit addresses
 XCX_DEV int wave_in_group() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
-// the 16-row quarter `blk & 3` of T tile `blk >> 2` of one pair-window
+// the 16-row quarter `blk & 3` of T tile `blk >> 2` of one pair-window: [k2][16 rows], contiguous
 XCX_DEV const cf* t_quarter(const cf* __restrict__ Tpw, int blk, int N2h) {
-  return Tpw + (size_t)((blk >> 2) * (N2h + 1)) * kTR + (blk & 3) * kWRB;
+  return Tpw + (size_t)((blk >> 2) * (N2h + 1)) * kTR + (size_t)(blk & 3) * (N2h + 1) * kWRB;
 }
 // staging buffer of the workgroup-cooperative CCF store: (N2h + 1) lag blocks x 64 rows of float
 constexpr int lds_stage_floats(int N2h) { return (N2h + 1) * kTR; }
@@ -452,19 +455,23 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
     }
   };
 #endif
-  cf* __restrict__ Tc = T + k2 * kTR;
+  cf* __restrict__ Tc = T + k2 * kWRB;
   const int trow = (N2h + 1) * kTR;           // float2 per 64-row tile
+  const int qrow = (N2h + 1) * kWRB;          // float2 per 16-row quarter
+  auto roff = [=](int r64) -> unsigned {      // row r64 of a tile (this wave's k2): quarter, row inside it
+    return (unsigned)((r64 >> 4) * qrow + (r64 & 15));
+  };
   // Pair stores (round 2): every lane ends up with two adjacent rows of one tile and stores 16 bytes;
-  // a wave instruction writes two aligned 512-byte runs, lanes 0..31 one tile and lanes 32..63 the
-  // next, in lane order.  (The lane ORDER matters: the same 16-byte stores with even / odd lanes
-  // alternating between the two runs were no faster than 8-byte stores; in lane order the
-  // no-arithmetic build lost 9 of 80 ms, profiles/r02_ablation.txt.)
+  // a wave instruction writes lanes 0..31 to one tile and lanes 32..63 to the next, in lane order,
+  // as eight full 128-byte lines.  Measured neutral against 8-byte stores (the write side of this
+  // pass is not what limits it, profiles/r02_ablation.txt); kept because it halves the store
+  // instructions of the column wave.
   auto epi = [=](int it, int j0, int, cf (&v)[CG::RL]) {
     cf g8 = gstep, f = f0[it];
     if constexpr (CG::RL > 8) g8 = csq(csq(csq(gstep)));
     int res0 = j0 + shift;
     if (res0 >= N1) res0 -= N1;
-    const unsigned off0 = (unsigned)((res0 >> 6) * trow + (res0 & 63));
+    const unsigned off0 = (unsigned)((res0 >> 6) * trow) + roff(res0 & 63);
     const int twrap = (N1 - res0 + CG::NSL - 1) / CG::NSL;            // first t whose residue wraps
     const unsigned wrapsz = (unsigned)(N1 / kTR) * (unsigned)trow;
     static_for<CG::RL>([&](auto tc) {                                 // four-step factors, in place
@@ -501,7 +508,7 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
         const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(w[2 * u].y), __float_as_uint(w[2 * u + 1].y), false, false);
         int tile = a0 + 2 * u + up;
         if (tile >= NT) tile -= NT;
-        const unsigned o = (unsigned)tile * (unsigned)trow + 2u * (unsigned)(lane & 31);
+        const unsigned o = (unsigned)tile * (unsigned)trow + roff(2 * (lane & 31));
 #ifdef XCX_SKIP_TST
         if (N2h == -1)                             // ablation: never true at run time
 #endif
@@ -524,7 +531,7 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
         } else {
           int res = j0 + t * CG::NSL + shift;
           if (res >= N1) res -= N1;
-          *uoff(Tc, (unsigned)((res >> 6) * trow + (res & 63))) = v[t];
+          *uoff(Tc, (unsigned)((res >> 6) * trow) + roff(res & 63)) = v[t];
         }
       });
     }
@@ -590,6 +597,9 @@ template <bool SC1> XCX_DEV cf load_t(const cf* p) {
 #ifndef XCX_BUFSTORE
 #define XCX_BUFSTORE 1
 #endif
+#ifndef XCX_ROW_WIDE
+#define XCX_ROW_WIDE 0        // 16-byte T loads + LDS transpose in the row pass (0: one 8-byte load per butterfly input)
+#endif
 // COOP: the four waves of the workgroup own the four quarters of ONE 64-row tile (blk = 4 wgblk +
 // wave) of one pair-window and store the CCF together: every wave parks its 16 x 2 N2h values in
 // the workgroup's LDS as [lag block][64 rows], and the workgroup then writes 16 bytes per lane,
@@ -615,115 +625,22 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
   stage_tw_base<N2h, RX::R1, RX::R0, kWRB, kWNT>(tw_sub, b1);
 
   // ---- stage 0: paired butterflies (j, S-j) with the Hermitian untangle ----
-#ifdef XCX_STAMPS
   cf s0a[IT][R], s0b[IT][R];
-  auto load_it = [&](int it, cf (&av)[R], cf (&bv)[R]) {
-    const int w = lane + it * kWNT;
-    if ((TOTAL % kWNT) != 0 && w >= TOTAL) return;
-    const int r = w % kWRB;
-    const int j = w / kWRB;                       // 0..S/2
-    const int jp = (j == 0) ? 0 : (S - j);
-    const bool single = jp == j;
+  // Hermitian untangle, shared by the pair: with h = H[k] (k = j + S t),
+  // g = H[N2h-k] = bv[R-1-t], e = e^{+2 pi i k/N2} = conj(twu[j]) e^{+2 pi i t/(2R)}
+  //   sm = h + conj g,  ed = e (h - conj g)
+  //   U_j [t]     = sm + i ed
+  //   U_j'[R-1-t] = conj(sm) + i conj(ed)      (because e_{N2h-k} = -conj e_k)
+  auto untangle = [&](int it, int j, bool single, cf (&av)[R], cf (&bv)[R], float ny) {
+    if (single) {
+      if (j == 0) {
 #pragma unroll
-    for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(uoff(Tt, (unsigned)((j + S * t) * kTR + r)));
-    if (!single) {
+        for (int t = 0; t < R; ++t) bv[t] = av[(t + 1) % R];   // mirror of S*t' is S*(R-t')
+      } else {
 #pragma unroll
-      for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(uoff(Tt, (unsigned)((jp + S * t) * kTR + r)));
-    } else if (j == 0) {
-#pragma unroll
-      for (int t = 0; t < R; ++t) bv[t] = av[(t + 1) % R];   // mirror of S*t' is S*(R-t')
-    } else {
-#pragma unroll
-      for (int t = 0; t < R; ++t) bv[t] = av[t];             // j = S/2 mirrors inside itself
-    }
-  };
-  auto compute_it = [&](int it, cf (&av)[R], cf (&bv)[R]) {
-    const int w = lane + it * kWNT;
-    if ((TOTAL % kWNT) != 0 && w >= TOTAL) return;
-    const int r = w % kWRB;
-    const int j = w / kWRB;
-    const int jp = (j == 0) ? 0 : (S - j);
-    const bool single = jp == j;
-    // Hermitian untangle, shared by the pair: with h = H[k] (k = j + S t),
-    // g = H[N2h-k] = bv[R-1-t], e = e^{+2 pi i k/N2} = conj(twu[j]) e^{+2 pi i t/(2R)}
-    //   sm = h + conj g,  ed = e (h - conj g)
-    //   U_j [t]     = sm + i ed
-    //   U_j'[R-1-t] = conj(sm) + i conj(ed)      (because e_{N2h-k} = -conj e_k)
-    const cf ej = cconj(*uoff(twu, (unsigned)j));
-    cf uj[R], ujp[R];
-    static_for<R>([&](auto tc) {
-      constexpr int t = decltype(tc)::value;
-      const cf h = av[t], hb = cconj(bv[R - 1 - t]);
-      const cf sm = cadd(h, hb), df = csub(h, hb);
-      const cf ed = cmul(mul_wconst<t, 2 * R, true>(ej), df);
-      uj[t] = make_float2(sm.x - ed.y, sm.y + ed.x);
-      ujp[R - 1 - t] = make_float2(sm.x + ed.y, ed.x - sm.y);
-    });
-    if (j == 0) {                                  // DC and Nyquist of the row are real
-      const float dc = av[0].x, ny = load_t<SC1>(uoff(Tt, (unsigned)(N2h * kTR + r))).x;
-      uj[0] = make_float2(dc + ny, dc - ny);
-    }
-    Bfly<R, true>::run(uj);
-    if (!single) Bfly<R, true>::run(ujp);
-    // Stockham positions of stage 0 (NS = 1): butterfly j -> j*R + t; real and
-    // imaginary parts go through the half-size LDS buffer in two rounds below
-#pragma unroll
-    for (int t = 0; t < R; ++t) { s0a[it][t] = uj[t]; s0b[it][t] = ujp[t]; }
-  };
-  {
-    cf av_all[IT][R], bv_all[IT][R];
-#pragma unroll
-    for (int it = 0; it < IT; ++it) load_it(it, av_all[it], bv_all[it]);
-    XCX_STAMP(1, av_all[0][0].x);                  // T tile has arrived
-#pragma unroll
-    for (int it = 0; it < IT; ++it) compute_it(it, av_all[it], bv_all[it]);
-    XCX_STAMP(2, s0a[0][0].x);
-  }
-#else
-  cf s0a[IT][R], s0b[IT][R];
-#pragma unroll
-  for (int it = 0; it < IT; ++it) {
-    const int w = lane + it * kWNT;
-    if ((TOTAL % kWNT) != 0 && w >= TOTAL) continue;
-    const int r = w % kWRB;
-    const int j = w / kWRB;                       // 0..S/2
-    const int jp = (j == 0) ? 0 : (S - j);
-    const bool single = jp == j;
-    cf av[R], bv[R];
-#if defined(XCX_ABLATE_MATH) && defined(XCX_ABLATE_WIDE_TL)
-    // bandwidth experiment: this wave's 16 KB share of the tile as 16-byte loads, 1 KB per instruction
-    {
-      const cf* __restrict__ Tw = Tt - (blk & 3) * kWRB;                 // tile base
-      static_assert(R % 2 == 0, "pairs");
-#pragma unroll
-      for (int u = 0; u < R; ++u) {
-        const unsigned e = ((unsigned)(blk & 3) * 2u * (unsigned)R + (unsigned)(it * R + u)) * 128u + 2u * (unsigned)lane;
-        const unsigned emax = (unsigned)(N2h + 1) * kTR - 2u;
-        const float4 q = *reinterpret_cast<const float4*>(uoff(Tw, e < emax ? e : (emax & ~1u)));
-        if (u < R / 2) { av[2 * u] = make_float2(q.x, q.y); av[2 * u + 1] = make_float2(q.z, q.w); }
-        else { bv[2 * (u - R / 2)] = make_float2(q.x, q.y); bv[2 * (u - R / 2) + 1] = make_float2(q.z, q.w); }
+        for (int t = 0; t < R; ++t) bv[t] = av[t];             // j = S/2 mirrors inside itself
       }
     }
-    if (false) {
-#else
-#pragma unroll
-    for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(uoff(Tt, (unsigned)((j + S * t) * kTR + r)));
-    if (!single) {
-#endif
-#pragma unroll
-      for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(uoff(Tt, (unsigned)((jp + S * t) * kTR + r)));
-    } else if (j == 0) {
-#pragma unroll
-      for (int t = 0; t < R; ++t) bv[t] = av[(t + 1) % R];   // mirror of S*t' is S*(R-t')
-    } else {
-#pragma unroll
-      for (int t = 0; t < R; ++t) bv[t] = av[t];             // j = S/2 mirrors inside itself
-    }
-    // Hermitian untangle, shared by the pair: with h = H[k] (k = j + S t),
-    // g = H[N2h-k] = bv[R-1-t], e = e^{+2 pi i k/N2} = conj(twu[j]) e^{+2 pi i t/(2R)}
-    //   sm = h + conj g,  ed = e (h - conj g)
-    //   U_j [t]     = sm + i ed
-    //   U_j'[R-1-t] = conj(sm) + i conj(ed)      (because e_{N2h-k} = -conj e_k)
     const cf ej = cconj(*uoff(twu, (unsigned)j));
     cf uj[R], ujp[R];
     static_for<R>([&](auto tc) {
@@ -735,7 +652,7 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
       ujp[R - 1 - t] = make_float2(sm.x + ed.y, ed.x - sm.y);
     });
     if (j == 0) {                                  // DC and Nyquist of the row are real
-      const float dc = av[0].x, ny = load_t<SC1>(uoff(Tt, (unsigned)(N2h * kTR + r))).x;
+      const float dc = av[0].x;
       uj[0] = make_float2(dc + ny, dc - ny);
     }
     Bfly<R, true>::run(uj);
@@ -744,8 +661,85 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
     // imaginary parts go through the half-size LDS buffer in two rounds below
 #pragma unroll
     for (int t = 0; t < R; ++t) { s0a[it][t] = uj[t]; s0b[it][t] = ujp[t]; }
+  };
+  if constexpr (!SC1 && XCX_ROW_WIDE) {
+    // The quarter ([k2][16 rows], (N2h + 1) x 128 bytes, contiguous) streams in as 16-byte loads,
+    // 1 KB per wave instruction, and is transposed to the butterfly inputs through the wave's own
+    // LDS slice, 64 k2 (8 loads) at a time.  8-byte loads of 128-byte runs (one per butterfly
+    // input) cost the no-arithmetic build 8.5 of 80 ms more (profiles/r02_ablation.txt).
+    constexpr int NK = N2h + 1;
+    constexpr int NL = (NK + 7) / 8;               // wave loads
+    constexpr int NP = (NL + 7) / 8;               // LDS passes
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 q[NL];
+    static_for<NL>([&](auto uc) {
+      constexpr int u = decltype(uc)::value;
+      unsigned e = (unsigned)(u * 128) + 2u * (unsigned)lane;
+      constexpr unsigned emax = (unsigned)(NK * kWRB - 2);
+      if constexpr (u * 128 + 126 > NK * kWRB - 2) e = e < emax ? e : emax;     // last load: stay inside the quarter
+      q[u] = *reinterpret_cast<const f32x4*>(uoff(Tt, e));
+    });
+    cf av[IT][R], bv[IT][R];
+    float ny[IT];
+    f32x4* __restrict__ ldsq = reinterpret_cast<f32x4*>(lds);
+    static_for<NP>([&](auto pc) {
+      constexpr int p = decltype(pc)::value;
+      static_for<(NL - p * 8 < 8 ? NL - p * 8 : 8)>([&](auto uc) {
+        constexpr int u = decltype(uc)::value;
+        ldsq[u * 64 + lane] = q[p * 8 + u];
+      });
+      group_sync<kWNT>();
+      static_for<IT>([&](auto ic) {
+        constexpr int it = decltype(ic)::value;
+        const int w = lane + it * kWNT;
+        if ((TOTAL % kWNT) == 0 || w < TOTAL) {
+          const int r = w % kWRB;
+          const int j = w / kWRB;                  // 0..S/2
+          const int jp = (j == 0) ? 0 : (S - j);
+          static_for<R>([&](auto tc) {
+            constexpr int t = decltype(tc)::value;
+            const int ka = j + S * t, kb = jp + S * t;
+            if ((ka >> 6) == p) av[it][t] = lds[(ka - 64 * p) * kWRB + r];
+            if (jp != j && (kb >> 6) == p) bv[it][t] = lds[(kb - 64 * p) * kWRB + r];
+          });
+          if constexpr ((N2h >> 6) == p) ny[it] = lds[(N2h - 64 * p) * kWRB + r].x;
+        }
+      });
+      group_sync<kWNT>();
+    });
+    XCX_STAMP(1, av[0][0].x);                      // T quarter has arrived
+    static_for<IT>([&](auto ic) {
+      constexpr int it = decltype(ic)::value;
+      const int w = lane + it * kWNT;
+      if ((TOTAL % kWNT) == 0 || w < TOTAL) {
+        const int j = w / kWRB;
+        const int jp = (j == 0) ? 0 : (S - j);
+        untangle(it, j, jp == j, av[it], bv[it], ny[it]);
+      }
+    });
+    XCX_STAMP(2, s0a[0][0].x);
+  } else {
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int w = lane + it * kWNT;
+      if ((TOTAL % kWNT) != 0 && w >= TOTAL) continue;
+      const int r = w % kWRB;
+      const int j = w / kWRB;                       // 0..S/2
+      const int jp = (j == 0) ? 0 : (S - j);
+      const bool single = jp == j;
+      cf av[R], bv[R];
+#pragma unroll
+      for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(uoff(Tt, (unsigned)((j + S * t) * kWRB + r)));
+      if (!single) {
+#pragma unroll
+        for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(uoff(Tt, (unsigned)((jp + S * t) * kWRB + r)));
+      }
+      float ny = 0.f;
+      if (j == 0) ny = load_t<SC1>(uoff(Tt, (unsigned)(N2h * kWRB + r))).x;
+      untangle(it, j, single, av, bv, ny);
+    }
+    XCX_STAMP(2, s0a[0][0].x);
   }
-#endif
   float* __restrict__ ldsf = reinterpret_cast<float*>(lds);
   using G1 = StageGeom<N2h, RX::R1, RX::R0, kWRB, kWNT>;
   cf v1[G1::IT][RX::R1];
