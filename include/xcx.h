@@ -239,6 +239,16 @@ int xcx_snr(xcx_ctx* ctx, const float* x, long batch, long n,
 int xcx_timeshift(xcx_ctx* ctx, const float* x, float* y, long batch, long size,
                   const double* delay, double sampling_rate, int on_device);
 
+/* timeshift(..., fast=False) of xcorr/signal/timeshift.py:90-96: the fft / ifft path
+ * (signal/fft.py:104-113, 239-241).  x, y: [batch][size] (every sample kept);
+ * delay: [batch] host doubles (seconds); delta: sample spacing (rounded to 1e-10
+ * like the reference's frequency axis).  Even size: the same period-`size` shift
+ * as xcx_timeshift up to the frequency-axis rounding.  Odd size: the reference's
+ * second fftshift leaves the spectrum rolled by one bin and real() of the result
+ * is the shifted row times cos(2 pi m / size); reproduced literally. */
+int xcx_timeshift_fft(xcx_ctx* ctx, const float* x, float* y, long batch, long size,
+                      const double* delay, double delta, int on_device);
+
 /* Two-dimensional cross-correlation of tiles (xcorr/signal/correlate.py:162-291
  * with norm2d of signal/normalize.py:95-155; the inner call of
  * scripts/timelapse.py:243-268 which keeps max and argmax only).
@@ -316,6 +326,16 @@ int xcx_block_rms(xcx_ctx* ctx, const float* x, float* y, long batch, long n, lo
 int xcx_spectrogram(xcx_ctx* ctx, const float* x, float* S, long batch, long n,
                     int win_len, int nfft, const double* window, double scale,
                     int detrend, int on_device);
+
+/* Segmented spectrogram with any hop: scipy.signal.spectrogram(x, nperseg=win_len,
+ * noverlap=win_len-hop, nfft, window, detrend, mode='psd') as called by
+ * spectrogram_mtc, xcorr/signal/spectrogram.py:266-276.  x [batch][n] ->
+ * S [batch][nfft/2+1][nseg], nseg = (n - win_len)/hop + 1, segment s starts at
+ * sample s*hop.  window / scale / detrend as for xcx_spectrogram.  Segments are
+ * framed on the device and transformed by the any-length DFT (nfft <= 184320). */
+int xcx_spectrogram_seg(xcx_ctx* ctx, const float* x, float* S, long batch, long n,
+                        int win_len, long hop, int nfft, const double* window,
+                        double scale, int detrend, int on_device);
 
 /* ---- multi-GPU time-stack reduction (RCCL over xGMI) --------------------
  * One communicator per process/GPU.  id_bytes is the 128-byte ncclUniqueId

@@ -299,6 +299,22 @@ def timeshift(x, delay, sampling_rate):
     return np.fft.irfft(X, n=n, axis=-1).astype(x.dtype)
 
 
+def timeshift_fft(x, delay, delta):
+    """fast=False (signal/timeshift.py:90-96): ``X = fftshift(fft(x))`` on
+    ``f = fftshift(fftfreq(n, round(delta, 10)))`` (fft.py:104-113), phase ramp,
+    ``real(ifft(fftshift(X)))`` (fft.py:239-241 -- fftshift again, literally:
+    for odd n that leaves the spectrum rolled by one bin)."""
+    x = np.asarray(x)
+    n = x.shape[-1]
+    d = np.round(np.fabs(delta), decimals=10)
+    f = np.fft.fftshift(np.fft.fftfreq(n, d=d))
+    X = np.fft.fftshift(np.fft.fft(x.astype(np.complex128), n=n, axis=-1), axes=-1)
+    delay = np.asarray(delay, dtype=np.float64)[..., None]
+    X = X * np.exp(-1j * 2 * np.pi * delay * f)
+    y = np.fft.ifft(np.fft.fftshift(X, axes=-1), n=n, axis=-1)
+    return np.real(y).astype(x.dtype)
+
+
 # --------------------------------------------------------------------------
 # signal/snr.py:107-116, signal/rms.py:52-58  (envelope=False)
 # --------------------------------------------------------------------------
@@ -686,3 +702,21 @@ def spectrogram(x, sampling_rate, duration, padding_factor=2, scaling='density',
     npad = [(0, 0)] * (Sxx.ndim - 1) + [(edge, x.shape[-1] - Sxx.shape[-1] - edge)]
     freq = np.linspace(0., sampling_rate / 2, int(nfft / 2 + 1))
     return freq, np.pad(Sxx, pad_width=npad, mode='constant', constant_values=0)
+
+
+def spectrogram_mtc(x, sampling_rate, duration=None, padding_factor=None, overlap=None, **kwargs):
+    """signal/spectrogram.py:253-276: argument defaults as the reference resolves them, then
+    scipy.signal.spectrogram(nperseg, noverlap=int(nperseg*overlap), nfft, 'density', 'psd').
+    Returns (f, t, Sxx[..., nfreq, nseg]); float64."""
+    x = np.asarray(x, dtype=np.float64)
+    delta = 1.0 / sampling_rate
+    padding_factor = padding_factor if (padding_factor and padding_factor >= 1) else 1
+    duration = duration if (duration and duration > delta) else delta
+    win_len = int(duration * sampling_rate)
+    if win_len < 16:
+        raise ValueError('Change duration to have at least 16 sample points!')
+    overlap = overlap if overlap and (0. < overlap < 1.) else .9
+    win_shift = int(win_len * overlap)
+    return scipy.signal.spectrogram(x=x, fs=sampling_rate, nperseg=win_len, noverlap=win_shift,
+                                    nfft=int(win_len * padding_factor), scaling='density', mode='psd', axis=-1,
+                                    **kwargs)

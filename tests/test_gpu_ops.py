@@ -132,6 +132,29 @@ def test_timeshift_matches_reference_semantics(ctx, size):
     assert relerr(ops.timeshift(ctx, x, -0.013, fs), R.timeshift(x, -0.013, fs)) < TOL
 
 
+@pytest.mark.parametrize('size', [64, 1001, 5999, 60000])
+def test_timeshift_fft_path(ctx, size):
+    """fast=False (signal/timeshift.py:90-96 over fft.py:104-113,239-241): every sample kept; an
+    odd axis comes back times cos(2 pi m / n) exactly as the reference's fftshift-twice ifft gives."""
+    rng = np.random.default_rng(size + 1)
+    fs = 50.
+    x = rng.standard_normal((5, size)).astype(np.float32)
+    x *= np.hanning(size).astype(np.float32)
+    delay = np.array([0.0, 0.02, -0.013, 0.25 / fs, 1.37])
+    got = ops.timeshift(ctx, x, delay, fs, fast=False)
+    ref = R.timeshift_fft(x, delay, 1. / fs)
+    assert got.shape == ref.shape == (5, size)
+    assert relerr(got, ref) < TOL
+    if size % 2 == 0:           # the two paths agree on an even axis
+        assert relerr(got, ops.timeshift(ctx, x, delay, fs)) < TOL
+        assert relerr(got[1], np.roll(x[1], 1)) < TOL
+    else:                       # the quirk is really there
+        m = np.arange(size)
+        assert relerr(got[0], x[0] * np.cos(2 * np.pi * m / size)) < TOL
+    from xcorr_amd import signal as S
+    assert relerr(S.timeshift(x, delay, fast=False, sampling_rate=fs), ref) < TOL
+
+
 def test_timeshift_full_lag_axis(ctx):
     """L = 359999 lags -> n = 359998 = 2 * 179999 (prime): no FFT of that length
     exists in the engine; the circular convolution runs at N = 737280."""

@@ -85,3 +85,27 @@ def test_feeds_correlate2d(ctx):
     band = slice(10, 74)                                                   # 64 bins x 2001 lags
     pk, ix = signal.correlate2d_peak(Sy[0, band], Sx[0, band])
     assert tuple(ix) == (63, 2000 + 7) and pk > 0.9
+
+
+@pytest.mark.parametrize('duration,pf,overlap', [(2.5, None, None), (2.5, 2, .5), (1.0, 4, .9), (5.12, 1, .75),
+                                                 (0.5, 3, .2), (20., 2, .5), (2.5, 1, .99)])
+def test_spectrogram_mtc_matches_scipy(ctx, duration, pf, overlap):
+    """signal/spectrogram.py:199-335: manual segment control (any hop; odd and even nfft)."""
+    x = ccf_like(3, 6001, seed=int(duration * 10))
+    f, t, S = signal.spectrogram_mtc(x, duration=duration, padding_factor=pf, overlap=overlap, sampling_rate=FS)
+    rf, rt, ref = R.spectrogram_mtc(x, FS, duration, pf, overlap)
+    assert np.allclose(f, rf) and np.allclose(t, rt)
+    check(S, ref)
+
+
+def test_spectrogram_mtc_argument_rules(ctx):
+    x = ccf_like(1, 2001, seed=5)
+    with pytest.raises(ValueError):
+        signal.spectrogram_mtc(x, duration=0.1, sampling_rate=FS)          # 5 samples < 16
+    with pytest.raises(ValueError):
+        signal.spectrogram_mtc(x, duration=2.5)                            # array input needs sampling_rate
+    with pytest.raises(XcxError):
+        ops.spectrogram_seg(ctx, x, 125, 200, 125, np.ones(125), 1.0)      # hop > win_len
+    # leading dimensions are kept
+    f, t, S = signal.spectrogram_mtc(x.reshape(1, 1, -1), duration=2.5, sampling_rate=FS)
+    assert S.shape == (1, 1, f.size, t.size)

@@ -160,3 +160,37 @@ def test_fourier_resample(ctx, raw, new_rate):
         assert fs2 == new_rate and relerr(y2, R.resample_fourier(x, 250., new_rate)) < TOL
     with pytest.raises(ValueError):
         stream.resample(raw[:1, :1001], 250., 100., strict_length=True, ctx=ctx)
+
+
+def test_reference_edh_chain_with_merge_and_trim(ctx):
+    """xcorr/scripts/cc.py:96-113 (EDH): merge(method 1, interpolate) -> demean -> highpass ->
+    decimate(5) -> trim to the window -> demean -> taper; two segments with a 40-sample gap,
+    window bounds injected like stream/process.py:153-196."""
+    rng = np.random.default_rng(5)
+    fs = 250.
+    full = (rng.standard_normal(61000) + 2.0).astype(np.float32)
+    t_start = 1000.0
+    segs = [(full[30020:], t_start + 30020 / fs), (full[:29980], t_start)]      # out of order, gap 29980..30019
+    chain = [
+        ('merge', {'method': 1, 'fill_value': 'interpolate', 'interpolation_samples': 0}),
+        ('detrend', {'type': 'demean'}),
+        ('filter', {'type': 'highpass', 'freq': .05}),
+        ('decimate', {'factor': 5}),
+        ('trim', {}),
+        ('detrend', {'type': 'demean'}),
+        ('taper', {'type': 'cosine', 'max_percentage': 0.05, 'max_length': 30.}),
+    ]
+    w0, w1 = t_start + 4.0, t_start + 204.0
+    y, fs2, t0 = stream.apply_operations(segs, fs, chain, ctx=ctx, starttime=w0, endtime=w1, return_t0=True)
+    ref = full.astype(np.float64).copy()
+    ref[29980:30020] = np.linspace(full[29979], full[30020], 42)[1:-1]
+    r = R.demean(ref[None])
+    r = R.sosfilt(stream.butter_sos('highpass', fs, 4, freq=.05), r)
+    r = R.decimate(r, fs, 5)
+    r = r[:, 200:200 + 10001]                       # 4 s .. 204 s at 50 Hz, both ends included
+    r = R.demean(r)
+    r = r * R.cosine_taper_obspy(r.shape[-1], 50., 0.05, 30.)
+    assert fs2 == 50. and abs(t0 - w0) < 1e-9 and y.shape[-1] == 10001
+    assert relerr(np.asarray(y).reshape(1, -1), r) < 5 * TOL
+    with pytest.raises(ValueError):                 # a gap without fill_value leaves masked samples
+        stream.apply_operations(segs, fs, [('merge', {'method': 1})], ctx=ctx)

@@ -245,3 +245,78 @@ def test_io_roundtrip_naming_and_skip_if_done(tmp_path):
         def get_pair_processed_waveforms(self, **kw):
             raise AssertionError('a finished file must not be reprocessed')
     assert lazy.single_process(pair, '2020-02-03', args, NoClient(), str(tmp_path)) is True
+
+
+# ---- stream segment bookkeeping (stream/process.py:50-53,86-90; ObsPy rules restated) -------------
+def test_merge_rules():
+    from xcorr_amd.stream import merge
+    fs = 10.
+    a = (np.arange(10, dtype=np.float32), 0.0)                 # t = 0.0 .. 0.9
+    b = (np.arange(100, 110, dtype=np.float32), 1.0)           # exact fit
+    y, t0 = merge([b, a], fs)
+    assert t0 == 0.0 and np.array_equal(y, np.r_[a[0], b[0]])
+    # gap of 5 samples: NaN / number / latest / interpolate
+    c = (np.full(4, 20, np.float32), 1.5)
+    y, _ = merge([a, c], fs)
+    assert y.size == 19 and np.isnan(y[10:15]).all() and y[15] == 20
+    assert np.array_equal(merge([a, c], fs, fill_value=0)[0][10:15], np.zeros(5))
+    assert np.array_equal(merge([a, c], fs, fill_value='latest')[0][10:15], np.full(5, 9))
+    line = np.linspace(9, 20, 7)[1:-1].astype(np.float32)
+    assert np.allclose(merge([a, c], fs, method=1, fill_value='interpolate', interpolation_samples=0)[0][10:15], line)
+    # overlap of 3 samples, method 1: the later segment wins from the overlap on
+    d = (np.arange(50, 56, dtype=np.float32), 0.7)
+    y, _ = merge([a, d], fs, method=1)
+    assert np.array_equal(y, np.r_[np.arange(7), np.arange(50, 56)])
+    # ... interpolation_samples=-1: straight line across the whole overlap
+    y, _ = merge([a, d], fs, method=1, interpolation_samples=-1)
+    assert np.allclose(y[7:10], np.linspace(6, 53, 5)[1:-1]) and np.array_equal(y[10:], [53, 54, 55])
+    # method 0: differing overlap samples are discarded, equal ones kept
+    e = (np.r_[7, 8, 99, 10, 11].astype(np.float32), 0.7)
+    y, _ = merge([a, e], fs, method=0)
+    assert y[7] == 7 and y[8] == 8 and np.isnan(y[9]) and y[10] == 10
+    # contained segment: dropped by method 1
+    f = (np.full(3, -1, np.float32), 0.3)
+    assert np.array_equal(merge([a, f], fs, method=1)[0], a[0])
+    with pytest.raises(ValueError):
+        merge([], fs)
+
+
+def test_trim_rules():
+    from xcorr_amd.stream import trim
+    fs = 10.
+    x = np.arange(20, dtype=np.float32)                        # t = 100.0 .. 101.9
+    y, t0 = trim(x, fs, 100.0, 100.5, 101.2)
+    assert np.array_equal(y, np.arange(5, 13)) and abs(t0 - 100.5) < 1e-12
+    # nearest sample vs strictly inside
+    y, t0 = trim(x, fs, 100.0, 100.46, 101.24)
+    assert y[0] == 5 and y[-1] == 12
+    y, t0 = trim(x, fs, 100.0, 100.46, 101.24, nearest_sample=False)
+    assert y[0] == 5 and y[-1] == 12 and abs(t0 - 100.5) < 1e-12
+    y, _ = trim(x, fs, 100.0, 100.44, 101.26, nearest_sample=False)
+    assert y[0] == 5 and y[-1] == 12
+    # bounds outside the data: unchanged without pad, extended with pad
+    y, t0 = trim(x, fs, 100.0, 99.0, 103.0)
+    assert np.array_equal(y, x) and t0 == 100.0
+    y, t0 = trim(x, fs, 100.0, 99.8, 102.1, pad=True, fill_value=0)
+    assert y.size == 24 and np.array_equal(y[:2], [0, 0]) and np.array_equal(y[-2:], [0, 0]) and abs(t0 - 99.8) < 1e-12
+    assert np.isnan(trim(x, fs, 100.0, 99.8, None, pad=True)[0][:2]).all()
+    # leading dimensions are kept; empty result when the window misses the data
+    y, _ = trim(np.stack([x, x]), fs, 100.0, 100.5, 101.2)
+    assert y.shape == (2, 8)
+    assert trim(x, fs, 100.0, 105.0, 106.0)[0].size == 0
+    with pytest.raises(ValueError):
+        trim(x, fs, 100.0, 101.0, 100.0)
+
+
+def test_rotate_and_sensitivity():
+    from xcorr_amd.stream import rotate_ne_rt, remove_sensitivity
+    n, e = np.array([1., 0.]), np.array([0., 1.])
+    r, t = rotate_ne_rt(n, e, 0.)           # source due north: radial points south
+    assert np.allclose(r, [-1, 0]) and np.allclose(t, [0, -1])
+    r, t = rotate_ne_rt(n, e, 90.)
+    assert np.allclose(r, [0, -1]) and np.allclose(t, [1, 0])
+    with pytest.raises(ValueError):
+        rotate_ne_rt(n, e, 400.)
+    x = np.array([2., 4.], np.float32)
+    y = remove_sensitivity(x, 2.0)
+    assert y.dtype == np.float32 and np.array_equal(y, [1, 2])

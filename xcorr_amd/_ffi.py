@@ -78,6 +78,7 @@ SIGNATURES = {
     'xcx_sosfilt_zerophase': [_vp, _vp, _l, _l, _vp, _i, _i],
     'xcx_snr': [_vp, _vp, _l, _l, _vp, _vp, _vp, _vp, _vp, _i],
     'xcx_timeshift': [_vp, _vp, _vp, _l, _l, _vp, C.c_double, _i],
+    'xcx_timeshift_fft': [_vp, _vp, _vp, _l, _l, _vp, C.c_double, _i],
     'xcx_cc2d': [_vp, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _i],
     'xcx_fft': [_vp, _vp, _vp, _l, _l, _i],
     'xcx_ifft': [_vp, _vp, _vp, _l, _l, _i],
@@ -89,6 +90,7 @@ SIGNATURES = {
     'xcx_lanczos': [_vp, _vp, _vp, _l, _l, _l, C.c_double, C.c_double, _i, _i],
     'xcx_block_rms': [_vp, _vp, _vp, _l, _l, _l, _l, _l, _i],
     'xcx_spectrogram': [_vp, _vp, _vp, _l, _l, _i, _i, _vp, C.c_double, _i, _i],
+    'xcx_spectrogram_seg': [_vp, _vp, _vp, _l, _l, _i, _l, _i, _vp, C.c_double, _i, _i],
     'xcx_ram_normalize': [_vp, _vp, _l, _l, _l, _i],
     'xcx_cc1d_stack_add': [_vp, _vp, _i, _i, _l, _l, _vp, _i, _i],
     'xcx_cc1d_stack_finish': [_vp, _vp, _i, _vp, _l, _i, _vp],

@@ -232,3 +232,123 @@ extern "C" int xcx_spectrogram(xcx_ctx* ctx, const float* x, float* S, long batc
   if (hb) (void)hipFree(hb);
   return rc;
 }
+
+// ---- segmented spectrogram (any hop): signal/spectrogram.py:199-335 (spectrogram_mtc) -------------
+// scipy.signal.spectrogram(x, fs, nperseg = win_len, noverlap = win_len - hop, nfft, window,
+// detrend, scaling, mode='psd'): segment s starts at s*hop; per segment: remove the mean
+// ('constant'), multiply by the window, zero-pad to nfft, one-sided |rfft|^2 * scale (x2 except DC
+// and, for even nfft, Nyquist).  Segments are framed on the device and transformed by the batched
+// any-length DFT of fftn.hip; output [batch][nfreq][nseg] like scipy's Sxx.
+namespace {
+
+// frames [rows = batch*nseg][nfft] real (cplx = 0) or interleaved complex with zero imaginary part
+__global__ void k_frames(const float* __restrict__ x, float* __restrict__ fr, const float* __restrict__ w,
+                         long n, long nseg, int win_len, long hop, int nfft, int detrend, int cplx, long row0) {
+  const long row = row0 + blockIdx.x;               // b * nseg + s
+  const long b = row / nseg, s = row - b * nseg;
+  const float* __restrict__ xs = x + b * n + s * hop;
+  __shared__ float red[4];
+  float mean = 0.f;
+  if (detrend) {
+    double part = 0.0;                              // short segments, but offsets can dwarf the signal
+    for (int m = threadIdx.x; m < win_len; m += blockDim.x) part += (double)xs[m];
+    float pf = (float)part;
+    for (int o = 32; o > 0; o >>= 1) pf += __shfl_down(pf, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = pf;
+    __syncthreads();
+    mean = (red[0] + red[1] + red[2] + red[3]) / (float)win_len;
+  }
+  float* __restrict__ o = fr + (long)blockIdx.x * nfft * (cplx ? 2 : 1);
+  for (int m = threadIdx.x; m < nfft; m += blockDim.x) {
+    const float v = m < win_len ? (xs[m] - mean) * w[m] : 0.f;
+    if (cplx) { o[2 * m] = v; o[2 * m + 1] = 0.f; }
+    else o[m] = v;
+  }
+}
+
+// S[b][f][s] = |X[b*nseg + s][f]|^2 * sc(f); spec rows have `pitch` complex entries
+__global__ void k_psd_t(const float2* __restrict__ spec, float* __restrict__ S, long nseg, int nfreq, long pitch,
+                        int nfft, float scale, long rows0, long nrows, long nseg_total) {
+  // tile transpose: 32 segments x 32 frequencies
+  __shared__ float tile[32][33];
+  const long r0 = (long)blockIdx.x * 32;            // local frame rows
+  const int f0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: ty 0..7
+  for (int j = ty; j < 32; j += 8) {
+    const long r = r0 + j; const int f = f0 + tx;
+    float v = 0.f;
+    if (r < nrows && f < nfreq) {
+      const float2 c = spec[r * pitch + f];
+      const bool single = f == 0 || (nfft % 2 == 0 && f == nfft / 2);
+      v = (c.x * c.x + c.y * c.y) * scale * (single ? 1.f : 2.f);
+    }
+    tile[j][tx] = v;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int f = f0 + j; const long r = r0 + tx;
+    if (r < nrows && f < nfreq) {
+      const long g = rows0 + r;                     // global frame row
+      const long b = g / nseg_total, s = g - b * nseg_total;
+      S[(b * nfreq + f) * nseg_total + s] = tile[tx][j];
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int xcx_spectrogram_seg(xcx_ctx* ctx, const float* x, float* S, long batch, long n, int win_len,
+                                   long hop, int nfft, const double* window, double scale, int detrend,
+                                   int on_device) {
+  if (!ctx || !x || !S || !window) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || n < 1) return set_err(XCX_EINVAL, "batch and n must be >= 1");
+  if (win_len < 2) return set_err(XCX_EINVAL, "win_len must be >= 2");
+  if (hop < 1 || hop > win_len) return set_err(XCX_EINVAL, "hop %ld outside [1, win_len]", hop);
+  if (nfft < win_len) return set_err(XCX_EINVAL, "nfft %d < win_len %d", nfft, win_len);
+  if (nfft > 184320) return set_err(XCX_EUNSUPPORTED, "nfft %d beyond the DFT engine (184320)", nfft);
+  if (n < win_len) return set_err(XCX_EINVAL, "row shorter than one segment (%ld < %d)", n, win_len);
+  HIP_TRY(hipSetDevice(ctx->device));
+  const long nseg = (n - win_len) / hop + 1;
+  const int nfreq = nfft / 2 + 1;
+  const int cplx = nfft & 1;                        // xcx_rfft handles even lengths; odd ones go through the complex DFT
+  const long total = batch * nseg;
+  // frames per chunk: bound the temporaries to ~256 MB
+  const size_t per_row = sizeof(float) * (size_t)nfft * (cplx ? 2 : 1) + sizeof(float2) * (size_t)(cplx ? nfft : nfreq);
+  const long chunk = std::max<long>(1, std::min<long>(total, (long)(((size_t)256 << 20) / per_row)));
+  std::vector<float> wf(window, window + win_len);
+  void *dw = nullptr, *dfr = nullptr, *dsp = nullptr, *ha = nullptr, *hb = nullptr;
+  auto cleanup = [&]() { (void)hipFree(dw); (void)hipFree(dfr); (void)hipFree(dsp); (void)hipFree(ha); (void)hipFree(hb); };
+  auto fail = [&](int rc) { cleanup(); return rc; };
+  if (hipMalloc(&dw, sizeof(float) * win_len) != hipSuccess ||
+      hipMalloc(&dfr, sizeof(float) * (size_t)nfft * (cplx ? 2 : 1) * chunk) != hipSuccess ||
+      hipMalloc(&dsp, sizeof(float2) * (size_t)(cplx ? nfft : nfreq) * chunk) != hipSuccess)
+    return fail(set_err(XCX_ENOMEM, "spectrogram workspaces"));
+  const size_t in_b = sizeof(float) * (size_t)batch * n, out_b = sizeof(float) * (size_t)batch * nfreq * nseg;
+  const float* xd = x; float* Sd = S;
+  if (!on_device) {
+    if (hipMalloc(&ha, in_b) != hipSuccess || hipMalloc(&hb, out_b) != hipSuccess)
+      return fail(set_err(XCX_ENOMEM, "spectrogram buffers"));
+    (void)hipMemcpyAsync(ha, x, in_b, hipMemcpyHostToDevice, ctx->stream);
+    xd = (const float*)ha; Sd = (float*)hb;
+  }
+  if (hipMemcpyAsync(dw, wf.data(), sizeof(float) * win_len, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess)
+    return fail(set_err(XCX_EHIP, "window upload"));
+  const long pitch = cplx ? nfft : nfreq;
+  for (long r0 = 0; r0 < total; r0 += chunk) {
+    const long cnt = std::min(chunk, total - r0);
+    hipLaunchKernelGGL(k_frames, dim3((unsigned)cnt), dim3(256), 0, ctx->stream,
+                       xd, (float*)dfr, (const float*)dw, n, nseg, win_len, hop, nfft, detrend, cplx, r0);
+    if (hipGetLastError() != hipSuccess) return fail(set_err(XCX_EHIP, "k_frames launch"));
+    int rc = cplx ? xcx_fft(ctx, (const float*)dfr, (float*)dsp, cnt, nfft, 1)
+                  : xcx_rfft(ctx, (const float*)dfr, (float*)dsp, cnt, nfft, 1);
+    if (rc) return fail(rc);
+    hipLaunchKernelGGL(k_psd_t, dim3((unsigned)((cnt + 31) / 32), (unsigned)((nfreq + 31) / 32)), dim3(256), 0,
+                       ctx->stream, (const float2*)dsp, Sd, nseg, nfreq, pitch, nfft, (float)scale, r0, cnt, nseg);
+    if (hipGetLastError() != hipSuccess) return fail(set_err(XCX_EHIP, "k_psd_t launch"));
+  }
+  if (!on_device) (void)hipMemcpyAsync(S, Sd, out_b, hipMemcpyDeviceToHost, ctx->stream);
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return fail(set_err(XCX_EHIP, "spectrogram_seg sync"));
+  cleanup();
+  return XCX_OK;
+}

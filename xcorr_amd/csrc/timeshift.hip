@@ -44,6 +44,9 @@ namespace {
 // cosine terms cancel and   h[m] = -(-1)^m sin(pi n alpha) cot(pi u) / n   -- one sincospi
 // per sample (float64: u is a small difference near the peak) instead of three circular
 // functions; the removable singularity u -> 0 takes the limit (n-1 + cos(pi n alpha)(-1)^m)/n.
+// Odd n (only reachable through the fft/ifft path, which keeps every sample): all n frequencies
+// |k| <= (n-1)/2 exist and  h[m] = sin(n pi u) / (n sin(pi u)) = -(-1)^m sin(pi n alpha) / (n sin(pi u)),
+// limit 1 at u -> 0.
 __global__ void k_dirichlet(float* __restrict__ hr, long n, long rows, const double* __restrict__ alpha) {
   // grid (ceil(n / 256), rows): no 64-bit division per sample
   const long r = blockIdx.y;
@@ -60,30 +63,33 @@ __global__ void k_dirichlet(float* __restrict__ hr, long n, long rows, const dou
   sincospi(fmod((double)n * al, 2.0), &sa, &ca);    // row constants
   const double sgn = (m & 1) ? -1.0 : 1.0;
   double h;
-  if (fabs(su) < 1e-12) h = ((double)(n - 1) + ca * sgn) * inv_n;
-  else h = -sgn * sa * (cu / su) * inv_n;
+  if (n & 1) {
+    if (fabs(su) < 1e-12) h = 1.0;
+    else h = -sgn * sa / su * inv_n;
+  } else {
+    if (fabs(su) < 1e-12) h = ((double)(n - 1) + ca * sgn) * inv_n;
+    else h = -sgn * sa * (cu / su) * inv_n;
+  }
   hr[r * n + t] = (float)h;
 }
 
-// y[r][m] = R[r][m + n - 1] + (m >= 1 ? R[r][m - 1] : 0)
-__global__ void k_fold(const float* __restrict__ lin, long ld, float* __restrict__ y, long n, long rows) {
+// y[r][m] = R[r][m + n - 1] + (m >= 1 ? R[r][m - 1] : 0), times cos(2 pi m / n) when `modulate`
+__global__ void k_fold(const float* __restrict__ lin, long ld, float* __restrict__ y, long n, long rows, int modulate) {
   const long r = blockIdx.y;
   const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (m >= n || r >= rows) return;
   const float* R = lin + r * ld;
   float v = R[m + n - 1];
   if (m >= 1) v += R[m - 1];
+  if (modulate) v = (float)((double)v * cospi(2.0 * (double)m / (double)n));
   y[r * n + m] = v;
 }
 
 }  // namespace
 
-extern "C" int xcx_timeshift(xcx_ctx* ctx, const float* x, float* y, long batch, long size,
-                             const double* delay, double sampling_rate, int on_device) {
-  if (!ctx || !x || !y || !delay) return set_err(XCX_EINVAL, "null argument");
-  if (batch < 1 || size < 2) return set_err(XCX_EINVAL, "batch >= 1 and size >= 2 required");
-  if (!(sampling_rate > 0)) return set_err(XCX_EINVAL, "sampling_rate must be positive");
-  const long n = size - (size & 1);
+// rows [batch][size] -> [batch][n] (n <= size), alpha[r] = shift of row r in cycles per frequency bin
+static int timeshift_rows(xcx_ctx* ctx, const float* x, float* y, long batch, long size, long n,
+                          const std::vector<double>& alpha, int modulate, int on_device) {
   HIP_TRY(hipSetDevice(ctx->device));
   int rc;
   if (!ctx->ts_plan || ctx->ts_n != n) {
@@ -93,11 +99,6 @@ extern "C" int xcx_timeshift(xcx_ctx* ctx, const float* x, float* y, long batch,
     ctx->ts_n = n;
   }
   xcx_plan* plan = ctx->ts_plan;
-  // alpha = delay * fN / (n/2), fN = round(n/2 / ((n-1) delta))   (fft.py:358)
-  const double delta = 1.0 / sampling_rate;
-  const double fN = std::round((double)(n / 2) / ((double)(n - 1) * delta));
-  std::vector<double> alpha(batch);
-  for (long r = 0; r < batch; ++r) alpha[r] = delay[r] * fN / (double)(n / 2);
   const long L = 2 * n - 1;
   const long ld = (L + 31) / 32 * 32;
   const int kRows = 128;
@@ -131,7 +132,7 @@ extern "C" int xcx_timeshift(xcx_ctx* ctx, const float* x, float* y, long batch,
     for (int i = 0; i < cnt; ++i) d[i] = PwDesc{i, cnt + i, (long long)i * ld};
     if ((rc = xcx_internal_pairs(plan, d.data(), cnt, (float*)lin.ptr))) return rc;
     hipLaunchKernelGGL(k_fold, grid, dim3(256), 0, ctx->stream, (const float*)lin.ptr, ld, yd + r0 * n, n,
-                       (long)cnt);
+                       (long)cnt, modulate);
     HIP_TRY(hipGetLastError());
   }
   if (!on_device) {
@@ -139,4 +140,36 @@ extern "C" int xcx_timeshift(xcx_ctx* ctx, const float* x, float* y, long batch,
     HIP_TRY(hipStreamSynchronize(ctx->stream));
   }
   return XCX_OK;
+}
+
+extern "C" int xcx_timeshift(xcx_ctx* ctx, const float* x, float* y, long batch, long size,
+                             const double* delay, double sampling_rate, int on_device) {
+  if (!ctx || !x || !y || !delay) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || size < 2) return set_err(XCX_EINVAL, "batch >= 1 and size >= 2 required");
+  if (!(sampling_rate > 0)) return set_err(XCX_EINVAL, "sampling_rate must be positive");
+  const long n = size - (size & 1);
+  // alpha = delay * fN / (n/2), fN = round(n/2 / ((n-1) delta))   (fft.py:358)
+  const double delta = 1.0 / sampling_rate;
+  const double fN = std::round((double)(n / 2) / ((double)(n - 1) * delta));
+  std::vector<double> alpha(batch);
+  for (long r = 0; r < batch; ++r) alpha[r] = delay[r] * fN / (double)(n / 2);
+  return timeshift_rows(ctx, x, y, batch, size, n, alpha, 0, on_device);
+}
+
+// fast=False of the reference (signal/timeshift.py:90-96): X = fftshift(fft(x)) on the axis
+// f = fftshift(fftfreq(n, round(delta, 10)))  (fft.py:104-113), phase ramp, then
+// real(ifft(fftshift(X)))  (fft.py:239-241).  Every sample is kept.  For even n fftshift undoes
+// itself and the result is the period-n shift; for odd n the second fftshift is NOT the inverse
+// of the first (the spectrum ends up rolled by one bin), so the reference returns the shifted row
+// times cos(2 pi m / n) -- reproduced as it is.
+extern "C" int xcx_timeshift_fft(xcx_ctx* ctx, const float* x, float* y, long batch, long size,
+                                 const double* delay, double delta, int on_device) {
+  if (!ctx || !x || !y || !delay) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || size < 2) return set_err(XCX_EINVAL, "batch >= 1 and size >= 2 required");
+  if (!(delta > 0)) return set_err(XCX_EINVAL, "delta must be positive");
+  const double dr = std::nearbyint(delta * 1e10) / 1e10;          // numpy.round(delta, decimals=10)
+  if (!(dr > 0)) return set_err(XCX_EINVAL, "delta rounds to zero at 1e-10");
+  std::vector<double> alpha(batch);
+  for (long r = 0; r < batch; ++r) alpha[r] = delay[r] / ((double)size * dr);
+  return timeshift_rows(ctx, x, y, batch, size, size, alpha, (int)(size & 1), on_device);
 }

@@ -15,7 +15,8 @@ from .engine import DeviceArray, default_context
 
 __all__ = ['copy', 'norm1d', 'demean', 'detrend_linear', 'taper', 'taper_table', 'detrend_nan', 'unbias', 'post_prep',
            'onebit', 'sosfiltfilt', 'sosfilt', 'sosfilt_zerophase', 'timeshift', 'snr', 'correlate2d',
-           'fft', 'ifft', 'rfft', 'irfft', 'hilbert', 'decimate', 'resample', 'lanczos', 'block_rms', 'spectrogram', 'ram_normalize']
+           'fft', 'ifft', 'rfft', 'irfft', 'hilbert', 'decimate', 'resample', 'lanczos', 'block_rms', 'spectrogram', 'spectrogram_seg',
+           'ram_normalize']
 
 
 def _prep(x):
@@ -168,15 +169,18 @@ def sosfilt_zerophase(ctx, x, sos):
     return buf
 
 
-def timeshift(ctx, x, delay, sampling_rate, out=None):
-    """Fractional time shift (xcorr/signal/timeshift.py:90-96, fast=True):
-    rows of length `size` -> rows of length size - (size & 1).  `delay` is a
-    scalar or one value per row (seconds)."""
+def timeshift(ctx, x, delay, sampling_rate, out=None, fast=True):
+    """Fractional time shift (xcorr/signal/timeshift.py:90-96).  fast=True
+    (rfft/irfft): rows of length `size` -> rows of length size - (size & 1).
+    fast=False (fft/ifft, signal/fft.py:104-113,239-241): every sample kept;
+    for an odd length the reference's result carries a cos(2 pi m / size)
+    factor (its second fftshift is not the inverse of the first), reproduced.
+    `delay` is a scalar or one value per row (seconds)."""
     ctx = _ctx(ctx, x)
     if isinstance(x, DeviceArray):
         size = x.shape[-1]
         batch = int(np.prod(x.shape[:-1])) if len(x.shape) > 1 else 1
-        n = size - (size & 1)
+        n = size - (size & 1) if fast else size
         if out is None:
             out = DeviceArray(ctx, (batch, n))
         src, dev, lead = x, 1, None
@@ -185,15 +189,19 @@ def timeshift(ctx, x, delay, sampling_rate, out=None):
         size = src.shape[-1]
         lead = src.shape[:-1]
         batch = int(np.prod(lead)) if src.ndim > 1 else 1
-        n = size - (size & 1)
+        n = size - (size & 1) if fast else size
         out = np.empty(lead + (n,), dtype=np.float32)
         dev = 0
     d = np.ascontiguousarray(np.broadcast_to(np.asarray(delay, dtype=np.float64),
                                              lead if lead is not None else (batch,)).reshape(-1))
     if d.size != batch:
         raise ValueError('delay must be a scalar or one value per row')
-    check(_ffi.lib().xcx_timeshift(ctx.handle, ptr(src), ptr(out), batch, size, ptr(d),
-                                   float(sampling_rate), dev))
+    if fast:
+        check(_ffi.lib().xcx_timeshift(ctx.handle, ptr(src), ptr(out), batch, size, ptr(d),
+                                       float(sampling_rate), dev))
+    else:
+        check(_ffi.lib().xcx_timeshift_fft(ctx.handle, ptr(src), ptr(out), batch, size, ptr(d),
+                                           1.0 / float(sampling_rate), dev))
     return out
 
 
@@ -384,6 +392,23 @@ def spectrogram(ctx, x, win_len, nfft, window, scale, detrend=True):
                                      float(scale), int(bool(detrend)), dev))
     return y
 
+
+
+def spectrogram_seg(ctx, x, win_len, hop, nfft, window, scale, detrend=True):
+    """One-sided PSD of segments starting every `hop` samples (scipy.signal.spectrogram as
+    called by spectrogram_mtc, xcorr/signal/spectrogram.py:266-276):
+    [..., n] -> [..., nfft//2+1, (n-win_len)//hop+1]."""
+    ctx = _ctx(ctx, x)
+    src, dev, lead, n = _rows(x)
+    batch = int(np.prod(lead)) if lead else 1
+    w = np.ascontiguousarray(window, dtype=np.float64)
+    if w.shape != (int(win_len),):
+        raise ValueError('window must have win_len samples')
+    nseg = (n - int(win_len)) // int(hop) + 1
+    y = _out(ctx, src, dev, tuple(lead) + (int(nfft) // 2 + 1, nseg))
+    check(_ffi.lib().xcx_spectrogram_seg(ctx.handle, ptr(src), ptr(y), batch, n, int(win_len), int(hop), int(nfft),
+                                         ptr(w), float(scale), int(bool(detrend)), dev))
+    return y
 
 
 def ram_normalize(ctx, x, half_width):

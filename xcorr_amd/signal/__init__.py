@@ -15,11 +15,11 @@ from .ops1d import (correlate1d, norm1d, norm, demean, detrend, window, taper,
                     envelope, rms, absolute)  # noqa: F401
 from .ops2d import norm2d, correlate2d, correlate2d_peak  # noqa: F401
 from .fftops import fft, ifft, rfft, irfft  # noqa: F401
-from .spectral import spectrogram, psd  # noqa: F401
+from .spectral import spectrogram, psd, spectrogram_mtc  # noqa: F401
 
 __all__ = ['correlate1d', 'norm1d', 'norm', 'demean', 'detrend', 'window',
            'taper', 'filter', 'unbias', 'unbias_weights', 'timeshift', 'snr',
-           'norm2d', 'correlate2d', 'correlate2d_peak', 'fft', 'ifft', 'rfft', 'irfft', 'hilbert', 'envelope', 'spectrogram', 'psd', 'rms', 'absolute']
+           'norm2d', 'correlate2d', 'correlate2d_peak', 'fft', 'ifft', 'rfft', 'irfft', 'hilbert', 'envelope', 'spectrogram', 'psd', 'spectrogram_mtc', 'rms', 'absolute']
 
 try:                                    # B4 seam: DataArray.signal accessor
     from . import accessor  # noqa: F401

@@ -87,6 +87,10 @@ class SignalAccessor():
 
     psd = spectrogram
 
+    @wraps(_fs.spectrogram_mtc)
+    def spectrogram_mtc(self, **kwargs):
+        return _fs.spectrogram_mtc(self._da, **kwargs)
+
     @wraps(_f.rms)
     def rms(self, **kwargs):
         return _f.rms(self._da, **kwargs)

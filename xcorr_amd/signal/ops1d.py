@@ -263,9 +263,9 @@ def timeshift(x, delay, dtype=None, dim=None, fast=True, sampling_rate=None):
     phase ramp exp(-2 pi i delay f) (signal/timeshift.py:90-96).  `delay` is a
     float or an array broadcasting over the leading dimensions.  Like the
     reference (rfft path, signal/fft.py:357) an odd-length axis loses its last
-    sample.  Only ``fast=True`` (rfft/irfft) is built."""
-    if not fast:
-        raise NotImplementedError('only fast=True (rfft/irfft) is built on the GPU path')
+    sample with ``fast=True``; ``fast=False`` (fft/ifft) keeps every sample and,
+    for an odd length, reproduces the reference's cos(2 pi m / n) factor (its
+    `ifft` applies fftshift where ifftshift is due, signal/fft.py:239-241)."""
     if _is_da(x):
         dim = _check_dim(x, dim)
         if not np.all(np.abs(x[dim].diff(dim, 2)) < 1e-10):
@@ -286,7 +286,10 @@ def timeshift(x, delay, dtype=None, dim=None, fast=True, sampling_rate=None):
         dl = delay
         if _is_da(delay):
             dl = delay.broadcast_like(xt.isel({dim: 0})).transpose(*xt.dims[:-1]).values
-        out = _ops.timeshift(None, np.ascontiguousarray(xt.values, np.float32), dl, fs)
+        if not fast:        # the fft path takes delta from the coordinate itself (fft.py:104-107)
+            c = x[dim].values
+            fs = 1.0 / float(np.fabs(c[1] - c[0]))
+        out = _ops.timeshift(None, np.ascontiguousarray(xt.values, np.float32), dl, fs, fast=fast)
         y = xt.isel({dim: slice(0, out.shape[-1])}).copy(data=out.astype(x.dtype))
         y = y.transpose(*x.dims)
         y.attrs = x.attrs
@@ -297,7 +300,7 @@ def timeshift(x, delay, dtype=None, dim=None, fast=True, sampling_rate=None):
     if not isinstance(delay, (float, np.ndarray, np.floating)):
         raise TypeError('delay should be a float or an array')
     x = np.asarray(x)
-    out = _ops.timeshift(None, x, delay, sampling_rate)
+    out = _ops.timeshift(None, x, delay, sampling_rate, fast=fast)
     return out.astype(dtype or x.dtype)
 
 

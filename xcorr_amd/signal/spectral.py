@@ -66,3 +66,63 @@ def spectrogram(x, duration=None, padding_factor=2, scaling=None, dim=None, samp
 
 
 psd = spectrogram
+
+
+def spectrogram_mtc(x, duration=None, padding_factor=None, overlap=None, dim='lag', sampling_rate=None,
+                    window=('tukey', .25), detrend='constant', **kwargs):
+    """Spectrogram with manual time-segment control (signal/spectrogram.py:199-335):
+    ``scipy.signal.spectrogram(nperseg=int(duration*fs), noverlap=int(nperseg*overlap),
+    nfft=int(nperseg*padding_factor), scaling='density', mode='psd')``.  Defaults as the
+    reference resolves them: padding_factor 1, overlap 0.9, duration at least one sample.
+
+    numpy input ``[..., n]`` needs ``sampling_rate``; returns ``(f, t, Sxx[..., nfreq, nseg])``.
+    DataArray input: dims of `x` without `dim`, then ``psd_f``, ``psd_t`` (``t`` offset by the
+    first coordinate value)."""
+    if kwargs:
+        raise NotImplementedError(f'scipy.signal.spectrogram arguments {sorted(kwargs)} are not built')
+    if detrend not in ('constant', False, None):
+        raise NotImplementedError('only detrend="constant" or False is built')
+    if _is_da(x):
+        if dim not in x.dims:
+            raise ValueError(f'x has no dimension "{dim}"')
+        if 'sampling_rate' not in x[dim].attrs:
+            raise ValueError('Dimension has no attribute "{sampling_rate}"!')
+        if 'delta' not in x[dim].attrs:
+            raise ValueError('Dimension has no attribute "{delta}"!')
+        fs = x[dim].attrs['sampling_rate']
+        xt = x.transpose(..., dim)
+        f, t, S = spectrogram_mtc(xt.values, duration, padding_factor, overlap, sampling_rate=fs, window=window,
+                                  detrend=detrend)
+        t = t + x[dim].values[0]
+        pf = padding_factor if (padding_factor and padding_factor >= 1) else 1
+        ov = overlap if overlap and (0. < overlap < 1.) else .9
+        du = duration if (duration and duration > x[dim].attrs['delta']) else x[dim].attrs['delta']
+        coords = {d: xt[d] for d in xt.dims[:-1] if d in xt.coords}
+        coords['psd_f'] = ('psd_f', f, {'long_name': 'Frequency', 'standard_name': 'frequency', 'units': 'Hz'})
+        coords['psd_t'] = ('psd_t', t, {'long_name': 'Time', 'standard_name': 'time'})
+        return xr.DataArray(S, dims=xt.dims[:-1] + ('psd_f', 'psd_t'), coords=coords, name='psd',
+                            attrs={'long_name': 'Power Spectral Density', 'standard_name': 'power_spectral_density',
+                                   'units': 'Hz-1', 'scaling': 'density', 'mode': 'psd', 'duration': du,
+                                   'padding_factor': pf, 'overlap': ov, 'centered': np.byte(True)})
+    if sampling_rate is None:
+        raise ValueError('sampling_rate is required for array input')
+    delta = 1.0 / sampling_rate
+    padding_factor = padding_factor if (padding_factor and padding_factor >= 1) else 1
+    duration = duration if (duration and duration > delta) else delta
+    win_len = int(duration * sampling_rate)
+    if win_len < 16:
+        raise ValueError('Change duration to have at least 16 sample points!')
+    overlap = overlap if overlap and (0. < overlap < 1.) else .9
+    noverlap = int(win_len * overlap)
+    nfft = int(win_len * padding_factor)
+    win = scipy.signal.get_window(window, win_len) if isinstance(window, (str, tuple)) else np.asarray(window, float)
+    if win.shape != (win_len,):
+        raise ValueError('window must have length of nperseg')
+    scale = 1.0 / (sampling_rate * (win * win).sum())
+    x = np.asarray(x)
+    hop = win_len - noverlap
+    S = _ops.spectrogram_seg(None, x, win_len, hop, nfft, win, scale, detrend == 'constant')
+    # scipy: freqs = rfftfreq(nfft, 1/fs); time = arange(nperseg/2, n - nperseg/2 + 1, hop) / fs
+    f = np.fft.rfftfreq(nfft, 1 / sampling_rate)
+    t = np.arange(win_len / 2, x.shape[-1] - win_len / 2 + 1, hop) / float(sampling_rate)
+    return f, t, S.astype(x.dtype if x.dtype.kind == 'f' else np.float32)

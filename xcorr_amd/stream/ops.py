@@ -3,6 +3,7 @@ import numpy as np
 import scipy.signal
 
 from .. import ops as _ops
+from . import segments as _seg
 
 
 # -- filter design (host side, scipy) -----------------------------------------
@@ -153,12 +154,22 @@ def running_rms(x, sampling_rate, window=1., ctx=None):
 
 
 _OPS = {'detrend': detrend, 'filter': filter, 'taper': taper, 'decimate': decimate, 'resample': resample,
-        'interpolate': interpolate, 'running_rms': running_rms}
+        'interpolate': interpolate, 'running_rms': running_rms, 'merge': _seg.merge, 'trim': _seg.trim,
+        'remove_sensitivity': _seg.remove_sensitivity}
 
 
-def apply_operations(x, sampling_rate, operations, ctx=None):
+def apply_operations(x, sampling_rate, operations, ctx=None, t0=0.0, starttime=None, endtime=None,
+                     sensitivity=None, return_t0=False):
     """Run a reference-style operation list ``[(name, params), ...]``
-    (xcorr/stream/process.py:300-412) on an array.  Returns (y, sampling_rate)."""
+    (xcorr/stream/process.py:300-412) on an array.  Returns (y, sampling_rate), or
+    (y, sampling_rate, t0) with ``return_t0``.
+
+    `x` is one array ``[..., npts]`` starting at `t0` seconds, or -- when the list
+    starts with ``merge`` -- a list of segments ``[(data, starttime), ...]``.
+    `starttime` / `endtime` / `sensitivity` are the dynamic parameters the reference
+    injects from the window bounds and the inventory (stream/process.py:153-196):
+    ``trim`` cuts to [starttime, endtime], ``remove_sensitivity`` divides by
+    `sensitivity`."""
     for name, params in operations:
         if callable(name):
             x = name(x, **params)
@@ -166,7 +177,22 @@ def apply_operations(x, sampling_rate, operations, ctx=None):
         if name not in _OPS:
             raise NotImplementedError(f'"{name}" is not an implemented operation or callable.')
         p = dict(params)
-        if name == 'detrend':
+        if name == 'merge':
+            if isinstance(x, np.ndarray):
+                continue                               # a single segment is already merged
+            x, t0 = _seg.merge(x, sampling_rate, **p)
+            if np.isnan(x).any():
+                raise ValueError('merge left gaps (masked samples); pass a fill_value')
+            x = np.ascontiguousarray(x, dtype=np.float32)
+        elif name == 'trim':
+            p.setdefault('starttime', starttime)
+            p.setdefault('endtime', endtime)
+            x, t0 = _seg.trim(x, sampling_rate, t0, **p)
+        elif name == 'remove_sensitivity':
+            if sensitivity is None:
+                raise ValueError('remove_sensitivity needs the channel sensitivity (inventory)')
+            x = _seg.remove_sensitivity(x, sensitivity)
+        elif name == 'detrend':
             x = detrend(x, ctx=ctx, **p)
         elif name == 'taper':
             x = taper(x, sampling_rate, ctx=ctx, **p)
@@ -179,7 +205,10 @@ def apply_operations(x, sampling_rate, operations, ctx=None):
             x, sampling_rate = resample(x, sampling_rate, new_rate, ctx=ctx, **p)
         elif name == 'interpolate':
             new_rate = p.pop('sampling_rate')
+            if 'starttime' in p:                       # ObsPy: absolute start time of the new axis
+                p['starttime_offset'] = p.pop('starttime') - t0
+            t0 = t0 + p.get('starttime_offset', 0.0)
             x, sampling_rate = interpolate(x, sampling_rate, new_rate, ctx=ctx, **p)
         elif name == 'running_rms':
             x, sampling_rate = running_rms(x, sampling_rate, ctx=ctx, **p)
-    return x, sampling_rate
+    return (x, sampling_rate, t0) if return_t0 else (x, sampling_rate)
