@@ -56,7 +56,9 @@ __global__ void k_dirichlet(float* __restrict__ hr, long n, long rows, const dou
   const double al = alpha[r];
   const double inv_n = 1.0 / (double)n;
   double u = (double)m * inv_n - al;
-  u -= rint(u);                                     // [-1/2, 1/2]
+  const double uw = rint(u);
+  u -= uw;                                          // [-1/2, 1/2]; sin(pi u) changes sign with odd uw (cot does not)
+  const double wsgn = ((long)uw & 1) ? -1.0 : 1.0;
   double su, cu;
   sincospi(u, &su, &cu);
   double sa, ca;
@@ -65,7 +67,7 @@ __global__ void k_dirichlet(float* __restrict__ hr, long n, long rows, const dou
   double h;
   if (n & 1) {
     if (fabs(su) < 1e-12) h = 1.0;
-    else h = -sgn * sa / su * inv_n;
+    else h = -sgn * wsgn * sa / su * inv_n;
   } else {
     if (fabs(su) < 1e-12) h = ((double)(n - 1) + ca * sgn) * inv_n;
     else h = -sgn * sa * (cu / su) * inv_n;
