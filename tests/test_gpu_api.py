@@ -116,6 +116,27 @@ def test_process_batched_equals_process(ctx):
     assert relerr(out, ref) < TOL
 
 
+def test_process_hashes_waveforms(ctx):
+    """core/process.py:78-79,146-149: sha256 of the two preprocessed traces per processed step."""
+    from xcorr_amd.util import hasher
+    fs, wl = 50., 40.
+    tr = R.synthetic_traces(2, 7000)
+    client = core.ArrayClient({'IM.H10N1..EDH': tr[0], 'IU.RAR.10.BHZ': tr[1]}, fs)
+    pair = 'IM.H10N1..EDH-IU.RAR.10.BHZ'
+    ds = core.init(pair, 0., 7000 / fs, sampling_rate=fs, window_length=wl, window_overlap=.5, hash_waveforms=True)
+    core.process(ds, client, hash_waveforms=True)
+    done = ds.status[0] == 1
+    assert done.any() and all(len(h) == 64 for h in ds.hash[0][done]) and (ds.hash[0][~done] == 'n/a').all()
+    it = int(np.flatnonzero(done)[0])
+    (xa, ta), (xb, tb) = client.get_pair_processed_waveforms(pair=pair, time=ds.time[it], duration=wl, sampling_rate=fs)
+    want = hasher.hash_stream([(hasher.trace_stats('IM.H10N1..EDH', ta, fs, len(xa)), xa),
+                               (hasher.trace_stats('IU.RAR.10.BHZ', tb, fs, len(xb)), xb)])
+    assert ds.hash[0, it] == want and len(set(ds.hash[0][done])) == done.sum()
+    ds2 = core.init(pair, 0., 7000 / fs, sampling_rate=fs, window_length=wl, window_overlap=.5)
+    core.process(ds2, client, hash_waveforms=True)                 # no hash variable: nothing to fill
+    assert ds2.hash is None and np.array_equal(ds2.cc, ds.cc)
+
+
 def test_signal_timeshift_and_core_postprocess(ctx):
     """signal.timeshift (array form) and the whole core.postprocess chain on a
     processed dataset, against the oracle chain (core/postprocess.py:133-141)."""
@@ -125,8 +146,8 @@ def test_signal_timeshift_and_core_postprocess(ctx):
     y = sig.timeshift(a, d, sampling_rate=50.)
     assert y.shape == (2, 3, 800) and y.dtype == np.float32
     assert relerr(y, R.timeshift(a, d, 50.)) < TOL
-    with pytest.raises(NotImplementedError):
-        sig.timeshift(a, 0.1, sampling_rate=50., fast=False)
+    yf = sig.timeshift(a, d, sampling_rate=50., fast=False)        # fft/ifft path keeps all 801 samples
+    assert yf.shape == (2, 3, 801) and relerr(yf, R.timeshift_fft(a, d, 1 / 50.)) < TOL
     with pytest.raises(TypeError):
         sig.timeshift(a, 1, sampling_rate=50.)
     # process + postprocess on an in-memory client with sub-sample start offsets

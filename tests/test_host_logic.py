@@ -320,3 +320,47 @@ def test_rotate_and_sensitivity():
     x = np.array([2., 4.], np.float32)
     y = remove_sensitivity(x, 2.0)
     assert y.dtype == np.float32 and np.array_equal(y, [1, 2])
+
+
+def test_hasher_restates_reference_serialisation():
+    """util/hasher.py:38-48,106-139,174-181: json form and update order; sha256 recomputed by hand."""
+    import hashlib, json
+    from xcorr_amd.util import hasher
+    obj = {'b': np.int32(2), 'a': np.float64(.5), 'sha256_hash': 'ignored', 'scale_factor': 1., 'c': [1, 2]}
+    text = json.dumps({'a': .5, 'b': 2, 'c': [1, 2]}, separators=(',', ':'), sort_keys=True, indent=4)
+    assert hasher.hash_obj(obj) == hashlib.sha256(text.encode()).hexdigest()
+    assert hasher.utcdatetime_repr(1421280000.0) == 'UTCDateTime(2015, 1, 15, 0, 0)'
+    assert hasher.utcdatetime_repr(1421280005.5) == 'UTCDateTime(2015, 1, 15, 0, 0, 5, 500000)'
+    st = hasher.trace_stats('IM.H10N1..EDH', 1421280000.0, 50., 4)
+    assert st['endtime'] == 1421280000.06 and st['location'] == '' and st['delta'] == .02
+    data = np.arange(4, dtype=np.float32)
+    head = dict(st, starttime='UTCDateTime(2015, 1, 15, 0, 0)', endtime='UTCDateTime(2015, 1, 15, 0, 0, 0, 60000)')
+    h = hashlib.sha256()
+    h.update(json.dumps(head, separators=(',', ':'), sort_keys=True, indent=4).encode())
+    for d in data:
+        h.update(d.tobytes())
+    assert hasher.hash_trace(st, data) == h.hexdigest()
+    # stream = one running hash, order matters
+    two = hasher.hash_stream([(st, data), (st, data[::-1].copy())])
+    assert two != hasher.hash_stream([(st, data[::-1].copy()), (st, data)])
+    assert two != hasher.hash_trace(st, data)
+
+
+def test_io_keeps_hash_variable(tmp_path):
+    from xcorr_amd import io
+    ds = core.init('A.B..C-D.E..F', 0., 3600., sampling_rate=10., window_length=600., window_overlap=.5,
+                   hash_waveforms=True)
+    ds.status[...] = 1
+    ds.hash[0, 2] = 'ab' * 32
+    path = str(tmp_path / 'h.nc')
+    assert io.write(ds, path)
+    r = io.read(path)
+    assert r.hash.shape == ds.hash.shape and r.hash[0, 2] == 'ab' * 32 and r.hash[0, 0] == 'n/a'
+
+
+def test_init_hash_variable():
+    from xcorr_amd.core import init
+    ds = init('IM.H10N1..EDH-IU.RAR.10.BHZ', 0., 7200., sampling_rate=50., window_length=3600., window_overlap=.5,
+              hash_waveforms=True)
+    assert ds.hash.shape == ds.status.shape and (ds.hash == 'n/a').all()
+    assert init('A-B', 0., 7200., sampling_rate=50., window_length=3600., window_overlap=.5).hash is None

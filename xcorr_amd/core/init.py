@@ -18,7 +18,7 @@ class CCDataset:
     """Plain-array stand-in for the reference's ``xarray.Dataset``."""
 
     def __init__(self, pair, time, lag, lag_attrs, cc_attrs, time_attrs,
-                 dtype=np.float32):
+                 dtype=np.float32, hash_waveforms=False):
         self.pair = np.asarray(pair, dtype=object)
         self.time = np.asarray(time)            # window CENTRES (core/init.py:163)
         self.lag = np.asarray(lag, dtype=np.float64)
@@ -31,6 +31,8 @@ class CCDataset:
         self.pair_offset = np.zeros(shape[:2], dtype=np.float64)
         self.time_offset = np.zeros(shape[:2], dtype=np.float64)
         self.attrs = {'history': ''}
+        # 'n/a' until processed (core/init.py:252-255); None when hashing was not requested
+        self.hash = np.full(shape[:2], 'n/a', dtype=object) if hash_waveforms else None
 
     def to_xarray(self):
         import xarray as xr
@@ -43,6 +45,8 @@ class CCDataset:
         ds['status'] = (('pair', 'time'), self.status)
         ds['pair_offset'] = (('pair', 'time'), self.pair_offset)
         ds['time_offset'] = (('pair', 'time'), self.time_offset)
+        if self.hash is not None:
+            ds['hash'] = (('pair', 'time'), self.hash)
         ds.attrs = dict(self.attrs)
         return ds
 
@@ -88,7 +92,8 @@ def init(pair, starttime, endtime, preprocess=None, attrs=None, sampling_rate=No
         end exclusive); a single float c means (-|c|, |c|) (the reference raises there,
         ``tuple(-c, c)``: SURVEY a12).
     inventory, stationary_poi : pair geodesy (util/receiver.py) is out of scope: accepted, unused.
-    hash_waveforms : accepted; waveform hashing is storage-integrity plumbing, not built.
+    hash_waveforms : adds the ``hash`` variable ('n/a' per (pair, time), core/init.py:252-272) that
+        ``process`` fills with the sha256 of the two preprocessed traces (util/hasher.py).
 
     Legacy numeric form of this build, still accepted:
         init(pair, start_s, end_s, sampling_rate, window_length, window_overlap, ...).
@@ -158,7 +163,7 @@ def init(pair, starttime, endtime, preprocess=None, attrs=None, sampling_rate=No
     time_attrs = {'window_length': window_length,
                   'window_overlap': window_overlap, 'closed': closed}
     ds = CCDataset(pairs, time, lag[nmin:nmax], lag_attrs, cc_attrs,
-                   time_attrs, dtype=dtype)
+                   time_attrs, dtype=dtype, hash_waveforms=hash_waveforms)
     ds.time_is_datetime = bool(dt0 or dt1)
     ds.pair_attrs = {'long_name': 'Cross-correlation receiver pair', 'standard_name': 'receiver_pair',
                      'units': '-', 'preprocess': preprocess if preprocess is not None else {}}

@@ -28,9 +28,13 @@ def process(dataset, client, inventory=None, retry_missing=False,
     client  : object with ``get_pair_processed_waveforms(pair, time, duration,
         ...)`` returning two (data, starttime_seconds) items or None
         (stream/client.py:1116-1149; :class:`ArrayClient` here).
-    Waveform hashing (core/process.py:146-149) is storage-integrity plumbing
-    and not part of this build (`hash_waveforms` is accepted and ignored).
+    hash_waveforms : when the container has a ``hash`` variable (``init(...,
+        hash_waveforms=True)``), store the sha256 of the two preprocessed traces per
+        (pair, time) (core/process.py:78-79,146-149; util/hasher.py:142-215 -- headers
+        rebuilt from the pair string, the start times and the sampling rate).
     """
+    from ..util import hasher
+    hash_waveforms = hash_waveforms and getattr(dataset, 'hash', None) is not None
     la = dataset.lag_attrs
     npts, imin, imax = la['npts'], la['index_min'], la['index_max']
     wl = dataset.time_attrs['window_length']
@@ -51,6 +55,12 @@ def process(dataset, client, inventory=None, retry_missing=False,
             (xa, ta), (xb, tb) = w
             dataset.pair_offset[ip, it] = ta - tb            # :135-138
             dataset.time_offset[ip, it] = ta + wl / 2 - t    # :139-143
+            if hash_waveforms:                               # :146-149, the whole traces as received
+                ids = str(p).split('-')
+                fs = la['sampling_rate']
+                dataset.hash[ip, it] = hasher.hash_stream(
+                    (hasher.trace_stats(ids[k] if k < len(ids) else '', tk, fs, len(xk)), np.asarray(xk))
+                    for k, (xk, tk) in enumerate(((xa, ta), (xb, tb))))
             xs.append(np.asarray(xa[:npts], dtype=np.float32))
             ys.append(np.asarray(xb[:npts], dtype=np.float32))
             todo.append((ip, it))

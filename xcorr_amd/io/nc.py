@@ -118,6 +118,12 @@ def write(data, path, close=True, force_write=False, hash_data=True, verb=0):
                 v = nc.createVariable(name, 'd', ('pair', 'time'))
                 v[:] = getattr(data, name)
                 v.units, v.description = 's', desc
+            if getattr(data, 'hash', None) is not None:            # core/init.py:252-272
+                nc.createDimension('hash_strlen', 64)
+                v = nc.createVariable('hash', 'c', ('pair', 'time', 'hash_strlen'))
+                v[:] = np.array([[list(str(h).ljust(64)[:64]) for h in row] for row in data.hash], dtype='S1')
+                v.long_name, v.standard_name, v.units = ('pair preprocessed stream hash',
+                                                         'pair_preprocessed_stream_hash', '-')
             for k, a in data.attrs.items():
                 setattr(nc, k, _attr(a))
             nc.Conventions = 'CF-1.9'
@@ -169,7 +175,12 @@ def read(path, fast=False, quick_and_dirty=False):
         cc = np.array(nc.variables['cc'][:])
         cc = cc.astype(cc.dtype.newbyteorder('='))             # the file is big-endian
         ds = CCDataset(pairs, np.array(tv[:], dtype=np.float64), np.array(nc.variables['lag'][:], dtype=np.float64), la, ca, ta,
-                       dtype=cc.dtype)
+                       dtype=cc.dtype, hash_waveforms='hash' in nc.variables)
+        if ds.hash is not None:
+            hv = nc.variables['hash'][:]
+            for i in range(hv.shape[0]):
+                for j in range(hv.shape[1]):
+                    ds.hash[i, j] = b''.join(hv[i, j]).decode().rstrip()
         ds.cc[...] = cc
         ds.status[...] = nc.variables['status'][:]
         ds.pair_offset[...] = nc.variables['pair_offset'][:]
