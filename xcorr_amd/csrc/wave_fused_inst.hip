@@ -53,7 +53,7 @@ hipError_t XCX_CAT3(launch_wflow_, XCX_FC_L, _, XCX_FR_L)(const WFlowArgs& a, hi
   constexpr size_t lds = sizeof(float) * PG::kLdsFloats;
   const int nbatch = (a.count + a.B - 1) / a.B;
   const long wpg = (long)(PG::CWX + PG::RWX) * a.B;
-  const long nwg = 8L * wpg * (nbatch + kFlowLag);           // trailing groups: rows of the last batches
+  const long nwg = 8L * wpg * (nbatch + a.lag);               // trailing groups: rows of the last batches
   if (nwg > 0x7fffffffL) return hipErrorInvalidValue;
   const dim3 grid((unsigned)nwg);
   if (a.nstack < 0)

@@ -1223,6 +1223,11 @@ struct WFlowArgs {
   int* err;
   const cf* tw_N1; const cf* tw_N2h; const cf* tw_unt; const cf* tw_N;
   Geom g;
+  int lag;                          // rows of batch g-lag ride in group g (kFlowLag by default)
+  int local;                        // 1: XCD-local assignment -- pair-window pwl of a batch is processed entirely by
+                                    // the workgroups with blockIdx.x % 8 == pwl % 8 (B % 8 == 0), so its T stays in
+                                    // ONE XCD's L2 (sc1 loads are L2-served).  Only coherent with a cached T if those
+                                    // workgroups really share an XCD: experiment switch (XCX_FLOW_LOCAL)
 };
 
 // completion counters are sharded by the XCD label of the signalling wave (8 words, one 128-byte
@@ -1230,6 +1235,8 @@ struct WFlowArgs {
 // batch -- longer than the batch itself.  A waiter reads the 8 shards with one wave instruction.
 constexpr int kFlowShardInts = 32;                           // ints per shard (one cache line)
 constexpr int kFlowLag = 2;                                  // rows of batch g-2 ride in group g
+
+XCX_DEV int flow_npw_x(int Bc, int x) { return Bc > x ? (Bc - x + 7) / 8 : 0; }   // pair-windows pwl < Bc with pwl % 8 == x
 
 XCX_DEV bool flow_wait8(const int* shards, int target_lane, int* err) {
   const int lane = tid_of<kWNT>();
@@ -1277,12 +1284,15 @@ void k_wpair_flow(WFlowArgs a) {
     if (b >= nbatch) return;
     const int Bc = min(B, a.count - b * B);
     const int ci = (grp * PG::CWX + pos) * kWPB + wave;
-    const int k2 = (ci / B) * 8 + x;
-    const int pwl = ci % B;
+    int k2 = (ci / B) * 8 + x;
+    int pwl = ci % B;
+    if (a.local) { k2 = ci % (N2h + 1); pwl = (ci / (N2h + 1)) * 8 + x; }
     if (k2 > N2h || pwl >= Bc) return;
     if (b >= a.R) {                                           // ring slot consumed?
       const int bp = b - a.R;
-      if (!flow_wait8(a.rdone + (size_t)bp * 8 * kFlowShardInts, nrx * min(B, a.count - bp * B), a.err)) return;
+      const int Bp = min(B, a.count - bp * B);
+      const int tgt = a.local ? ((lane == x) ? PG::NRW * kWPB * flow_npw_x(Bp, x) : 0) : nrx * Bp;
+      if (!flow_wait8(a.rdone + (size_t)bp * 8 * kFlowShardInts, tgt, a.err)) return;
     }
     cf* Tb = a.T + (size_t)(b % a.R) * B * N1 * (N2h + 1);
     pair_col_body<RXC, MODE>(lds, a.X, a.spec_pitch, a.pw[b * B + pwl], a.nstack, k2,
@@ -1291,17 +1301,19 @@ void k_wpair_flow(WFlowArgs a) {
     if (lane == 0)
       __hip_atomic_fetch_add(a.cdone + ((size_t)b * 8 + x) * kFlowShardInts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   } else {
-    const int b = grp_b - kFlowLag;
+    const int b = grp_b - a.lag;
     if (b < 0 || b >= nbatch) return;
     const int Br = min(B, a.count - b * B);
     const int ri = grp * PG::RWX + (pos - PG::CWX);
-    const int pwl = ri / PG::RWX;
-    const int wgblk = (ri % PG::RWX) * 8 + x;
+    int pwl = ri / PG::RWX;
+    int wgblk = (ri % PG::RWX) * 8 + x;
+    if (a.local) { pwl = (ri / PG::NRW) * 8 + x; wgblk = ri % PG::NRW; }
     if (wgblk >= PG::NRW || pwl >= Br) return;               // workgroup-uniform
     const int blk = wgblk * kWPB + wave;
     // a timed-out wait must not leave the workgroup's barriers one wave short: all four waves
     // poll the same counters and agree
-    if (!flow_wait8(a.cdone + (size_t)b * 8 * kFlowShardInts, ncx * Br, a.err)) return;
+    const int ctgt = a.local ? ((lane == x) ? (N2h + 1) * flow_npw_x(Br, x) : 0) : ncx * Br;
+    if (!flow_wait8(a.cdone + (size_t)b * 8 * kFlowShardInts, ctgt, a.err)) return;
     const cf* __restrict__ Tt = t_quarter(a.T + ((size_t)(b % a.R) * B + pwl) * (size_t)N1 * (N2h + 1), blk, N2h);
     float* o = a.out + a.pw[b * B + pwl].out_off;
     float* stg = reinterpret_cast<float*>(lds_all);

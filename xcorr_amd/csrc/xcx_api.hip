@@ -981,7 +981,11 @@ static int flow_run(xcx_plan* p, size_t first, size_t count, int nstack, float* 
   const Geom& g = p->g;
   int rc;
   if ((rc = flow_check(ctx))) return rc;                     // a previous launch timed out?
-  const int B = p->batch, R = p->flow_R;
+  // experiment (XCX_FLOW_LOCAL=1 with XCX_FLOW_T=plain): XCD-local pair-windows, batches of XCX_FLOW_B (multiple of 8)
+  static const bool local = getenv("XCX_FLOW_LOCAL") && atoi(getenv("XCX_FLOW_LOCAL")) != 0;
+  static const int localB = getenv("XCX_FLOW_B") ? std::max(8, atoi(getenv("XCX_FLOW_B")) / 8 * 8) : 8;
+  static const int lag = getenv("XCX_FLOW_LAG") ? std::max(1, atoi(getenv("XCX_FLOW_LAG"))) : kFlowLag;
+  const int B = local ? localB : p->batch, R = std::max(p->flow_R, lag + 2);
   const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
   const size_t tbytes = sizeof(cf) * tm_per * (size_t)B * R;
   if (ctx->flow_T_bytes < tbytes) {
@@ -1021,6 +1025,8 @@ static int flow_run(xcx_plan* p, size_t first, size_t count, int nstack, float* 
   a.tw_unt = (const cf*)p->tw_unt.ptr;
   a.tw_N = (const cf*)p->tw_N.ptr;
   a.g = g;
+  a.lag = lag;
+  a.local = local ? 1 : 0;
   {
     ProfScope phase(p, KID_PAIR_PHASE, (int)count);
     ProfScope ps(p, KID_PAIR_FUSED, (int)count);
