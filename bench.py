@@ -358,6 +358,19 @@ def main():
                 'value': len(prs) * W_h / dt_h, 'unit': 'pair-windows/s',
                 'sample': f'{len(prs) * W_h} pair-windows, host traces in ({host_tr.nbytes / 1e6:.0f} MB) and '
                           f'full-lag CCFs out ({len(prs) * W_h * L * 4 / 1e6:.0f} MB) into page-locked result arrays, per call'}
+            # the link's own ceiling: one device -> page-locked host copy of the same size
+            nb = len(prs) * W_h * L * 4 // 4 * 4
+            hbuf = ctx.pinned_empty((nb // 4,), np.float32)
+            dsrc = ctx.empty((nb // 4,))
+            dsrc.copy_to(hbuf); ctx.sync()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                dsrc.copy_to(hbuf)
+            ctx.sync()
+            d2h = 3 * nb / (time.perf_counter() - t1) / 1e9
+            extras['pcie_inclusive']['d2h_GBps_measured'] = d2h
+            extras['pcie_inclusive']['frac_of_measured_d2h'] = (len(prs) * W_h * L * 4 / dt_h / 1e9) / d2h
+            dsrc.free()
             hplan.close()
         except Exception as e:          # context number only
             extras['pcie_inclusive'] = {'error': str(e)}

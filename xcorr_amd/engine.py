@@ -73,6 +73,13 @@ class DeviceArray:
                                         C.c_void_p(self.ptr), self.nbytes))
         return out
 
+    def copy_to(self, out):
+        """Copy into an existing host array of the same size (e.g. page-locked, `Context.pinned_empty`)."""
+        if out.nbytes != self.nbytes or not out.flags['C_CONTIGUOUS']:
+            raise ValueError('copy_to needs a contiguous host array of the same size')
+        check(_ffi.lib().xcx_memcpy_d2h(self.ctx.handle, ptr(out), C.c_void_p(self.ptr), self.nbytes))
+        return out
+
     def rows_to_host(self, row0, nrows, width):
         """Copy rows [row0, row0+nrows) of a 2-D buffer, first `width` cols."""
         pitch = self.shape[-1] * self.dtype.itemsize
