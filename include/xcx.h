@@ -273,8 +273,10 @@ int xcx_cc2d(xcx_ctx* ctx, const float* tiles, int T, int F, int L,
  *   xcx_rfft           : x [batch][size] real  -> out [batch][n/2+1] complex with
  *                        n = size - (size & 1)  (fft.py:357 drops an odd last sample)
  *   xcx_irfft          : in [batch][m] complex -> x [batch][2(m-1)] real  (fft.py:475)
- * Bluestein's chirp convolution on the cross-correlation engine; supported while
- * 2 (nin + nout - 1) - 1 <= 737280 (n <= 184320 complex, n <= 245760 real). */
+ * Bluestein's chirp convolution on the cross-correlation engine: one convolution while
+ * 2 (nin + nout - 1) - 1 <= 737280 (n <= 184320 complex, n <= 245760 real); longer axes
+ * (the 359 998-sample lag axis) are split into partial transforms over blocks of inputs
+ * and outputs that are accumulated (cost grows with the square of n / 184320). */
 int xcx_fft(xcx_ctx* ctx, const float* in, float* out, long batch, long n, int on_device);
 int xcx_ifft(xcx_ctx* ctx, const float* in, float* out, long batch, long n, int on_device);
 int xcx_rfft(xcx_ctx* ctx, const float* x, float* out, long batch, long size, int on_device);
@@ -285,7 +287,7 @@ int xcx_irfft(xcx_ctx* ctx, const float* in, float* x, long batch, long m, int o
  *   y = irfft(interp(rfft(x) * window_half), num) * num / npts,   x [batch][npts] -> y [batch][num],
  * the spectrum linearly interpolated at bin positions j * ratio (ratio = npts * new_rate /
  * (num * old_rate)), clamped at the last bin like numpy.interp.  window_half: HOST float32
- * [npts/2 + 1] (ifftshift(get_window(w, npts))[:npts/2+1]) or NULL.  npts, num <= 245760. */
+ * [npts/2 + 1] (ifftshift(get_window(w, npts))[:npts/2+1]) or NULL.  Long rows are transformed in blocks (see xcx_fft). */
 int xcx_resample(xcx_ctx* ctx, const float* x, float* y, long batch, long npts, long num,
                  double ratio, const float* window_half, int on_device);
 

@@ -122,9 +122,44 @@ def test_snr_with_envelope(ctx):
 def test_errors(ctx):
     with pytest.raises(XcxError):
         ops.fft(ctx, np.zeros((1, 1), np.complex64))
-    with pytest.raises(XcxError):
-        ops.fft(ctx, np.zeros((1, 200000), np.complex64))            # beyond the Bluestein limit
     with pytest.raises(TypeError):
         signal.fft(np.zeros(8, np.float32), dtype=np.dtype('float32'))
     with pytest.raises(TypeError):
         signal.rfft(np.zeros(8, np.float32), dtype=np.dtype('complex64'))
+
+
+def test_full_lag_axis_transforms(ctx):
+    """The lag axis of the headline workload: 359 999 lags -> rfft of 359 998 = 2 x 179 999 (prime)
+    samples, hilbert / envelope of all 359 999 = 599 x 601.  Longer than one chirp convolution of
+    the engine: the transform is split into partial transforms over input / output blocks."""
+    rng = np.random.default_rng(8)
+    n = 359999
+    t = np.arange(n)
+    x = (0.05 * rng.standard_normal((2, n))).astype(np.float32)
+    x += (np.exp(-0.5 * ((t - 179800) / 900.0) ** 2) * np.cos(2 * np.pi * t / 23.0)).astype(np.float32)
+    X = ops.rfft(ctx, x)
+    ref = np.fft.rfft(x[:, :n - 1].astype(np.float64), axis=-1)
+    assert X.shape == ref.shape == (2, 180000) and relerr(X, ref) < TOL
+    back = ops.irfft(ctx, X)
+    assert back.shape == (2, n - 1) and relerr(back, x[:, :n - 1]) < 2 * TOL
+    z = ops.hilbert(ctx, x)
+    zr = R.hilbert(x)
+    assert z.shape == (2, n) and relerr(z, zr) < TOL
+    e = ops.hilbert(ctx, x, envelope=True)
+    assert relerr(e, np.abs(zr)) < TOL
+    # complex transform of the same length (2 x 2 partial transforms), device-resident rows
+    c = (x[:1] + 1j * np.roll(x[:1], 1000, axis=-1)).astype(np.complex64)
+    assert relerr(ops.fft(ctx, c), np.fft.fft(c.astype(np.complex128), axis=-1)) < TOL
+    assert relerr(ops.ifft(ctx, c), np.fft.ifft(c.astype(np.complex128), axis=-1)) < TOL
+
+
+def test_split_transform_boundaries(ctx):
+    """Lengths right at and beyond the single-convolution limit (np = nin + nout - 1 <= 368640)."""
+    rng = np.random.default_rng(9)
+    for n in (184320, 184321, 245760, 245762, 400001):
+        x = rng.standard_normal((1, n)).astype(np.float32)
+        X = ops.rfft(ctx, x)
+        m = n - (n & 1)
+        assert relerr(X, np.fft.rfft(x[:, :m].astype(np.float64), axis=-1)) < TOL
+    c = (rng.standard_normal((1, 184321)) + 1j * rng.standard_normal((1, 184321))).astype(np.complex64)
+    assert relerr(ops.fft(ctx, c), np.fft.fft(c.astype(np.complex128), axis=-1)) < TOL

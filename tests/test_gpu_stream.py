@@ -194,3 +194,13 @@ def test_reference_edh_chain_with_merge_and_trim(ctx):
     assert relerr(np.asarray(y).reshape(1, -1), r) < 5 * TOL
     with pytest.raises(ValueError):                 # a gap without fill_value leaves masked samples
         stream.apply_operations(segs, fs, [('merge', {'method': 1})], ctx=ctx)
+
+
+def test_resample_long_rows(ctx):
+    """Fourier resample beyond one chirp convolution (npts 500 000 -> 200 000): split transforms."""
+    rng = np.random.default_rng(12)
+    x = rng.standard_normal((1, 500000)).astype(np.float32)
+    y, fs2 = stream.resample(x, 250., 100., ctx=ctx)
+    ref = R.resample_fourier(x, 250., 100.)
+    assert fs2 == 100. and y.shape == ref.shape == (1, 200000)
+    assert relerr(y, ref) < TOL

@@ -43,6 +43,10 @@ struct BsGeom {
   int in_complex;          // input rows are interleaved complex (else real)
   int half_weights;        // irfft: double every bin except DC and Nyquist (bin n/2)
   long in_pitch;           // elements (floats or complex) between input rows
+  // partial transform (long axes are split): inputs m0 .. m0+nin, outputs k0 .. k0+nout of the
+  // length-n transform; rows of `out` are out_pitch elements apart (0: nout); accumulate: out +=
+  long m0 = 0, k0 = 0, out_pitch = 0;
+  int accumulate = 0;
 };
 
 // c[m] = exp(sign i pi m^2 / n), exact argument reduction in integers
@@ -63,22 +67,24 @@ __global__ void k_bs_pre(const float* __restrict__ in, BsGeom g, long B, float* 
     if (b < B) {
       float ar = 0.f, ai = 0.f;
       if (t < g.nin) {
+        const long m = g.m0 + t;
         double vr, vi = 0.0;
         if (g.in_complex) {
-          const float2 v = reinterpret_cast<const float2*>(in)[b * g.in_pitch + t];
+          const float2 v = reinterpret_cast<const float2*>(in)[b * g.in_pitch + m];
           vr = v.x; vi = v.y;
         } else {
-          vr = in[b * g.in_pitch + t];
+          vr = in[b * g.in_pitch + m];
         }
-        if (g.half_weights && t != 0 && 2 * t != g.n) { vr *= 2.0; vi *= 2.0; }
-        const double2 c = chirp(t, g.n, g.sign);
+        if (g.half_weights && m != 0 && 2 * m != g.n) { vr *= 2.0; vi *= 2.0; }
+        const double2 c = chirp(m, g.n, g.sign);
         ar = (float)(vr * c.x - vi * c.y);
         ai = (float)(vr * c.y + vi * c.x);
       }
       tr[(b * 2 + 0) * np + t] = ar;
       tr[(b * 2 + 1) * np + t] = ai;
     } else {                                    // the two chirp stations
-      const double2 c = chirp(t - (g.nout - 1), g.n, -g.sign);      // conj(c)[u], u = t - (nout-1)
+      // conj(c)[m - k] at m - k = (m0 + s) - (k0 + u), s - u = t - (nout-1)
+      const double2 c = chirp(t - (g.nout - 1) - (g.k0 - g.m0), g.n, -g.sign);
       tr[((B + 0) * 2 + 0) * np + t] = (float)c.x;
       tr[((B + 0) * 2 + 1) * np + t] = (float)-c.y;
       tr[((B + 1) * 2 + 0) * np + t] = (float)c.y;
@@ -95,21 +101,28 @@ __global__ void k_bs_post(const float* __restrict__ R, long ld, BsGeom g, long B
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const long b = i / g.nout, k = i % g.nout;
     const double re = R[(2 * b) * ld + k], im = R[(2 * b + 1) * ld + k];
-    const double2 c = chirp(k, g.n, g.sign);
-    const double orr = (re * c.x - im * c.y) * scale, oi = (re * c.y + im * c.x) * scale;
-    if (real_only == 1) out[i] = (float)orr;
-    else if (real_only == 2) out[i] = (float)sqrt(orr * orr + oi * oi);
-    else reinterpret_cast<float2*>(out)[i] = make_float2((float)orr, (float)oi);
+    const double2 c = chirp(g.k0 + k, g.n, g.sign);
+    double orr = (re * c.x - im * c.y) * scale, oi = (re * c.y + im * c.x) * scale;
+    const long o = b * (g.out_pitch ? g.out_pitch : g.nout) + g.k0 + k;
+    if (real_only == 1) out[o] = (float)(g.accumulate ? (double)out[o] + orr : orr);
+    else if (real_only == 2) out[o] = (float)sqrt(orr * orr + oi * oi);
+    else {
+      float2* oc = reinterpret_cast<float2*>(out) + o;
+      if (g.accumulate) { orr += (double)oc->x; oi += (double)oc->y; }
+      *oc = make_float2((float)orr, (float)oi);
+    }
   }
 }
 
-int bluestein(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom g, double scale, int real_only,
-              int in_dev, int out_dev) {
+constexpr long kBsMaxNp = (737280 + 1) / 2;          // 2 np - 1 <= 737280, the longest correlation plan
+
+int bluestein_core(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom g, double scale, int real_only,
+                   int in_dev, int out_dev) {
   if (!ctx || !in || !out) return set_err(XCX_EINVAL, "null argument");
   if (batch < 1 || g.n < 2) return set_err(XCX_EINVAL, "batch >= 1 and n >= 2 required");
   HIP_TRY(hipSetDevice(ctx->device));
   g.np = g.nin + g.nout - 1;
-  if (2 * g.np - 1 > 737280) return set_err(XCX_EUNSUPPORTED, "transform length %ld too long for the Bluestein path", g.n);
+  if (g.np > kBsMaxNp) return set_err(XCX_EUNSUPPORTED, "transform length %ld too long for the Bluestein path", g.n);
   int rc;
   const long imin = g.nin - 1, imax = g.nin - 1 + g.nout;
   int slot = -1;
@@ -130,7 +143,7 @@ int bluestein(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom g, d
   if ((rc = tr.ensure(ctx, sizeof(float) * 2 * g.np * (chunk + 2)))) return rc;
   if ((rc = lin.ensure(ctx, sizeof(float) * ld * 2 * chunk))) return rc;
   const size_t in_row = (size_t)g.in_pitch * (g.in_complex ? 8 : 4);
-  const size_t out_row = (size_t)g.nout * (real_only ? 4 : 8);
+  const size_t out_row = (size_t)(g.out_pitch ? g.out_pitch : g.nout) * (real_only ? 4 : 8);
   const bool stage_in = !in_dev, stage_out = !out_dev;
   const float* ind = in;
   float* outd = out;
@@ -170,6 +183,61 @@ int bluestein(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom g, d
   }
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return XCX_OK;
+}
+
+// Any length: an axis whose chirp convolution (nin + nout - 1 points) exceeds the longest
+// correlation plan is split into si input blocks x so output blocks,
+//     out[k0 + u] = sum over input blocks of  c[k] sum_t (in[m0+t] c[m0+t]) conj(c)[(k0+u) - (m0+t)],
+// each a partial transform of ceil(nin/si) + ceil(nout/so) - 1 points accumulated into `out`
+// (the full-lag axis 359 998: rfft = 2 x 1, hilbert = 2 x 1 forward and 1 x 2 back, fft = 2 x 2).
+int bluestein(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom g, double scale, int real_only,
+              int in_dev, int out_dev) {
+  if (!ctx || !in || !out) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || g.n < 2) return set_err(XCX_EINVAL, "batch >= 1 and n >= 2 required");
+  if (g.nin + g.nout - 1 <= kBsMaxNp) return bluestein_core(ctx, in, out, batch, g, scale, real_only, in_dev, out_dev);
+  if (real_only == 2) return set_err(XCX_EINVAL, "modulus output of a split transform goes through a complex buffer");
+  long si = 1, so = 1;
+  auto np_of = [&](long a, long b) { return (g.nin + a - 1) / a + (g.nout + b - 1) / b - 1; };
+  while (np_of(si, so) > kBsMaxNp) {
+    if ((g.nin + si - 1) / si >= (g.nout + so - 1) / so) ++si; else ++so;
+    if (si * so > 4096) return set_err(XCX_EUNSUPPORTED, "transform length %ld needs more than 4096 partial transforms", g.n);
+  }
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc;
+  const size_t in_row = (size_t)g.in_pitch * (g.in_complex ? 8 : 4);
+  const size_t out_row = (size_t)(g.out_pitch ? g.out_pitch : g.nout) * (real_only ? 4 : 8);
+  void *din = nullptr, *dout = nullptr;                     // own buffers: the core uses the context scratch
+  auto done = [&](int r) { (void)hipFree(din); (void)hipFree(dout); return r; };
+  const float* ind = in; float* outd = out;
+  if (!in_dev) {
+    if (hipMalloc(&din, in_row * batch) != hipSuccess) return done(set_err(XCX_ENOMEM, "split transform input"));
+    if (hipMemcpyAsync(din, in, in_row * batch, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return done(set_err(XCX_EHIP, "H2D"));
+    ind = (const float*)din;
+  }
+  if (!out_dev) {
+    if (hipMalloc(&dout, out_row * batch) != hipSuccess) return done(set_err(XCX_ENOMEM, "split transform output"));
+    outd = (float*)dout;
+  }
+  const long ci = (g.nin + si - 1) / si, co = (g.nout + so - 1) / so;
+  for (long k0 = 0; k0 < g.nout; k0 += co)
+    for (long m0 = 0; m0 < g.nin; m0 += ci) {
+      BsGeom p = g;
+      p.nin = std::min(ci, g.nin - m0); p.nout = std::min(co, g.nout - k0);
+      p.m0 = m0; p.k0 = k0; p.out_pitch = g.out_pitch ? g.out_pitch : g.nout; p.accumulate = m0 > 0;
+      if ((rc = bluestein_core(ctx, ind, outd, batch, p, scale, real_only, 1, 1))) return done(rc);
+    }
+  if (!out_dev) {
+    if (hipMemcpyAsync(out, outd, out_row * batch, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) return done(set_err(XCX_EHIP, "D2H"));
+  }
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) return done(set_err(XCX_EHIP, "split transform sync"));
+  return done(XCX_OK);
+}
+
+__global__ void k_modulus(const float2* __restrict__ z, float* __restrict__ out, long total) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const double a = z[i].x, b = z[i].y;
+    out[i] = (float)sqrt(a * a + b * b);
+  }
 }
 
 }  // namespace
@@ -273,6 +341,27 @@ extern "C" int xcx_hilbert(xcx_ctx* ctx, const float* x, float* out, long batch,
     BsGeom f{n, nh, n, 0, -1, 0, 0, n};
     if ((rc = bluestein(ctx, x + r0 * n, (float*)spec.ptr, cnt, f, 1.0, 0, on_device, 1))) return rc;
     BsGeom b{nh, n, n, 0, +1, 1, 1, nh};
+    if (envelope && nh + n - 1 > kBsMaxNp) {
+      // split transform: the partial sums are complex, the modulus comes last
+      void *dz = nullptr, *dm = nullptr;
+      auto done = [&](int r) { (void)hipFree(dz); (void)hipFree(dm); return r; };
+      if (hipMalloc(&dz, sizeof(float2) * n * cnt) != hipSuccess) return done(set_err(XCX_ENOMEM, "analytic signal buffer"));
+      if ((rc = bluestein(ctx, (const float*)spec.ptr, (float*)dz, cnt, b, 1.0 / (double)n, 0, 1, 1))) return done(rc);
+      float* dst = (float*)((char*)out + orow * r0);
+      if (!on_device) {
+        if (hipMalloc(&dm, sizeof(float) * n * cnt) != hipSuccess) return done(set_err(XCX_ENOMEM, "envelope buffer"));
+        dst = (float*)dm;
+      }
+      const long tot = n * cnt;
+      hipLaunchKernelGGL(k_modulus, dim3((unsigned)std::min<long>((tot + 255) / 256, 256L * 16)), dim3(256), 0, ctx->stream,
+                         (const float2*)dz, dst, tot);
+      if (hipGetLastError() != hipSuccess) return done(set_err(XCX_EHIP, "k_modulus launch"));
+      if (!on_device && hipMemcpyAsync((char*)out + orow * r0, dm, sizeof(float) * tot, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        return done(set_err(XCX_EHIP, "D2H"));
+      if (hipStreamSynchronize(ctx->stream) != hipSuccess) return done(set_err(XCX_EHIP, "envelope sync"));
+      (void)done(0);
+      continue;
+    }
     if ((rc = bluestein(ctx, (const float*)spec.ptr, (float*)((char*)out + orow * r0), cnt, b, 1.0 / (double)n,
                         envelope ? 2 : 0, 1, on_device)))
       return rc;

@@ -94,7 +94,7 @@ def resample(x, sampling_rate, new_sampling_rate, window='hann', no_filter=True,
     of ``fftfreq(npts)`` / an array of npts samples / None), linear interpolation of the spectrum
     onto the new frequency grid, irfft to ``num = int(npts / factor)`` samples, scaled by
     num / npts.  ``no_filter=False`` first applies the Chebyshev-II anti-alias low-pass of
-    ``decimate`` (factor <= 16).  Returns (y, new_sampling_rate).  npts <= 245 760."""
+    ``decimate`` (factor <= 16).  Returns (y, new_sampling_rate)."""
     npts = x.shape[-1]
     factor = sampling_rate / float(new_sampling_rate)
     if strict_length and npts % factor != 0.0:
