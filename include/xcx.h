@@ -334,7 +334,7 @@ int xcx_spectrogram(xcx_ctx* ctx, const float* x, float* S, long batch, long n,
  * spectrogram_mtc, xcorr/signal/spectrogram.py:266-276.  x [batch][n] ->
  * S [batch][nfft/2+1][nseg], nseg = (n - win_len)/hop + 1, segment s starts at
  * sample s*hop.  window / scale / detrend as for xcx_spectrogram.  Segments are
- * framed on the device and transformed by the any-length DFT (nfft <= 184320). */
+ * framed on the device and transformed by the any-length DFT (nfft <= 2^22). */
 int xcx_spectrogram_seg(xcx_ctx* ctx, const float* x, float* S, long batch, long n,
                         int win_len, long hop, int nfft, const double* window,
                         double scale, int detrend, int on_device);

@@ -86,3 +86,18 @@ def test_segmented_plan_matches_single_transform(ctx, monkeypatch):
         X.CCPlan(ctx, n, stack=True).stack_add if False else X.CCPlan(ctx, 4320000, stack=True)
     with pytest.raises(XcxError):
         X.CCPlan(ctx, 4320000, whiten=(50., 1., 10., .5))
+
+
+def test_timeshift_of_long_rows(ctx):
+    """Post-processing of the production lag axis (clip_lag = (0, 9 h) -> 1.62 M lags): the
+    period-n Dirichlet convolution runs through the block-decomposed correlation."""
+    from xcorr_amd import ops
+    rng = np.random.default_rng(21)
+    fs = 50.
+    for size in (500001, 1620000):
+        x = (rng.standard_normal((2, size)) * np.hanning(size)).astype(np.float32)
+        delay = np.array([0.0071, -0.0183])
+        got = ops.timeshift(ctx, x, delay, fs)
+        ref = R.timeshift(x, delay, fs)
+        assert got.shape == ref.shape == (2, size - (size & 1))
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()

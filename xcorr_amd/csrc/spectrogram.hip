@@ -305,7 +305,7 @@ extern "C" int xcx_spectrogram_seg(xcx_ctx* ctx, const float* x, float* S, long 
   if (win_len < 2) return set_err(XCX_EINVAL, "win_len must be >= 2");
   if (hop < 1 || hop > win_len) return set_err(XCX_EINVAL, "hop %ld outside [1, win_len]", hop);
   if (nfft < win_len) return set_err(XCX_EINVAL, "nfft %d < win_len %d", nfft, win_len);
-  if (nfft > 184320) return set_err(XCX_EUNSUPPORTED, "nfft %d beyond the DFT engine (184320)", nfft);
+  if (nfft > (1 << 22)) return set_err(XCX_EUNSUPPORTED, "nfft %d beyond 2^22", nfft);
   if (n < win_len) return set_err(XCX_EINVAL, "row shorter than one segment (%ld < %d)", n, win_len);
   HIP_TRY(hipSetDevice(ctx->device));
   const long nseg = (n - win_len) / hop + 1;

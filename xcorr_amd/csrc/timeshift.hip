@@ -34,6 +34,8 @@ int xcx_internal_forward(xcx_plan* p, const float* traces, long stride_s, long s
                          int W, int w0, int sw_begin, int sw_end, int slot0);
 int xcx_internal_pairs(xcx_plan* p, const PwDesc* hdesc, int count, float* out);
 int xcx_internal_spectra(xcx_plan* p, size_t slots);
+bool xcx_internal_segmented(xcx_plan* p);
+int xcx_internal_seg_rows(xcx_plan* p, const float* const* xs, const float* const* ys, int count, float* out, long ld);
 
 namespace {
 
@@ -103,7 +105,7 @@ static int timeshift_rows(xcx_ctx* ctx, const float* x, float* y, long batch, lo
   xcx_plan* plan = ctx->ts_plan;
   const long L = 2 * n - 1;
   const long ld = (L + 31) / 32 * 32;
-  const int kRows = 128;
+  const int kRows = n > 400000 ? 16 : 128;            // bounded workspace for long rows
   DevBuf &hr = ctx->scratch[1], &lin = ctx->scratch[2], &dal = ctx->scratch[3], &dx = ctx->scratch[4],
          &dy = ctx->scratch[5];
   const int chunk = (int)std::min<long>(kRows, batch);
@@ -121,18 +123,25 @@ static int timeshift_rows(xcx_ctx* ctx, const float* x, float* y, long batch, lo
     xd = (const float*)dx.ptr;
     yd = (float*)dy.ptr;
   }
-  if ((rc = xcx_internal_spectra(plan, 2 * (size_t)chunk))) return rc;
+  const bool seg = xcx_internal_segmented(plan);     // rows longer than one transform: block decomposition
+  if (!seg && (rc = xcx_internal_spectra(plan, 2 * (size_t)chunk))) return rc;
   std::vector<PwDesc> d(chunk);
+  std::vector<const float*> xs(chunk), ys(chunk);
   for (long r0 = 0; r0 < batch; r0 += chunk) {
     const int cnt = (int)std::min<long>(chunk, batch - r0);
     const dim3 grid((unsigned)((n + 255) / 256), (unsigned)cnt);
     hipLaunchKernelGGL(k_dirichlet, grid, dim3(256), 0, ctx->stream, (float*)hr.ptr, n, (long)cnt,
                        (const double*)dal.ptr + r0);
     HIP_TRY(hipGetLastError());
-    if ((rc = xcx_internal_forward(plan, xd + r0 * size, size, 0, 1, 0, 0, cnt, 0))) return rc;
-    if ((rc = xcx_internal_forward(plan, (const float*)hr.ptr, n, 0, 1, 0, 0, cnt, cnt))) return rc;
-    for (int i = 0; i < cnt; ++i) d[i] = PwDesc{i, cnt + i, (long long)i * ld};
-    if ((rc = xcx_internal_pairs(plan, d.data(), cnt, (float*)lin.ptr))) return rc;
+    if (seg) {
+      for (int i = 0; i < cnt; ++i) { xs[i] = xd + (r0 + i) * size; ys[i] = (const float*)hr.ptr + (long)i * n; }
+      if ((rc = xcx_internal_seg_rows(plan, xs.data(), ys.data(), cnt, (float*)lin.ptr, ld))) return rc;
+    } else {
+      if ((rc = xcx_internal_forward(plan, xd + r0 * size, size, 0, 1, 0, 0, cnt, 0))) return rc;
+      if ((rc = xcx_internal_forward(plan, (const float*)hr.ptr, n, 0, 1, 0, 0, cnt, cnt))) return rc;
+      for (int i = 0; i < cnt; ++i) d[i] = PwDesc{i, cnt + i, (long long)i * ld};
+      if ((rc = xcx_internal_pairs(plan, d.data(), cnt, (float*)lin.ptr))) return rc;
+    }
     hipLaunchKernelGGL(k_fold, grid, dim3(256), 0, ctx->stream, (const float*)lin.ptr, ld, yd + r0 * n, n,
                        (long)cnt, modulate);
     HIP_TRY(hipGetLastError());

@@ -1587,6 +1587,11 @@ int xcx_internal_spectra(xcx_plan* p, size_t slots) {
   return p->spectra.ensure(p->ctx, sizeof(cf) * p->spec_pitch * slots);
 }
 xcx_ctx* xcx_internal_ctx(xcx_plan* p) { return p->ctx; }
+// long windows (block decomposition): device row pointers x[i], y[i] -> out + i*ld
+bool xcx_internal_segmented(xcx_plan* p) { return p->seg != nullptr; }
+int xcx_internal_seg_rows(xcx_plan* p, const float* const* xs, const float* const* ys, int count, float* out, long ld) {
+  return seg_run(p, xs, ys, count, out, ld);
+}
 
 #ifdef XCX_STAMPS
 // diagnostic build only (not part of include/xcx.h): copy the recorded phase stamps to the host
