@@ -101,3 +101,22 @@ def test_timeshift_of_long_rows(ctx):
         ref = R.timeshift(x, delay, fs)
         assert got.shape == ref.shape == (2, size - (size & 1))
         assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+
+
+def test_production_postprocess_chain(ctx):
+    """core/postprocess.py:133-141 on the production container layout: day-long windows
+    (npts = 4 320 000), clip_lag = (0, 9 h) -> rows of 1 620 000 lags, device-resident."""
+    from xcorr_amd.core.postprocess import postprocess_rows
+    n, fs = 4320000, 50.
+    i0, i1 = n - 1, n - 1 + 1620000
+    rng = np.random.default_rng(22)
+    rows = (1e-3 * rng.standard_normal((2, i1 - i0))).astype(np.float32)
+    rows[:, 5000:5400] += (1e-2 * np.hanning(400)).astype(np.float32)
+    delay = np.array([0.0123, -0.0042])
+    d = ctx.array(rows.copy())
+    y = postprocess_rows(d, delay, fs, n, i0, i1, ctx=ctx)
+    got = y.to_host()
+    y.free(); d.free()
+    ref = R.postprocess_chain(rows.astype(np.float64), n, fs, i0, i1, delay)
+    assert got.shape == ref.shape == (2, 1620000)
+    assert _rel(got, ref) < 2 * TOL                 # six chained float32 stages
