@@ -71,7 +71,7 @@ def test_shapes_device_and_errors(ctx):
     with pytest.raises(ValueError):
         signal.spectrogram(x, duration=0.1, sampling_rate=FS)              # < 16 samples
     with pytest.raises(XcxError):
-        signal.spectrogram(x, duration=6.0, sampling_rate=FS)              # 300 > 256 samples
+        ops.spectrogram(ctx, x, 300, 600, np.ones(300), 1.0)               # 300 > 256 samples: the MFMA kernel's tile
     with pytest.raises(XcxError):
         ops.spectrogram(ctx, x[..., :20], 32, 64, w, 1.0)                  # row shorter than a segment
 
@@ -109,3 +109,12 @@ def test_spectrogram_mtc_argument_rules(ctx):
     # leading dimensions are kept
     f, t, S = signal.spectrogram_mtc(x.reshape(1, 1, -1), duration=2.5, sampling_rate=FS)
     assert S.shape == (1, 1, f.size, t.size)
+
+
+def test_long_segments_fall_back_to_framed_transforms(ctx):
+    """duration 8 s -> 400-sample segments (beyond the 256-sample MFMA tile)."""
+    x = ccf_like(2, 3001, seed=9)
+    freq, S = signal.spectrogram(x, duration=8., padding_factor=2, sampling_rate=FS)
+    rfreq, ref = R.spectrogram(x, FS, 8., 2)
+    assert np.allclose(freq, rfreq)
+    check(S, ref)

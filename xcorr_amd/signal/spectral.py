@@ -60,7 +60,15 @@ def spectrogram(x, duration=None, padding_factor=2, scaling=None, dim=None, samp
         raise ValueError('sampling_rate is required for array input')
     win_len, nfft, win, scale, *_ = _design(sampling_rate, duration, padding_factor, scaling, window)
     x = np.asarray(x)
-    S = _ops.spectrogram(None, x, win_len, nfft, win, scale, detrend == 'constant')
+    if win_len <= 256 and nfft <= 8192:
+        S = _ops.spectrogram(None, x, win_len, nfft, win, scale, detrend == 'constant')
+    else:
+        # segments longer than the MFMA kernel's tile: framed transforms, one per sample, then the
+        # reference's zero columns at the edges (spectrogram.py:138-141)
+        core = _ops.spectrogram_seg(None, x, win_len, 1, nfft, win, scale, detrend == 'constant')
+        edge = int(np.rint(win_len / 2))
+        npad = [(0, 0)] * (core.ndim - 1) + [(edge, x.shape[-1] - core.shape[-1] - edge)]
+        S = np.pad(np.asarray(core), npad, mode='constant', constant_values=0)
     freq = np.linspace(0., sampling_rate / 2, int(nfft / 2 + 1))
     return freq, S.astype(x.dtype if x.dtype.kind == 'f' else np.float32)
 
