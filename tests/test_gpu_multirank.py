@@ -75,3 +75,50 @@ def test_two_rank_rccl_stack_reduce(tmp_path):
     assert np.array_equal(tot[0], tot[1])
     shares = np.concatenate([np.load(tmp_path / f'share_{r}.npy') for r in range(world)])
     assert np.array_equal(shares.reshape(tot[0].shape), tot[0])
+
+
+_RANK_WINDOWS = r'''
+import os, sys, numpy as np
+sys.path.insert(0, {root!r})
+import ctypes as C
+import xcorr_amd as X
+from xcorr_amd import _ffi
+from xcorr_amd.rendezvous import FileRendezvous
+from xcorr_amd.synth import synthetic_traces
+rank, world, key, rdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+rd = FileRendezvous(rank, world, key, root=rdir, timeout=120)
+nd = C.c_int(0)
+_ffi.check(_ffi.lib().xcx_device_count(C.byref(nd)))
+ctx = X.Context(rank % max(nd.value, 1))          # ranks share the device when there are fewer GPUs
+S, n, hop, W = 6, 3000, 1500, 7
+tr = synthetic_traces(S, hop * (W - 1) + n)
+pairs = np.array([(i, j) for i in range(S) for j in range(i + 1, S)], np.int32)
+w0, w1 = (W * rank) // world, (W * (rank + 1)) // world        # bench.py --shard windows
+plan = X.CCPlan(ctx, n, demean=True)
+blk = plan.pairs(np.ascontiguousarray(tr[:, w0 * hop:(w1 - 1) * hop + n]), pairs, w1 - w0, hop)
+np.save(os.path.join(rdir, f'block_{{rank}}.npy'), np.asarray(blk))
+rd.barrier()
+'''
+
+
+def test_window_blocks_over_rank_processes(tmp_path):
+    """bench.py's N > 1 default (strong scaling, no collective): every rank PROCESS correlates its
+    block of windows with the engine; the blocks concatenated equal the oracle on the whole
+    record.  Runs on one GPU too (the ranks then share the device)."""
+    import subprocess
+    world = 3
+    script = tmp_path / 'rank_w.py'
+    script.write_text(_RANK_WINDOWS.format(root=ROOT))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), 'win', str(tmp_path)], env=env)
+             for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    from oracle import ref_numpy as R
+    from xcorr_amd.synth import synthetic_traces
+    S, n, hop, W = 6, 3000, 1500, 7
+    tr = synthetic_traces(S, hop * (W - 1) + n)
+    ref = R.cc_pairs(tr, R.all_pairs(S), n, hop, demean_=True, dtype=np.float64)
+    got = np.concatenate([np.load(tmp_path / f'block_{r}.npy') for r in range(world)], axis=1)
+    assert got.shape == ref.shape == (15, W, 2 * n - 1)
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-5
