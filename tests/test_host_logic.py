@@ -364,3 +364,40 @@ def test_init_hash_variable():
               hash_waveforms=True)
     assert ds.hash.shape == ds.status.shape and (ds.hash == 'n/a').all()
     assert init('A-B', 0., 7200., sampling_rate=50., window_length=3600., window_overlap=.5).hash is None
+
+
+def test_io_merge_and_mfread(tmp_path):
+    """core/merge.py:53-79, io/read.py:95-200: union of pairs and times, processed steps win."""
+    from xcorr_amd import io
+    rng = np.random.default_rng(4)
+    att = {'institution': 'i', 'author': 'a', 'source': 's', 'title': 'T'}
+    kw = dict(attrs=att, sampling_rate=10., window_length=600., window_overlap=.5, clip_lag=(-5., 5.))
+    days = []
+    for day, pair in (('2020-02-03', 'A.B..Z-C.D..Z'), ('2020-02-04', 'A.B..Z-C.D..Z'), ('2020-02-03', 'A.B..Z-E.F..Z')):
+        ds = core.init(pair, day, str(np.datetime64(day) + 1), **kw)
+        ds.cc[...] = rng.standard_normal(ds.cc.shape).astype(np.float32)
+        ds.status[...] = 1
+        ds.status[0, 5] = 0
+        ds.cc[0, 5] = 0
+        path = io.ncfile(pair, ds.time[0], str(tmp_path))
+        assert io.write(ds, path)
+        days.append((ds, path))
+    m = io.merge(days[0][0], days[1][0], days[2][0])
+    n0 = len(days[0][0].time)
+    assert list(m.pair) == ['A.B..Z-C.D..Z', 'A.B..Z-E.F..Z'] and len(m.time) == 2 * n0
+    assert np.array_equal(m.cc[0, :n0], days[0][0].cc[0]) and np.array_equal(m.cc[0, n0:], days[1][0].cc[0])
+    assert np.array_equal(m.cc[1, :n0], days[2][0].cc[0]) and (m.status[1, n0:] == 0).all() and (m.cc[1, n0:] == 0).all()
+    assert m.attrs['title'].startswith('T Cross-correlations - 2020.034 to 2020.035') and m.attrs['history'].startswith('Merged @')
+    # a processed step is not overwritten by a pending copy of the same step, in either order
+    redo = core.init('A.B..Z-C.D..Z', '2020-02-03', '2020-02-04', **kw)          # all pending
+    assert np.array_equal(io.merge(days[0][0], redo).cc, days[0][0].cc)
+    assert np.array_equal(io.merge(redo, days[0][0]).status, days[0][0].status)
+    # files: glob, list, extract
+    g = io.mfread(os.path.join(str(tmp_path), '2020', '*', '*.nc'), extract=True)
+    assert g.cc.shape == m.cc.shape and np.isnan(g.cc[0, 5]).all() and np.isnan(g.cc[1, n0:]).all()
+    assert np.array_equal(np.nan_to_num(g.cc), m.cc)
+    assert io.merge(os.path.join(str(tmp_path), 'nothing', '*.nc')) is None
+    assert np.isnan(io.read(days[0][1], extract=True).cc[0, 5]).all()
+    other = core.init('A-B', 0., 7200., sampling_rate=10., window_length=600., window_overlap=.5)
+    with pytest.raises(ValueError):
+        io.merge(days[0][0], other)

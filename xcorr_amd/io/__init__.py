@@ -11,6 +11,6 @@ index_max``), readable by ``xarray.open_dataset`` (scipy engine), uncompressed. 
 sha256 *metadata* hash walks an xarray object and is not reproduced; ``sha256_hash`` here covers
 the bytes of ``cc`` + ``status`` and is verified by :func:`read`.
 """
-from .nc import ncfile, write, read, validate      # noqa: F401
+from .nc import ncfile, write, read, validate, merge, mfread      # noqa: F401
 
-__all__ = ['ncfile', 'write', 'read', 'validate']
+__all__ = ['ncfile', 'write', 'read', 'validate', 'merge', 'mfread']

@@ -8,7 +8,7 @@ import numpy as np
 
 from ..core.init import CCDataset
 
-__all__ = ['ncfile', 'write', 'read', 'validate']
+__all__ = ['ncfile', 'write', 'read', 'validate', 'merge', 'mfread']
 
 _EPOCH = 'seconds since 1970-01-01 00:00:00'
 
@@ -140,10 +140,11 @@ def write(data, path, close=True, force_write=False, hash_data=True, verb=0):
     return True
 
 
-def read(path, fast=False, quick_and_dirty=False):
+def read(path, fast=False, quick_and_dirty=False, extract=False):
     """Open a file written by :func:`write` -> :class:`CCDataset`, or None when it does not exist
     (io/read.py returns ``None`` for a missing file; core/lazy.py:53-56 relies on it).
-    The data hash is verified unless ``quick_and_dirty``."""
+    The data hash is verified unless ``quick_and_dirty``.  ``extract`` masks the estimates of
+    steps with ``status != 1`` with NaN (io/read.py:88-90)."""
     from scipy.io import netcdf_file
     if not os.path.isfile(path):
         return None
@@ -192,7 +193,81 @@ def read(path, fast=False, quick_and_dirty=False):
         ds.attrs = ga
     if stored is not None and not quick_and_dirty and stored != _data_hash(ds):
         raise ValueError(f'{path}: data sha256 hash does not match the stored one')
+    if extract:
+        ds.cc[ds.status != 1] = np.nan
     return ds
+
+
+def merge(*datasets, extract=False, quick_and_dirty=False):
+    """Combine containers (or paths / glob strings of files written by :func:`write`) by their
+    coordinates -- ``xarray.combine_by_coords(join='outer')`` of core/merge.py:53-79 for this
+    layout: the union of the pairs and of the window times (sorted), one common lag axis; steps no
+    input holds keep ``status`` 0 and zero estimates (NaN with ``extract``); a step present in
+    several inputs is taken from the one where it is processed.  Global attributes of the first
+    input, ``title`` extended by the covered day range, ``history`` = 'Merged @ <now>'."""
+    import glob as _glob
+    dsets = []
+    for d in datasets:
+        if isinstance(d, CCDataset):
+            dsets.append(d)
+        elif isinstance(d, (str, os.PathLike)):
+            paths = sorted(_glob.glob(str(d))) if any(c in str(d) for c in '*?[') else [str(d)]
+            for pth in paths:
+                r = read(pth, quick_and_dirty=quick_and_dirty)
+                if r is not None:
+                    dsets.append(r)
+        elif isinstance(d, (list, tuple)):
+            sub = merge(*d, quick_and_dirty=quick_and_dirty) if d else None
+            if sub is not None:
+                dsets.append(sub)
+        else:
+            raise TypeError('datasets should be CCDataset objects or paths')
+    if not dsets:
+        return None
+    first = dsets[0]
+    for d in dsets[1:]:
+        if d.lag.shape != first.lag.shape or not np.allclose(d.lag, first.lag, rtol=0, atol=1e-9):
+            raise ValueError('datasets have different lag axes')
+        for k in ('sampling_rate', 'npts', 'index_min', 'index_max'):
+            if d.lag_attrs[k] != first.lag_attrs[k]:
+                raise ValueError(f'datasets differ in lag attribute "{k}"')
+    pairs = sorted({str(p) for d in dsets for p in d.pair})
+    times = np.unique(np.concatenate([np.asarray(d.time, np.float64) for d in dsets]))
+    out = CCDataset(pairs, times, first.lag, first.lag_attrs, first.cc_attrs, first.time_attrs, dtype=first.cc.dtype,
+                    hash_waveforms=any(getattr(d, 'hash', None) is not None for d in dsets))
+    out.time_is_datetime = getattr(first, 'time_is_datetime', False)
+    out.pair_attrs = dict(getattr(first, 'pair_attrs', {}))
+    pidx = {p: i for i, p in enumerate(pairs)}
+    for d in dsets:
+        ti = np.searchsorted(times, np.asarray(d.time, np.float64))
+        for ip, p in enumerate(d.pair):
+            row = pidx[str(p)]
+            take = (d.status[ip] == 1) | (out.status[row, ti] != 1)       # a processed step is never overwritten by a pending one
+            cols = ti[take]
+            out.cc[row, cols] = d.cc[ip, take]
+            out.status[row, cols] = d.status[ip, take]
+            out.pair_offset[row, cols] = d.pair_offset[ip, take]
+            out.time_offset[row, cols] = d.time_offset[ip, take]
+            if out.hash is not None and getattr(d, 'hash', None) is not None:
+                out.hash[row, cols] = d.hash[ip, take]
+    out.attrs = {k: v for k, v in first.attrs.items() if k != 'sha256_hash'}
+    t0, t1 = _utc(times[0]), _utc(times[-1])
+    s0, s1 = t0.strftime('%Y.%j'), t1.strftime('%Y.%j')
+    title = str(out.attrs.get('title', '')).split(' - ')[0]
+    out.attrs['title'] = (title + ' - ' + s0 + (' to {}'.format(s1) if s0 != s1 else '')).strip()
+    out.attrs['history'] = 'Merged @ {}'.format(_dt.datetime.now(_dt.timezone.utc).strftime('%Y-%m-%d %H:%M:%S'))
+    if extract:
+        out.cc[out.status != 1] = np.nan
+    return out
+
+
+def mfread(paths, extract=False, quick_and_dirty=True):
+    """Read several files (glob string or list) as ONE container (io/read.py:95-200: the
+    reference opens them lazily with ``xarray.open_mfdataset(combine='by_coords', join='outer')``
+    after ``validate(quick_and_dirty=True)``; here they are read and merged eagerly)."""
+    if isinstance(paths, (str, os.PathLike)):
+        paths = [paths]
+    return merge(*paths, extract=extract, quick_and_dirty=quick_and_dirty)
 
 
 def validate(ds, raise_error=True):
