@@ -401,3 +401,14 @@ def test_io_merge_and_mfread(tmp_path):
     other = core.init('A-B', 0., 7200., sampling_rate=10., window_length=600., window_overlap=.5)
     with pytest.raises(ValueError):
         io.merge(days[0][0], other)
+
+
+def test_top_level_names_of_the_reference():
+    """xcorr/__init__.py:34-46: init / process / postprocess / read / write / merge / mfread, signal, stream, util, io."""
+    import xcorr_amd as X
+    for name in ('init', 'process', 'postprocess', 'read', 'write', 'merge', 'mfread'):
+        assert callable(getattr(X, name)), name
+    assert X.init is core.init and X.read is X.io.read
+    assert X.signal.__name__ == 'xcorr_amd.signal' and X.stream.__name__ == 'xcorr_amd.stream'
+    with pytest.raises(AttributeError):
+        X.plot
