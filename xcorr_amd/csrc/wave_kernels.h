@@ -73,6 +73,21 @@ XCX_DEV unsigned long long stamp_nowait(float pin) {
 #define XCX_ROW_WAVES 1
 #endif
 constexpr int kWRB = 16;     // rows per wave
+// wave priority experiment (XCX_PRIO_MODE 1: high while the first loads are issued, low after they
+// arrived; 2: the reverse); 0 = no s_setprio at all
+#ifndef XCX_PRIO_MODE
+#define XCX_PRIO_MODE 0
+#endif
+#if XCX_PRIO_MODE == 1
+#define XCX_PRIO_START() __builtin_amdgcn_s_setprio(3)
+#define XCX_PRIO_DATA() __builtin_amdgcn_s_setprio(0)
+#elif XCX_PRIO_MODE == 2
+#define XCX_PRIO_START() __builtin_amdgcn_s_setprio(0)
+#define XCX_PRIO_DATA() __builtin_amdgcn_s_setprio(3)
+#else
+#define XCX_PRIO_START() ((void)0)
+#define XCX_PRIO_DATA() ((void)0)
+#endif
 constexpr int kTR = 64;      // rows per T tile: T = [res >> 6][(res >> 4) & 3][k2 in 0..N2h][res & 15]: the four
                              // row waves of a workgroup own the four 16-row quarters of one tile, and a quarter
                              // ([k2][16 rows], 15.5 KB) is contiguous so that its wave streams it with 16-byte loads
@@ -164,6 +179,7 @@ XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in
     }
   }
 #endif
+  XCX_PRIO_DATA();
   cf v1[G1::IT][R1];
   if constexpr (RX::S == 2) {
     stage_exchange_pad8<L, R0, 1, R1, kWNT>(ldsf, v0, v1, ltid);
@@ -400,6 +416,7 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
   const unsigned kk = (unsigned)k2;
   const int shift = g.shift;
   using CG = ColGeom<RX>;
+  XCX_PRIO_START();
   // four-step factors w_N^{-(j0 + t*NSL) k2}: base per (lane, iteration) and
   // the wave-uniform step g = w_N^{-NSL k2}; powers by multiplication
   // last-stage slots rotated so that lane l holds the residues res = l (mod 64): every T store
@@ -621,6 +638,7 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
   const int N1 = g.N1, N = g.N, n = g.n;
   const int lane = tid_of<kWNT>();
   static_assert(RX::S == 2, "row configs have two stages");
+  XCX_PRIO_START();
   cf b1[StageGeom<N2h, RX::R1, RX::R0, kWRB, kWNT>::IT];
   stage_tw_base<N2h, RX::R1, RX::R0, kWRB, kWNT>(tw_sub, b1);
 
@@ -740,6 +758,7 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
     }
     XCX_STAMP(2, s0a[0][0].x);
   }
+  XCX_PRIO_DATA();
   float* __restrict__ ldsf = reinterpret_cast<float*>(lds);
   using G1 = StageGeom<N2h, RX::R1, RX::R0, kWRB, kWNT>;
   cf v1[G1::IT][RX::R1];
