@@ -20,14 +20,14 @@ __global__ __launch_bounds__(kWNT * kWPB) void k_gram(GramArgs a) {
   for (int i = 0; i < kGT; ++i)
 #pragma unroll
     for (int j = 0; j < kGT; ++j) acc[i][j] = make_float2(0.f, 0.f);
-  const int S = a.S, W = a.W;
+  const int S = a.S, W = a.W, ldw = a.ldw ? a.ldw : a.W;
   for (int w = 0; w < W; ++w) {
     cf ai[kGT], bj[kGT];
 #pragma unroll
     for (int i = 0; i < kGT; ++i) {
       const int si = min(t0.x + i, S - 1), sj = min(t0.y + i, S - 1);
-      ai[i] = a.X[((size_t)si * W + w) * a.spec_pitch + kk];
-      bj[i] = a.X[((size_t)sj * W + w) * a.spec_pitch + kk];
+      ai[i] = a.X[((size_t)si * ldw + w) * a.spec_pitch + kk];
+      bj[i] = a.X[((size_t)sj * ldw + w) * a.spec_pitch + kk];
     }
 #pragma unroll
     for (int i = 0; i < kGT; ++i)
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256, 3) void k_gram_mfma(GramArgs a) {
   f32x16 gr00 = {0}, gr01 = {0}, gr11 = {0}, gi00 = {0}, gi01 = {0}, gi11 = {0};
   const int ls_s = tid >> 2, ls_f = tid & 3;                 // loader role: station, frequency of the quad
   const bool ld_ok = ls_s < S && f0 + ls_f < a.nfreq;
-  const cf* __restrict__ src = a.X + (size_t)ls_s * W * a.spec_pitch + f0 + ls_f;
+  const cf* __restrict__ src = a.X + (size_t)ls_s * (a.ldw ? a.ldw : W) * a.spec_pitch + f0 + ls_f;
   const int part = lane >> 5, st = lane & 31;
   const float sgn = part ? -1.f : 1.f;
   // rows of C this thread will write (4 entries per 32x32 block), looked up before the main

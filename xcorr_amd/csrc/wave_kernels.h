@@ -345,6 +345,10 @@ struct WF2Args {
   const cf* tw_sub;          // W_{N1}
   float wb0, wb1, wb2, wb3, fixed_norm;
   Geom g;
+  // station-major slots with room for more windows per station (multi-day stacks): station-window
+  // q = sw_first + blockIdx.y goes to slot slot0 + (q / slot_w) * slot_ld + q % slot_w; slot_ld = 0:
+  // dense, slot0 + blockIdx.y
+  int sw_first, slot_w, slot_ld;
 };
 
 template <class RX>
@@ -361,7 +365,9 @@ void k_wfwd_cols(WF2Args a) {
   const float scale = sw_scale(a.psq, sw, N, g.flags, a.fixed_norm);
   const bool whiten = g.flags & XCX_F_WHITEN;
   const cf* __restrict__ src = a.Tf + ((size_t)sw * (N2h + 1) + k2) * N1;
-  cf* __restrict__ dst = a.X + (size_t)(a.slot0 + sw) * a.spec_pitch + (size_t)k2 * N1;
+  int slot = a.slot0 + sw;
+  if (a.slot_ld) { const int q = a.sw_first + sw; slot = a.slot0 + (q / a.slot_w) * a.slot_ld + q % a.slot_w; }
+  cf* __restrict__ dst = a.X + (size_t)slot * a.spec_pitch + (size_t)k2 * N1;
   const float wb0 = a.wb0, wb1 = a.wb1, wb2 = a.wb2, wb3 = a.wb3;
   auto in = [=](int m1, int) -> cf { return src[m1]; };
   using CG = ColGeom<RX>;
@@ -1366,6 +1372,7 @@ struct GramArgs {
   const int* pidx;                  // [S*S] -> row of C, or -1
   cf* C; size_t c_pitch;            // C[p*c_pitch + k]
   int accumulate;                   // 0: C = G;  1: C += G (multi-day stack, xcx_cc1d_stack_add)
+  int ldw;                          // slots per station (>= W; 0: W): X[(s*ldw + w)*spec_pitch + k]
 };
 
 hipError_t launch_gram(const GramArgs& a, hipStream_t s);

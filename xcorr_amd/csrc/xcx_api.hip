@@ -400,6 +400,10 @@ struct xcx_plan {
   unsigned long long gram_key = 0; int gram_ntiles = 0;
   // multi-call accumulation in gramC (xcx_cc1d_stack_add / _finish)
   unsigned long long acc_key = 0; int acc_count = 0, acc_S = 0, acc_P = 0; long long acc_windows = 0; long acc_ld = 0;
+  // multi-day stacks: the spectra of up to acc_cap adds wait in station-major slots [S][acc_cap * acc_W] and go
+  // through ONE Gram update (the read-modify-write of the P x N/2 accumulator is amortised over them)
+  int acc_pending = 0, acc_W = 0, acc_cap = 1, acc_grams = 0;
+  int fwd_slot_w = 0, fwd_slot_ld = 0;               // forward(): station-major slot mapping (0: dense)
   bool fused_ran = false;
   DevBuf psum, psq;          // partial statistics of a forward chunk
   int L = 0;                 // retained lags
@@ -755,7 +759,8 @@ static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_
       f2.psq = (const double*)p->psq.ptr;
       f2.X = (cf*)p->spectra.ptr;
       f2.spec_pitch = p->spec_pitch;
-      f2.slot0 = slot0 + b;
+      f2.slot0 = p->fwd_slot_ld ? slot0 : slot0 + b;
+      f2.sw_first = b; f2.slot_w = p->fwd_slot_w; f2.slot_ld = p->fwd_slot_ld;
       f2.tw_sub = (const cf*)p->tw_N1.ptr;
       f2.wb0 = p->wb[0]; f2.wb1 = p->wb[1]; f2.wb2 = p->wb[2]; f2.wb3 = p->wb[3];
       f2.fixed_norm = p->fixed_norm;
@@ -1148,7 +1153,7 @@ static int stack_tables(xcx_plan* p, const int* pairs, int S, int P, long ld_out
   return XCX_OK;
 }
 
-static int stack_gram(xcx_plan* p, int S, int W, int P, int accumulate) {
+static int stack_gram(xcx_plan* p, int S, int W, int P, int accumulate, int ldw = 0) {
   xcx_ctx* ctx = p->ctx;
   const Geom& g = p->g;
   int rc;
@@ -1164,11 +1169,22 @@ static int stack_gram(xcx_plan* p, int S, int W, int P, int accumulate) {
   ga.C = (cf*)p->gramC.ptr;
   ga.c_pitch = p->spec_pitch;
   ga.accumulate = accumulate;
+  ga.ldw = ldw;
   {
     ProfScope ps(p, KID_GRAM, P);
     HIP_TRY(launch_gram(ga, ctx->stream));
   }
   p->launches += 1;
+  return XCX_OK;
+}
+
+// Gram update over the pending adds: K = acc_pending * acc_W windows per station
+static int stack_flush(xcx_plan* p) {
+  if (p->acc_pending == 0) return XCX_OK;
+  const int rc = stack_gram(p, p->acc_S, p->acc_pending * p->acc_W, p->acc_P, p->acc_grams > 0 ? 1 : 0, p->acc_W * p->acc_cap);
+  if (rc) return rc;
+  p->acc_grams += 1;
+  p->acc_pending = 0;
   return XCX_OK;
 }
 
@@ -1221,11 +1237,24 @@ extern "C" int xcx_cc1d_stack_add(xcx_plan* p, const float* traces, int S, int W
   }
   // tables keyed without ld_out: the finish call supplies it (descriptors are rebuilt there if it differs)
   if ((rc = stack_tables(p, pairs, S, P, p->acc_ld))) return rc;
-  if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)S * W))) return rc;
-  if ((rc = forward(p, dtr, stride_s, stride_w, W, 0, 0, S * W, 0))) return rc;
-  if ((rc = stack_gram(p, S, W, P, p->acc_count > 0 ? 1 : 0))) return rc;
-  if (!on_device) HIP_TRY(hipStreamSynchronize(ctx->stream));     // the staging buffer may be reused
+  // adds of equal W are collected (station-major slots, cap so that the spectra stay below 24 GB) and go
+  // through one Gram update; a different W flushes what is pending first
+  if (p->acc_pending > 0 && W != p->acc_W) { if ((rc = stack_flush(p))) return rc; }
+  if (p->acc_pending == 0) {
+    static const int want = getenv("XCX_STACK_DAYS") ? std::max(1, atoi(getenv("XCX_STACK_DAYS"))) : 4;
+    const size_t per_add = sizeof(cf) * p->spec_pitch * (size_t)S * W;
+    p->acc_cap = (int)std::max<size_t>(1, std::min<size_t>((size_t)want, ((size_t)24 << 30) / std::max<size_t>(per_add, 1)));
+    p->acc_W = W;
+  }
+  if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)S * W * p->acc_cap))) return rc;
+  p->fwd_slot_w = W; p->fwd_slot_ld = W * p->acc_cap;
+  rc = forward(p, dtr, stride_s, stride_w, W, 0, 0, S * W, p->acc_pending * W);
+  p->fwd_slot_w = p->fwd_slot_ld = 0;
+  if (rc) return rc;
   p->acc_key = akey; p->acc_S = S; p->acc_P = P;
+  p->acc_pending += 1;
+  if (p->acc_pending == p->acc_cap && (rc = stack_flush(p))) return rc;
+  if (!on_device) HIP_TRY(hipStreamSynchronize(ctx->stream));     // the staging buffer may be reused
   p->acc_count += 1; p->acc_windows += W;
   return XCX_OK;
 }
@@ -1254,9 +1283,10 @@ extern "C" int xcx_cc1d_stack_finish(xcx_plan* p, const int* pairs, int P, float
     if ((rc = p->dout.ensure(ctx, (size_t)P * (size_t)ld_out * sizeof(float)))) return rc;
     dout = (float*)p->dout.ptr;
   }
+  if ((rc = stack_flush(p))) return rc;
   if ((rc = stack_inverse(p, P, dout))) return rc;
   if (windows) *windows = p->acc_windows;
-  p->acc_count = 0; p->acc_windows = 0;
+  p->acc_count = 0; p->acc_windows = 0; p->acc_grams = 0;
   if (!on_device) {
     HIP_TRY(hipMemcpy2DAsync(out, (size_t)ld_out * sizeof(float), dout, (size_t)ld_out * sizeof(float),
                              (size_t)L * sizeof(float), (size_t)P, hipMemcpyDeviceToHost, ctx->stream));
@@ -1270,6 +1300,8 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
                               long stride_s, long stride_w, const int* pairs,
                               int P, float* out, long ld_out, int on_device) {
   if (!p || !traces || !pairs || !out) return set_err(XCX_EINVAL, "null argument");
+  if (p->acc_count > 0)           // before anything touches the spectra that wait for their Gram update
+    return set_err(XCX_EINVAL, "xcx_cc1d_pairs: a xcx_cc1d_stack_add accumulation is in progress on this plan");
   if (S < 1 || W < 1 || P < 1) return set_err(XCX_EINVAL, "S, W, P must be >= 1");
   xcx_ctx* ctx = p->ctx;
   const Geom& g = p->g;
@@ -1372,8 +1404,6 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
     int ns = W;
     if (p->wave && p->gram && W > 1) {
       // cgemm-style stack: G_k = A_k A_k^H per frequency, then one inverse per pair
-      if (p->acc_count > 0)
-        return set_err(XCX_EINVAL, "xcx_cc1d_pairs: a xcx_cc1d_stack_add accumulation is in progress on this plan");
       if ((rc = stack_tables(p, pairs, S, P, ld_out))) return rc;
       if ((rc = stack_gram(p, S, W, P, 0))) return rc;
       src = (const cf*)p->gramC.ptr;
