@@ -19,7 +19,8 @@ def run(budget=60.0, seed=0, ctx=None):
     t_end = time.time() + budget
     worst, cases = {}, 0
     while time.time() < t_end:
-        kind = rng.choice(['sos', 'rowops', 'fft', 'hilbert', 'ram', 'cc2d', 'lanczos', 'timeshift'])
+        kind = rng.choice(['sos', 'rowops', 'fft', 'hilbert', 'ram', 'cc2d', 'lanczos', 'timeshift', 'timeshift_fft',
+                           'specseg', 'resample', 'bigfft', 'zerophase', 'postprep'])
         if kind == 'sos':
             n = int(rng.choice([rng.integers(40, 300), rng.integers(300, 20000), rng.integers(20000, 400000)]))
             b = int(rng.integers(1, 5)) if n > 20000 else int(rng.integers(1, 200))
@@ -69,6 +70,49 @@ def run(budget=60.0, seed=0, ctx=None):
             off = float(rng.uniform(0, 3)); nout = max(1, int((n - 1 - off) / step))
             x = rng.standard_normal((2, n)).astype(np.float32)
             e = rel(ops.lanczos(ctx, x, nout, off, step, a_), R.lanczos_interpolation(x, off, step, nout, a_)); tol = 1e-5
+        elif kind == 'timeshift_fft':
+            n = int(rng.integers(16, 60000)); x = (rng.standard_normal((3, n)) * np.hanning(n)).astype(np.float32)
+            d = rng.uniform(-1, 1, 3)
+            e = rel(ops.timeshift(ctx, x, d, 50., fast=False), R.timeshift_fft(x, d, 1 / 50.)); tol = 1e-5
+        elif kind == 'specseg':
+            import scipy.signal
+            n = int(rng.integers(64, 20000)); win = int(rng.integers(16, min(n, 700) + 1))
+            hop = int(rng.integers(1, win + 1)); nfft = int(win * rng.integers(1, 4) + rng.integers(0, 3))
+            x = (rng.standard_normal((2, n)) + 0.5).astype(np.float32)
+            w = scipy.signal.get_window(('tukey', .25), win)
+            det = bool(rng.random() < 0.7)
+            got = ops.spectrogram_seg(ctx, x, win, hop, nfft, w, 1.0 / (50. * (w * w).sum()), det)
+            _, _, ref = scipy.signal.spectrogram(x.astype(np.float64), fs=50., nperseg=win, noverlap=win - hop, nfft=nfft,
+                                                 detrend='constant' if det else False, scaling='density', mode='psd')
+            e = rel(got, ref); tol = 1e-5
+        elif kind == 'resample':
+            from xcorr_amd import stream
+            n = int(rng.integers(64, 120000)); new = float(rng.choice([10., 12.5, 20., 40., 62.5, 100.]))
+            x = rng.standard_normal((2, n)).astype(np.float32)
+            y, _ = stream.resample(x, 50., new, ctx=ctx)
+            e = rel(y, R.resample_fourier(x, 50., new)); tol = 1e-5
+        elif kind == 'bigfft':
+            n = int(rng.integers(184000, 520000)); x = rng.standard_normal((1, n)).astype(np.float32)
+            e = rel(ops.rfft(ctx, x), R.rfft_kernel(x))
+            if rng.random() < 0.3:
+                e = max(e, rel(ops.hilbert(ctx, x, envelope=True), np.abs(R.hilbert(x))))
+            tol = 1e-5
+        elif kind == 'zerophase':
+            from xcorr_amd import stream
+            n = int(rng.integers(200, 300000)); x = (rng.standard_normal((2, n)) + 1.0).astype(np.float32)
+            sos = stream.butter_sos('bandpass', 50., int(rng.integers(1, 5)), freqmin=float(rng.uniform(0.05, 2.)), freqmax=float(rng.uniform(4., 20.)))
+            e = rel(ops.sosfilt_zerophase(ctx, x, sos), R.sosfilt_zerophase(sos, x)); tol = 2e-5
+        elif kind == 'postprep':
+            npts = int(rng.integers(200, 100000)); full = 2 * npts - 1
+            i0 = int(rng.integers(0, full - 64)); i1 = int(rng.integers(i0 + 64, full + 1))
+            x = (1e-2 * rng.standard_normal((3, i1 - i0))).astype(np.float32)
+            nmax = int(rng.integers(1, (i1 - i0) // 2 + 1))
+            got = ops.post_prep(ctx, x.copy(), npts, i0, i1, unbiased=True, taper_nmax=nmax)
+            r = R.demean(R.unbias(x.astype(np.float64), npts, i0, i1))
+            wt = np.ones(i1 - i0); hw = np.hanning(2 * nmax + 1)[1:]           # periodic Hann of 2*nmax points
+            import scipy.signal.windows as sw
+            win = sw.hann(2 * nmax, False); wt[:nmax] = win[:nmax]; wt[-nmax:] = win[-nmax:]
+            e = rel(got, r * wt); tol = 1e-5
         else:
             n = int(rng.integers(16, 60000)); x = (rng.standard_normal((3, n)) * np.hanning(n)).astype(np.float32)
             d = rng.uniform(-1, 1, 3)
