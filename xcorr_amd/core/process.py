@@ -18,6 +18,15 @@ from ..engine import CCPlan, default_context
 
 __all__ = ['process', 'process_batched']
 
+try:                                    # 128-bit content key of a window: xxh3 when present (10x blake2b)
+    import xxhash as _xx
+
+    def _digest(b):
+        return _xx.xxh3_128_digest(b)
+except ModuleNotFoundError:             # pragma: no cover
+    def _digest(b):
+        return hashlib.blake2b(b, digest_size=16).digest()
+
 
 def process(dataset, client, inventory=None, retry_missing=False,
             test_run=False, hash_waveforms=False, metadata_hash=None, verb=0,
@@ -70,22 +79,26 @@ def process(dataset, client, inventory=None, retry_missing=False,
             break
     if todo:
         ctx = ctx or default_context()
-        plan = CCPlan(ctx, npts, index_min=imin, index_max=imax,
-                      normalize=dataset.cc_attrs['normalize'] == 1,
-                      unbiased=False)
+        plan = ctx.plan(npts, index_min=imin, index_max=imax,
+                        normalize=bool(dataset.cc_attrs['normalize'] == 1), unbiased=False)
         # every distinct station window is transformed ONCE (the reference transforms both
-        # inputs of every pair): windows are identified by content, the pair list indexes them
+        # inputs of every pair): windows are identified by content, the pair list indexes them.
+        # A single-pair container cannot share windows between pairs: no hashing there (hashing
+        # 2 x 47 hour-long windows costs more than correlating them)
         uniq, index = [], {}
+        share = len(dataset.pair) > 1
 
         def slot(x):
-            key = (x.shape[0], hashlib.blake2b(np.ascontiguousarray(x).view(np.uint8), digest_size=16).digest())
+            if not share:
+                uniq.append(x)
+                return len(uniq) - 1
+            key = (x.shape[0], _digest(np.ascontiguousarray(x).view(np.uint8)))
             if key not in index:
                 index[key] = len(uniq)
                 uniq.append(x)
             return index[key]
         pairs = np.array([(slot(a), slot(b)) for a, b in zip(xs, ys)], np.int32)
         out = plan.pairs(np.stack(uniq), pairs, 1, npts)[:, 0]      # :155-162, batched
-        plan.close()
         for k, (ip, it) in enumerate(todo):
             dataset.cc[ip, it] = out[k].astype(dataset.cc.dtype)
             dataset.status[ip, it] = 1                       # :165

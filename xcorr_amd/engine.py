@@ -104,9 +104,23 @@ class Context:
         self.device = int(device)
         self._children = weakref.WeakSet()      # plans and arrays that must go first
         self._pin_pool = {}                     # capacity -> [addresses] of idle page-locked blocks
+        self._plans = {}                        # (n, lag slice, flags) -> CCPlan kept for repeated driver calls
+
+    def plan(self, n, index_min=0, index_max=None, **flags):
+        """A :class:`CCPlan` owned by the context and reused by later calls with the same arguments
+        (the reference-style driver makes one call per pair and day: plan workspaces are allocated
+        once, not per call).  Do not close it; `Context.close` does."""
+        key = (int(n), int(index_min), int(index_max or 0), tuple(sorted(flags.items())))
+        p = self._plans.get(key)
+        if p is None or not p.handle:
+            if len(self._plans) >= 8:                       # a handful of geometries at most
+                self._plans.pop(next(iter(self._plans))).close()
+            p = self._plans[key] = CCPlan(self, n, index_min=index_min, index_max=index_max, **flags)
+        return p
 
     def close(self):
         if self.handle:
+            self._plans = {}
             for child in list(self._children):
                 child.close()
             for blocks in self._pin_pool.values():
