@@ -1,5 +1,6 @@
 """GPU: the host-side mirrors of the reference interface (util.cc.cc,
 signal.*, core.process) -- these read like the reference's own call sites."""
+import os
 import numpy as np
 import pytest
 
@@ -399,3 +400,20 @@ def test_lazy_single_process_writes_resumes_and_skips(ctx, tmp_path):
     assert Counting.calls == n_missing
     ds2 = io.read(io.ncfile(pair, t0, str(tmp_path)))
     assert (ds2.status == 1).sum() > n_ok and np.array_equal(ds2.cc[0, k], ds.cc[0, k])
+
+
+def test_example_script_runs(ctx, tmp_path):
+    """examples/process_day.py: init -> process -> write -> mfread -> postprocess -> snr; the stack
+    of every pair peaks at the synthetic moveout (25 samples = 0.5 s per station step)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('example_process_day', os.path.join(root, 'examples', 'process_day.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    pp = mod.main(str(tmp_path))
+    assert len(pp.pair) == 3 and (pp.status == 1).sum() >= 27
+    for ip, pair in enumerate(pp.pair):
+        i, j = (int(s.split('.')[1][3]) for s in str(pair).split('-'))
+        stack = pp.cc[ip][pp.status[ip] == 1].mean(axis=0)
+        peak = pp.lag[int(np.argmax(np.abs(stack)))]
+        assert abs(peak - 0.5 * (i - j)) <= 0.04, (pair, peak)

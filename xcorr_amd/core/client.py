@@ -9,13 +9,15 @@ __all__ = ['ArrayClient']
 
 
 class ArrayClient:
-    """traces: dict receiver -> float32[T]; `t0`: time (s) of sample 0."""
+    """traces: dict receiver -> float32[T]; `t0`: time of sample 0 (POSIX seconds, or
+    anything ``init`` accepts as a start time: ISO string, datetime64, Timestamp)."""
 
     def __init__(self, traces, sampling_rate, t0=0.0, separator='-'):
+        from .init import _seconds
         self.traces = {k: np.ascontiguousarray(v, dtype=np.float32)
                        for k, v in traces.items()}
         self.sampling_rate = float(sampling_rate)
-        self.t0 = float(t0)
+        self.t0 = _seconds(t0)[0]
         self.separator = separator
 
     def window(self, receiver, center, duration):
