@@ -479,7 +479,13 @@ XCX_DEV void stage_exchange(float* __restrict__ ldsf, Idx idx,
 // access patterns step by multiples of 8 (or stay inside one aligned group of 8), where
 // idx(p0 + d) = idx(p0) + d + d/8 holds exactly: one base per butterfly, every other address
 // is a compile-time immediate of the ds instruction.
-template <int L, int RA, int NSA, int RB, int NT>
+// SRC_PAIRS (first exchange only, NSA = 1): the source registers hold the butterflies
+// j = 2 tid, 2 tid + 1 (iterations 0, 1) and tid + it NT (later iterations) -- the assignment of
+// the 16-byte first-stage loads -- instead of tid + it NT.
+template <int NT>
+XCX_DEV int pair_src_index(int tid, int it) { return it < 2 ? 2 * tid + it : tid + it * NT; }
+
+template <int L, int RA, int NSA, int RB, int NT, bool SRC_PAIRS = false>
 XCX_DEV void stage_exchange_pad8(float* __restrict__ ldsf,
                                  const typename StageGeom<L, RA, NSA, 1, NT>::Regs& src,
                                  typename StageGeom<L, RB, NSA * RA, 1, NT>::Regs& dst,
@@ -502,7 +508,7 @@ XCX_DEV void stage_exchange_pad8(float* __restrict__ ldsf,
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
     for (int it = 0; it < GA::IT; ++it) {
-      const int j = tid + it * NT;
+      const int j = SRC_PAIRS ? pair_src_index<NT>(tid, it) : tid + it * NT;
       if (!GA::GUARD || j < GA::NBF) {
         const int k = (NSA > 1) ? (j % NSA) : 0;
         const int j0 = (j - k) * RA + k;

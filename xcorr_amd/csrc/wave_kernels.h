@@ -25,6 +25,7 @@
 // S-j of its first stage are computed by the same lane, which therefore holds
 // both H[k] and H[N2h-k] for the Hermitian untangle.
 #pragma once
+#include <type_traits>
 #include "cc_kernels.h"
 
 namespace xcx {
@@ -141,10 +142,19 @@ template <class RX> struct ColRot {
   using CG = ColGeom<RX>;
   static constexpr bool ok = (CG::Last::NBF % kWNT == 0) && (CG::NSL % kTR == 0);
 };
-template <class RX, bool INV, class In, class Epi>
-XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in, Epi epi, int ltid XCX_ST_PARAM) {
+// `in2(k, a, b)` (may be a null functor, In2 = int): two adjacent inputs k, k + 1 (k even) at once -- 16-byte loads.
+// Used for the first 2 x 64 butterflies of stage 0 when the column has at least that many
+// (lane l takes butterflies 2l and 2l+1); see pair_src_index.
+struct NoIn2 {};
+#ifndef XCX_COL_WIDE
+#define XCX_COL_WIDE 1       // 16-byte spectrum loads in the pair column pass (+0.9 %, profiles/r02_ablation.txt)
+#endif
+template <class RX, bool INV, class In, class Epi, class In2 = NoIn2>
+XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in, Epi epi, int ltid XCX_ST_PARAM, In2 in2 = In2()) {
   constexpr int L = RX::L;
   constexpr int R0 = RX::R0, R1 = RX::R1, R2 = RX::R2;
+  constexpr bool WIDE0 = !std::is_same<In2, NoIn2>::value && (StageGeom<L, R0, 1, 1, kWNT>::NBF % kWNT == 0) &&
+                         (StageGeom<L, R0, 1, 1, kWNT>::IT >= 2);
   static_assert(RX::S == 2 || RX::S == 3, "column configs have two or three stages");
   float* __restrict__ ldsf = reinterpret_cast<float*>(lds);
   using G0 = StageGeom<L, R0, 1, 1, kWNT>;
@@ -169,20 +179,33 @@ XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in
   }
   XCX_STAMP(2, v0[G0::IT - 1][R0 - 1].x);          // stage 0 computed
 #else
+  if constexpr (WIDE0) {
 #pragma unroll
-  for (int it = 0; it < G0::IT; ++it) {
-    const int j = tid_of<kWNT>() + it * kWNT;
-    if (!G0::GUARD || j < G0::NBF) {
+    for (int t = 0; t < R0; ++t) in2(2 * tid_of<kWNT>() + t * (L / R0), v0[0][t], v0[1][t]);
+#pragma unroll
+    for (int it = 2; it < G0::IT; ++it) {
+      const int j = tid_of<kWNT>() + it * kWNT;
 #pragma unroll
       for (int t = 0; t < R0; ++t) v0[it][t] = in(j + t * (L / R0), 0);
-      Bfly<R0, INV>::run(v0[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < G0::IT; ++it) Bfly<R0, INV>::run(v0[it]);
+  } else {
+#pragma unroll
+    for (int it = 0; it < G0::IT; ++it) {
+      const int j = tid_of<kWNT>() + it * kWNT;
+      if (!G0::GUARD || j < G0::NBF) {
+#pragma unroll
+        for (int t = 0; t < R0; ++t) v0[it][t] = in(j + t * (L / R0), 0);
+        Bfly<R0, INV>::run(v0[it]);
+      }
     }
   }
 #endif
   XCX_PRIO_DATA();
   cf v1[G1::IT][R1];
   if constexpr (RX::S == 2) {
-    stage_exchange_pad8<L, R0, 1, R1, kWNT>(ldsf, v0, v1, ltid);
+    stage_exchange_pad8<L, R0, 1, R1, kWNT, WIDE0>(ldsf, v0, v1, ltid);
     stage_compute<L, R1, R0, 1, kWNT, INV>(v1, b1);
 #pragma unroll
     for (int it = 0; it < G1::IT; ++it) {
@@ -196,7 +219,7 @@ XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in
     using G2 = StageGeom<L, R2, R0 * R1, 1, kWNT>;
     cf b2[G2::IT];
     stage_tw_base<L, R2, R0 * R1, 1, kWNT>(tw, b2, ltid);
-    stage_exchange_pad8<L, R0, 1, R1, kWNT>(ldsf, v0, v1);
+    stage_exchange_pad8<L, R0, 1, R1, kWNT, WIDE0>(ldsf, v0, v1);
     XCX_STAMP(3, v1[G1::IT - 1][R1 - 1].y);
     stage_compute<L, R1, R0, 1, kWNT, INV>(v1, b1);
     XCX_STAMP(4, v1[G1::IT - 1][R1 - 1].y);
@@ -559,6 +582,22 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
       });
     }
   };
+#if XCX_COL_WIDE && !defined(XCX_STAMPS) && !defined(XCX_ABLATE_MATH)
+  if constexpr (MODE != 1) {
+    auto in2 = [=](int k1, cf& ra, cf& rb) {
+      typedef float f32x4 __attribute__((ext_vector_type(4)));
+      const f32x4 qa = *reinterpret_cast<const f32x4*>(uoff(A, (unsigned)k1));
+      if constexpr (MODE == 2) {
+        ra = make_float2(qa.x, qa.y); rb = make_float2(qa.z, qa.w);
+      } else {
+        const f32x4 qb = *reinterpret_cast<const f32x4*>(uoff(Bp, (unsigned)k1));
+        ra = cmulc(make_float2(qa.x, qa.y), make_float2(qb.x, qb.y));
+        rb = cmulc(make_float2(qa.z, qa.w), make_float2(qb.z, qb.w));
+      }
+    };
+    wave_col_fft<RX, true>(lds, tw_sub, in, epi, ltid XCX_ST_ARG, in2);
+  } else
+#endif
   wave_col_fft<RX, true>(lds, tw_sub, in, epi, ltid XCX_ST_ARG);
   XCX_STAMP_NW(7, gstep.x);                          // T stores issued
   XCX_STAMP(8, gstep.x);                             // ... and acknowledged
