@@ -659,6 +659,9 @@ template <bool SC1> XCX_DEV cf load_t(const cf* p) {
 #ifndef XCX_BUFSTORE
 #define XCX_BUFSTORE 1
 #endif
+#ifndef XCX_ROW_PAIR
+#define XCX_ROW_PAIR 0        // 16-byte T loads by lane pairs + DPP swap in the row pass (experiment)
+#endif
 #ifndef XCX_ROW_WIDE
 #define XCX_ROW_WIDE 0        // 16-byte T loads + LDS transpose in the row pass (0: one 8-byte load per butterfly input)
 #endif
@@ -780,6 +783,42 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
         untangle(it, j, jp == j, av[it], bv[it], ny[it]);
       }
     });
+    XCX_STAMP(2, s0a[0][0].x);
+  } else if constexpr (!SC1 && XCX_ROW_PAIR && (TOTAL % kWNT) == 0) {
+    // Lane pairs (rows r, r+1 of one butterfly pair j): the even lane loads rows (r, r+1) of the
+    // inputs k2 = j + S t as 16 bytes, the odd lane the same rows of the mirror inputs k2 = S-j + S t;
+    // one DPP swap inside the pair hands every lane both input sets of ITS row.  Half the load
+    // instructions of the 8-byte form, no LDS.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const bool odd = lane & 1;
+    auto swp = [](float v) -> float {               // value of the partner lane (l ^ 1)
+      return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, false));
+    };
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int w = lane + it * kWNT;
+      const int r = w % kWRB;
+      const int j = w / kWRB;                       // 0..S/2
+      const int jp = (j == 0) ? 0 : (S - j);
+      const bool single = jp == j;
+      const unsigned base = (unsigned)((odd ? jp : j) * kWRB + (r & ~1));
+      cf av[R], bv[R];
+      f32x4 q[R];
+#pragma unroll
+      for (int t = 0; t < R; ++t) q[t] = *reinterpret_cast<const f32x4*>(uoff(Tt, base + (unsigned)(S * t * kWRB)));
+      float ny = 0.f;
+      if (j == 0) ny = load_t<SC1>(uoff(Tt, (unsigned)(N2h * kWRB + r))).x;
+#pragma unroll
+      for (int t = 0; t < R; ++t) {
+        // even lane: own = (A_r, A_r+1), needs B_r = partner's low half
+        // odd lane : own = (B_r-1, B_r), needs A_r = partner's high half
+        const float sx = odd ? q[t].x : q[t].z, sy = odd ? q[t].y : q[t].w;      // what the partner needs
+        const float rx = swp(sx), ry = swp(sy);
+        av[t] = odd ? make_float2(rx, ry) : make_float2(q[t].x, q[t].y);
+        bv[t] = odd ? make_float2(q[t].z, q[t].w) : make_float2(rx, ry);
+      }
+      untangle(it, j, single, av, bv, ny);
+    }
     XCX_STAMP(2, s0a[0][0].x);
   } else {
 #pragma unroll
