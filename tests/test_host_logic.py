@@ -412,3 +412,14 @@ def test_top_level_names_of_the_reference():
     assert X.signal.__name__ == 'xcorr_amd.signal' and X.stream.__name__ == 'xcorr_amd.stream'
     with pytest.raises(AttributeError):
         X.plot
+
+
+def test_container_methods_mirror_the_dataset_accessor(tmp_path):
+    """core/accessors.py:52-110: postprocess / process / write / merge as methods."""
+    ds = core.init('A.B..Z-C.D..Z', 0., 7200., sampling_rate=10., window_length=600., window_overlap=.5)
+    ds.status[...] = 1
+    path = str(tmp_path / 'x.nc')
+    assert ds.write(path) is True
+    m = ds.merge(path)
+    assert np.array_equal(m.status, ds.status) and m.attrs['history'].startswith('Merged @')
+    assert callable(ds.process) and callable(ds.postprocess)

@@ -34,6 +34,24 @@ class CCDataset:
         # 'n/a' until processed (core/init.py:252-255); None when hashing was not requested
         self.hash = np.full(shape[:2], 'n/a', dtype=object) if hash_waveforms else None
 
+    # the methods of the reference's ``Dataset.xcorr`` accessor (core/accessors.py:52-110) that
+    # belong to this path, on the container itself
+    def process(self, client, **kwargs):
+        from .process import process
+        return process(self, client, **kwargs)
+
+    def postprocess(self, **kwargs):
+        from .postprocess import postprocess
+        return postprocess(self, **kwargs)
+
+    def write(self, path, **kwargs):
+        from ..io import write
+        return write(self, path, **kwargs)
+
+    def merge(self, *others, **kwargs):
+        from ..io import merge
+        return merge(self, *others, **kwargs)
+
     def to_xarray(self):
         import xarray as xr
         ds = xr.Dataset()
