@@ -71,3 +71,22 @@ def test_product_path_has_no_cpu_fallback():
         import xcorr_amd.util.cc as ucc
         with pytest.raises(_ffi.XcxError):
             ucc.cc(np.ones(8, np.float32), np.ones(8, np.float32))
+
+
+def test_header_is_plain_c(tmp_path):
+    """The boundary is a C ABI: include/xcx.h compiles as C99 with no C++ (or torch) in sight, and a
+    plain-C caller links against libxcx.so."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / 'hdr.c'
+    src.write_text('#include "xcx.h"\nint main(void) { return XCX_OK; }\n')
+    subprocess.run([gcc, '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I', os.path.join(root, 'include'),
+                    '-c', str(src), '-o', str(tmp_path / 'hdr.o')], check=True)
+    lib = os.path.join(root, 'xcorr_amd', 'lib')
+    subprocess.run([gcc, '-std=c99', '-Wall', '-O1', '-I', os.path.join(root, 'include'),
+                    os.path.join(root, 'examples', 'abi_demo.c'), '-L', lib, '-lxcx', f'-Wl,-rpath,{lib}', '-lm',
+                    '-o', str(tmp_path / 'abi_demo')], check=True)

@@ -417,3 +417,23 @@ def test_example_script_runs(ctx, tmp_path):
         stack = pp.cc[ip][pp.status[ip] == 1].mean(axis=0)
         peak = pp.lag[int(np.argmax(np.abs(stack)))]
         assert abs(peak - 0.5 * (i - j)) <= 0.04, (pair, peak)
+
+
+def test_plain_c_caller(ctx, tmp_path):
+    """examples/abi_demo.c: gcc-compiled C program against include/xcx.h + libxcx.so reproduces the
+    util/cc.py KAT of SURVEY 8c and finds the lag of a delayed copy."""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.path.join(root, 'xcorr_amd', 'lib')
+    exe = str(tmp_path / 'abi_demo')
+    subprocess.run([gcc, '-std=c99', '-O2', '-I', os.path.join(root, 'include'), os.path.join(root, 'examples', 'abi_demo.c'),
+                    '-L', lib, '-lxcx', f'-Wl,-rpath,{lib}', '-lm', '-o', exe], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=120).stdout.splitlines()
+    kat = np.array([float(v) for v in out[0].split()[1:]])
+    assert np.allclose(kat, [0, .5, 2, 3.5, 5, 4, 0], atol=1e-5)
+    f = out[1].split()
+    assert int(f[2]) == 359999 and int(f[6]) == -250 and 0.8 < float(f[8]) < 1.0
