@@ -179,6 +179,19 @@ def lib_sha256():
     return h.hexdigest()
 
 
+def src_sha256():
+    """sha256 over the kernel sources (csrc/*.hip, *.h, Makefile, include/xcx.h): identifies the build
+    independently of where and when it was compiled (the .so embeds build paths)."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, 'xcorr_amd', 'csrc')
+    files = sorted(f for f in os.listdir(csrc) if f.endswith(('.hip', '.h')) or f == 'Makefile')
+    for f in [os.path.join(csrc, f) for f in files] + [os.path.join(ROOT, 'include', 'xcx.h')]:
+        h.update(os.path.basename(f).encode())
+        with open(f, 'rb') as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get('RANK', '0'))
@@ -409,6 +422,11 @@ def main():
     if rank == 0:
         sha = lib_sha256()
         res['lib_sha256'] = sha
+        try:
+            ssha = src_sha256()
+        except OSError:
+            ssha = None
+        res['src_sha256'] = ssha
         # algorithmic bytes per pair-window: every CCF written once
         # + every station window read once (+ the preprocess pass over the day)
         b_pw = 4.0 * L + 4.0 * n * S / len(pairs_all)
@@ -429,7 +447,8 @@ def main():
                 try:
                     pmc = json.load(open(pmc_path))
                     st = pmc.get('_stamp', {})
-                    if st.get('lib_sha256') != sha:
+                    same_build = st.get('lib_sha256') == sha or (ssha is not None and st.get('src_sha256') == ssha)
+                    if not same_build:
                         tr_note = 'pmc_latest.json was measured on another libxcx.so build'
                     elif st.get('workload') != workload_str or st.get('pair_batch') != plan.batch:
                         tr_note = 'pmc_latest.json was measured on another workload'

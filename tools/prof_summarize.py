@@ -90,7 +90,7 @@ try:
     for ln in open(os.path.join(out, 'bench_kt.log')):
         if ln.startswith('{'):
             d = json.loads(ln)
-            stamp.update({'lib_sha256': d.get('lib_sha256'), 'workload': d['config']['workload'],
+            stamp.update({'lib_sha256': d.get('lib_sha256'), 'src_sha256': d.get('src_sha256'), 'workload': d['config']['workload'],
                           'pair_batch': d['config'].get('pair_batch'), 'value_during_kernel_trace': d.get('value')})
 except OSError:
     pass
