@@ -115,3 +115,29 @@ def test_signal_mirror_and_errors(ctx):
         ops.correlate2d(ctx, np.zeros((1, 8, 4097), np.float32), [(0, 0)])
     with pytest.raises(XcxError):
         ops.correlate2d(ctx, np.ones((2, 8, 8), np.float32), [(0, 2)])
+
+
+def test_timelapse_data_path(ctx):
+    """scripts/timelapse.py:196-268 for one pair: spectrogram of every time, then per band and time
+    pair the maximum of correlate2d and its (delta_freq, delta_lag), against scipy / numpy."""
+    from xcorr_amd.core import timelapse
+    rng = np.random.default_rng(17)
+    fs, T, L = 50., 4, 601
+    t = (np.arange(L) - L // 2) / fs
+    cc = np.stack([0.02 * rng.standard_normal(L) + np.exp(-0.5 * ((t - 0.04 * k) / 1.5) ** 2) * np.cos(2 * np.pi * (4. + 0.1 * k) * t)
+                   for k in range(T)]).astype(np.float32)
+    freq, bw = np.array([4., 8.]), np.array([4., 4.])
+    res = timelapse.correlate_spectrograms(cc, fs, freq, bw, duration=0.64, padding_factor=2, ctx=ctx)
+    f, psd = R.spectrogram(cc, fs, 0.64, 2)
+    assert np.allclose(res['freq'], f) and res['cc2'].shape == (2, 6) and (res['status'] == 1).all()
+    df = f[1] - f[0]
+    for b in range(2):
+        sel = (f >= freq[b] - bw[b] / 2) & (f < freq[b] + bw[b] / 2)
+        for k, (i, j) in enumerate(res['pairs']):
+            full = R.correlate2d(psd[i][sel], psd[j][sel], normalize=True)
+            a0, a1 = np.unravel_index(np.argmax(full), full.shape)
+            assert abs(res['cc2'][b, k] - full.max()) <= 1e-5 * abs(full.max())
+            assert np.isclose(res['delta_freq'][b, k], (a0 - (sel.sum() - 1)) * df)
+            assert np.isclose(res['delta_lag'][b, k], (a1 - (L - 1)) / fs)
+    empty = timelapse.correlate_spectrograms(cc, fs, [24.9], [0.01], duration=0.64, padding_factor=2, ctx=ctx)
+    assert (empty['status'] == 0).all()

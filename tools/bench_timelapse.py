@@ -26,10 +26,8 @@ def main():
     a = ap.parse_args()
     rank = int(os.environ.get('RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+    from xcorr_amd.rendezvous import from_env
+    rdzv = from_env()                          # file rendezvous of the launcher's ranks (no torch)
     import ctypes as C
     import xcorr_amd as X
     from xcorr_amd import _ffi, ops
@@ -58,16 +56,13 @@ def main():
     run = lambda: ops.correlate2d(ctx, tiles, pairs)
     for _ in range(a.warmup):
         run()
-    if dist: dist.barrier()
+    rdzv.barrier()
     ctx.sync(); t0 = time.perf_counter()
     for _ in range(a.steps):
         peak, idx = run()
     ctx.sync()
-    if dist: dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist:
-        import torch
-        tt = torch.tensor([dt], dtype=torch.float64); dist.all_reduce(tt, op=dist.ReduceOp.MAX); dt = float(tt[0])
+    rdzv.barrier()
+    dt = rdzv.max(time.perf_counter() - t0)
     if rank == 0:
         ms = dt / a.steps * 1e3
         # algorithmic bytes per pair: 2 spectra in + intermediate out/in = 67 MB
@@ -79,7 +74,7 @@ def main():
                                    f'peak + position, padded transform 512x8192' + (', tiles from spectrogram' if a.from_ccf else ''),
                        'pairs_per_rank': int(len(pairs)), **extra},
             'check': {'peak0': float(peak[0]), 'idx0': [int(v) for v in idx[0]]}}))
-    if dist: dist.destroy_process_group()
+    rdzv.close()
 
 
 if __name__ == '__main__':

@@ -4,5 +4,6 @@ from .process import process, process_batched  # noqa: F401
 from .client import ArrayClient  # noqa: F401
 from .postprocess import postprocess, postprocess_rows  # noqa: F401
 from . import lazy  # noqa: F401
+from . import timelapse  # noqa: F401
 
-__all__ = ['init', 'process', 'process_batched', 'postprocess', 'postprocess_rows', 'lazy', 'CCDataset', 'ArrayClient']
+__all__ = ['init', 'process', 'process_batched', 'postprocess', 'postprocess_rows', 'lazy', 'timelapse', 'CCDataset', 'ArrayClient']
