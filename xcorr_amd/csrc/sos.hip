@@ -48,10 +48,13 @@ template <int K>
 __device__ __forceinline__ double sos_step(const SosParams& P, double (&z)[K][2], double v) {
 #pragma unroll
   for (int k = 0; k < K; ++k) {
+    // five float64 operations per section, explicitly fused: the compiler's six-operation form of the
+    // same expressions costs the tiles kernel 6 % (SQ counters: a wave spends 25 % of its life issuing
+    // VALU, ~2.25 waves per SIMD; profiles/r02_ablation.txt)
     const SosCoef c = P.c[k];
-    const double y = c.b0 * v + z[k][0];
-    z[k][0] = c.b1 * v - c.a1 * y + z[k][1];
-    z[k][1] = c.b2 * v - c.a2 * y;
+    const double y = fma(c.b0, v, z[k][0]);
+    z[k][0] = fma(c.b1, v, fma(-c.a1, y, z[k][1]));
+    z[k][1] = fma(c.b2, v, -c.a2 * y);
     v = y;
   }
   return v;
