@@ -182,6 +182,10 @@ int xcx_norm1d(xcx_ctx* ctx, float* x, long batch, long n, int on_device);
 int xcx_demean(xcx_ctx* ctx, float* x, long batch, long n, int on_device);
 int xcx_detrend_linear(xcx_ctx* ctx, float* x, long batch, long n,
                        int on_device);
+/* the same two detrends from DEVICE rows src into DEVICE rows dst (dst may be src): an
+ * original that has to stay (raw traces, re-processed with other settings) needs no copy
+ * first.  linear: 0 = subtract the mean, 1 = subtract the least-squares line. */
+int xcx_detrend_to(xcx_ctx* ctx, const float* src, float* dst, long batch, long n, int linear);
 int xcx_taper(xcx_ctx* ctx, float* x, long batch, long n, long nmax,
               int wtype, int on_device);
 int xcx_unbias(xcx_ctx* ctx, float* x, long batch, long npts, long idx_min,

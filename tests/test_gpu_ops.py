@@ -286,3 +286,17 @@ def test_postprocess_rows_device_resident(ctx):
     assert dev.shape == (5, L - 1) and np.array_equal(dev.to_host(), host)
     ref = np.stack([R.postprocess_chain(x[i].astype(np.float64), npts, fs, 0, L, delay[i]) for i in range(5)])
     assert relerr(host, ref) < 2 * TOL
+
+
+def test_demean_out_of_place(ctx):
+    """xcx_detrend_to: device rows src -> dst, source untouched; long-row and short-row paths."""
+    rng = np.random.default_rng(31)
+    for rows, n in ((3, 100001), (40, 5000)):
+        x = (rng.standard_normal((rows, n)) + 2.5).astype(np.float32)
+        d, o = ctx.array(x), ctx.empty(x.shape)
+        ops.demean(ctx, d, out=o)
+        assert np.array_equal(d.to_host(), x)
+        assert np.array_equal(o.to_host(), ops.demean(ctx, x.copy()))          # bit-identical to the in-place op
+        assert relerr(o.to_host(), R.demean(x)) < TOL
+    with pytest.raises(ValueError):
+        ops.demean(ctx, x, out=o)                                              # host source

@@ -67,6 +67,7 @@ SIGNATURES = {
     'xcx_norm1d': [_vp, _vp, _l, _l, _i],
     'xcx_demean': [_vp, _vp, _l, _l, _i],
     'xcx_detrend_linear': [_vp, _vp, _l, _l, _i],
+    'xcx_detrend_to': [_vp, _vp, _vp, _l, _l, _i],
     'xcx_taper': [_vp, _vp, _l, _l, _l, _i, _i],
     'xcx_unbias': [_vp, _vp, _l, _l, _l, _l, _i],
     'xcx_onebit': [_vp, _vp, _l, _l, _i],

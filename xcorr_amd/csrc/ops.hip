@@ -103,9 +103,11 @@ __global__ __launch_bounds__(NT) void k_row_partial(const float* __restrict__ x,
   }
 }
 
+// src -> dst (dst may be src): out of place the separate copy of an untouched original is saved
 template <int OP>
-__global__ __launch_bounds__(NT) void k_row_apply(float* __restrict__ x, long n, const double* __restrict__ part) {
-  float* __restrict__ row = x + (size_t)blockIdx.y * n;
+__global__ __launch_bounds__(NT) void k_row_apply(const float* src, float* dst, long n, const double* __restrict__ part) {
+  const float* rin = src + (size_t)blockIdx.y * n;
+  float* row = dst + (size_t)blockIdx.y * n;
   const int tid = threadIdx.x;
   const long per = (n + kParts - 1) / kParts;
   const long lo = blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
@@ -116,16 +118,16 @@ __global__ __launch_bounds__(NT) void k_row_apply(float* __restrict__ x, long n,
   }
   if (OP == OP_NORM) {
     const float fn = (float)sqrt(s0);
-    for (long i = lo + tid; i < hi; i += NT) row[i] = row[i] / fn;
+    for (long i = lo + tid; i < hi; i += NT) row[i] = rin[i] / fn;
   } else if (OP == OP_DEMEAN) {
     const float mean = (float)(s0 / (double)n);
-    for (long i = lo + tid; i < hi; i += NT) row[i] = row[i] - mean;
+    for (long i = lo + tid; i < hi; i += NT) row[i] = rin[i] - mean;
   } else {
     const double tbar = 0.5 * (double)(n - 1);
     const double stt = (double)n * ((double)n * (double)n - 1.0) / 12.0;
     const double m = (n > 1) ? s1 / stt : 0.0;
     const double b = s0 / (double)n - m * tbar;
-    for (long i = lo + tid; i < hi; i += NT) row[i] = (float)((double)row[i] - (m * (double)i + b));
+    for (long i = lo + tid; i < hi; i += NT) row[i] = (float)((double)rin[i] - (m * (double)i + b));
   }
 }
 
@@ -342,13 +344,33 @@ template <int OP> int row_op(xcx_ctx* ctx, float* x, long batch, long n, int on_
     if ((rc = ctx->scratch[0].ensure(ctx, sizeof(double) * 2 * kParts * (size_t)batch))) return rc;
     double* part = (double*)ctx->scratch[0].ptr;
     hipLaunchKernelGGL(k_row_partial<OP>, dim3(kParts, (unsigned)batch), dim3(NT), 0, ctx->stream, st.dev, n, part);
-    hipLaunchKernelGGL(k_row_apply<OP>, dim3(kParts, (unsigned)batch), dim3(NT), 0, ctx->stream, st.dev, n, part);
+    hipLaunchKernelGGL(k_row_apply<OP>, dim3(kParts, (unsigned)batch), dim3(NT), 0, ctx->stream, (const float*)st.dev, st.dev, n, part);
     HIP_TRY(hipGetLastError());
     return st.end();
   }
   hipLaunchKernelGGL(k_row_reduce_apply<OP>, dim3((unsigned)batch), dim3(NT), 0, ctx->stream, st.dev, n);
   HIP_TRY(hipGetLastError());
   return st.end();
+}
+
+// device rows src -> dst; the source stays untouched
+template <int OP> int row_op_to(xcx_ctx* ctx, const float* src, float* dst, long batch, long n) {
+  if (!ctx || !src || !dst) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || n < 1) return set_err(XCX_EINVAL, "batch and n must be >= 1");
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc;
+  if (batch < 1024 && n >= 65536) {
+    if ((rc = ctx->scratch[0].ensure(ctx, sizeof(double) * 2 * kParts * (size_t)batch))) return rc;
+    double* part = (double*)ctx->scratch[0].ptr;
+    hipLaunchKernelGGL(k_row_partial<OP>, dim3(kParts, (unsigned)batch), dim3(NT), 0, ctx->stream, src, n, part);
+    hipLaunchKernelGGL(k_row_apply<OP>, dim3(kParts, (unsigned)batch), dim3(NT), 0, ctx->stream, src, dst, n, part);
+    HIP_TRY(hipGetLastError());
+    return XCX_OK;
+  }
+  if (dst != src) HIP_TRY(hipMemcpyAsync(dst, src, (size_t)batch * n * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  hipLaunchKernelGGL(k_row_reduce_apply<OP>, dim3((unsigned)batch), dim3(NT), 0, ctx->stream, dst, n);
+  HIP_TRY(hipGetLastError());
+  return XCX_OK;
 }
 
 }  // namespace
@@ -361,6 +383,9 @@ extern "C" int xcx_demean(xcx_ctx* ctx, float* x, long batch, long n, int on_dev
 }
 extern "C" int xcx_detrend_linear(xcx_ctx* ctx, float* x, long batch, long n, int on_device) {
   return row_op<OP_DETREND>(ctx, x, batch, n, on_device);
+}
+extern "C" int xcx_detrend_to(xcx_ctx* ctx, const float* src, float* dst, long batch, long n, int linear) {
+  return linear ? row_op_to<OP_DETREND>(ctx, src, dst, batch, n) : row_op_to<OP_DEMEAN>(ctx, src, dst, batch, n);
 }
 
 extern "C" int xcx_taper(xcx_ctx* ctx, float* x, long batch, long n, long nmax, int wtype, int on_device) {

@@ -52,9 +52,22 @@ def norm1d(ctx, x):
     return buf
 
 
-def demean(ctx, x):
-    """x - mean(x) (xcorr/signal/detrend.py:110)."""
+def _detrend_to(ctx, x, out, linear):
+    """device rows x -> device rows out (x untouched)."""
+    if not isinstance(x, DeviceArray) or not isinstance(out, DeviceArray) or out.nbytes != x.nbytes:
+        raise ValueError('out= needs DeviceArray source and destination of the same size')
+    n = x.shape[-1]
+    b = int(np.prod(x.shape[:-1])) if len(x.shape) > 1 else 1
+    check(_ffi.lib().xcx_detrend_to(ctx.handle, ptr(x), ptr(out), b, n, int(linear)))
+    return out
+
+
+def demean(ctx, x, out=None):
+    """x - mean(x) (xcorr/signal/detrend.py:110).  In place; with ``out`` (device arrays) the
+    source stays untouched and no copy of it is needed first."""
     ctx = _ctx(ctx, x)
+    if out is not None:
+        return _detrend_to(ctx, x, out, 0)
     buf, b, n, dev, _ = _prep(x)
     check(_ffi.lib().xcx_demean(ctx.handle, ptr(buf), b, n, dev))
     return buf

@@ -3,7 +3,7 @@ The driver-timed workload of BASELINE.json configs[2]/[3] as ONE object, so that
 ``bench.py`` (timing) and ``tests/test_gpu_config3.py`` (full-size parity test)
 run exactly the same calls.
 
-Per station-day: copy raw -> work, demean, cosine taper (5 %, <= 30 s),
+Per station-day: demean (raw -> work; raw is kept), cosine taper (5 %, <= 30 s),
 Butterworth band-pass 0.1-10 Hz (4 corners, forward ``sosfilt`` from rest:
 ObsPy's ``Trace.filter`` default, xcorr/stream/process.py:279-282).  Per
 window: one-bit + spectral whitening fused into the forward transforms (no
@@ -77,8 +77,7 @@ class StationDay:
         ctx = ctx or self.ctx
         if not self.preprocess:
             return
-        ops.copy(ctx, self.work, self.raw)
-        ops.demean(ctx, self.work)
+        ops.demean(ctx, self.raw, out=self.work)          # raw -> work: no separate copy of the day
         ops.taper(ctx, self.work, self.taper_n, wtype='cosine')
         ops.sosfilt(ctx, self.work, self.sos)
 
