@@ -60,6 +60,15 @@ __device__ __forceinline__ double sos_step(const SosParams& P, double (&z)[K][2]
   return v;
 }
 
+// value of lane `src` (wave-uniform index) as a scalar: v_readlane_b32 into SGPRs.  The tile loads and
+// stores walk the 64 sequences of the workgroup one after the other and need sequence i's base address and
+// length in every lane: as wave shuffles (ds_bpermute) those broadcasts were half of the kernel's LDS instructions.
+__device__ __forceinline__ long lane_bcast(long v, int src) {
+  const int lo = __builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v & 0xffffffffULL), src);
+  const int hi = __builtin_amdgcn_readlane((int)(unsigned)((unsigned long long)v >> 32), src);
+  return (long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+
 // sequence q -> (row, chunk); chunk covers [chunk*Lc, min(n, (chunk+1)*Lc))
 // REVERSE walks each sequence from its last sample to its first.
 // s0   : [nseq][2K] start states (null = rest)
@@ -102,8 +111,8 @@ __global__ __launch_bounds__(64) void k_sos_tiles(
       float v[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        const long base = __shfl(mybase, i0 + k, 64);
-        const long len = __shfl(mylen, i0 + k, 64);
+        const long base = lane_bcast(mybase, i0 + k);
+        const long len = lane_bcast(mylen, i0 + k);
         const long u = t0 + lane;               // step index within the sequence
         const long t = REVERSE ? (len - 1 - u) : u;
         v[k] = (u < len) ? x[base + t] : 0.f;
@@ -122,8 +131,8 @@ __global__ __launch_bounds__(64) void k_sos_tiles(
     __syncthreads();
     if (WRITE) {
       for (int i = 0; i < nact; ++i) {
-        const long base = __shfl(mybase, i, 64);
-        const long len = __shfl(mylen, i, 64);
+        const long base = lane_bcast(mybase, i);
+        const long len = lane_bcast(mylen, i);
         const long u = t0 + lane;
         if (u < len) {
           const long t = REVERSE ? (len - 1 - u) : u;
