@@ -98,7 +98,6 @@ __global__ __launch_bounds__(64) void k_sos_tiles(
       }
     }
   }
-  const int nact = (int)std::min((long)64, nseq - q0);
   // every lane knows where ITS sequence starts; the cooperative tile loads below fetch
   // sequence i's address and length from lane i (no 64-bit divisions in the loop)
   long mybase = 0;
@@ -130,13 +129,20 @@ __global__ __launch_bounds__(64) void k_sos_tiles(
     }
     __syncthreads();
     if (WRITE) {
-      for (int i = 0; i < nact; ++i) {
-        const long base = lane_bcast(mybase, i);
-        const long len = lane_bcast(mylen, i);
-        const long u = t0 + lane;
-        if (u < len) {
-          const long t = REVERSE ? (len - 1 - u) : u;
-          x[base + t] = tile[i][lane];
+      // 16 sequences per trip: the LDS reads of a trip are issued together (lanes beyond nact have len = 0)
+      for (int i0 = 0; i0 < 64; i0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = tile[i0 + k][lane];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const long base = lane_bcast(mybase, i0 + k);
+          const long len = lane_bcast(mylen, i0 + k);
+          const long u = t0 + lane;
+          if (u < len) {
+            const long t = REVERSE ? (len - 1 - u) : u;
+            x[base + t] = v[k];
+          }
         }
       }
       __syncthreads();
