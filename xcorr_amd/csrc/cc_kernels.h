@@ -50,6 +50,8 @@ struct Geom {
   int idx_min, idx_max;   // retained lag slice of the 2n-1 lags
   int shift;    // (n-1-idx_min) mod N1 : output residue of row m1 = 0
   int flags;
+  int band_hi;  // whitened plans: spectra are EXACTLY zero at folded bins min(k, N-k) > band_hi (the whitening
+                // gain is 0 there), so the pair column pass never loads them; N = no band limit
 };
 
 // per station-window statistics produced by k_stats

@@ -142,10 +142,14 @@ template <class RX> struct ColRot {
   using CG = ColGeom<RX>;
   static constexpr bool ok = (CG::Last::NBF % kWNT == 0) && (CG::NSL % kTR == 0);
 };
-// `in2(k, a, b)` (may be a null functor, In2 = int): two adjacent inputs k, k + 1 (k even) at once -- 16-byte loads.
+// `in(k, kb)`: input k; kb = the smallest k of this wave instruction (lane 0's), a compile-time constant per call.
+// `in2(k, a, b, kb)` (may be a null functor, In2 = int): two adjacent inputs k, k + 1 (k even) at once -- 16-byte loads.
 // Used for the first 2 x 64 butterflies of stage 0 when the column has at least that many
 // (lane l takes butterflies 2l and 2l+1); see pair_src_index.
 struct NoIn2 {};
+#ifndef XCX_TST_AUX
+#define XCX_TST_AUX -1       // T stores: -1 = plain global stores
+#endif
 #ifndef XCX_COL_WIDE
 #define XCX_COL_WIDE 1       // 16-byte spectrum loads in the pair column pass (+0.9 %, profiles/r02_ablation.txt)
 #endif
@@ -168,7 +172,7 @@ XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in
     const int j = tid_of<kWNT>() + it * kWNT;
     if (!G0::GUARD || j < G0::NBF) {
 #pragma unroll
-      for (int t = 0; t < R0; ++t) v0[it][t] = in(j + t * (L / R0), 0);
+      for (int t = 0; t < R0; ++t) v0[it][t] = in(j + t * (L / R0), it * kWNT + t * (L / R0));
     }
   }
   XCX_STAMP(1, v0[G0::IT - 1][R0 - 1].x);          // inputs have arrived (product formed)
@@ -181,12 +185,12 @@ XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in
 #else
   if constexpr (WIDE0) {
 #pragma unroll
-    for (int t = 0; t < R0; ++t) in2(2 * tid_of<kWNT>() + t * (L / R0), v0[0][t], v0[1][t]);
+    for (int t = 0; t < R0; ++t) in2(2 * tid_of<kWNT>() + t * (L / R0), v0[0][t], v0[1][t], t * (L / R0));
 #pragma unroll
     for (int it = 2; it < G0::IT; ++it) {
       const int j = tid_of<kWNT>() + it * kWNT;
 #pragma unroll
-      for (int t = 0; t < R0; ++t) v0[it][t] = in(j + t * (L / R0), 0);
+      for (int t = 0; t < R0; ++t) v0[it][t] = in(j + t * (L / R0), it * kWNT + t * (L / R0));
     }
 #pragma unroll
     for (int it = 0; it < G0::IT; ++it) Bfly<R0, INV>::run(v0[it]);
@@ -196,7 +200,7 @@ XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in
       const int j = tid_of<kWNT>() + it * kWNT;
       if (!G0::GUARD || j < G0::NBF) {
 #pragma unroll
-        for (int t = 0; t < R0; ++t) v0[it][t] = in(j + t * (L / R0), 0);
+        for (int t = 0; t < R0; ++t) v0[it][t] = in(j + t * (L / R0), it * kWNT + t * (L / R0));
         Bfly<R0, INV>::run(v0[it]);
       }
     }
@@ -485,23 +489,45 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
     return r;
   };
 #else
-  auto in = [=](int k1, int) -> cf {
+  // Band-limited spectra (whitened plans, Geom::band_hi): column k2 is exactly zero for k1 in [za, zb],
+  // i.e. where both k = k1 N2 + k2 and N - k lie above the band (60 % of a 0.1-10 Hz band at 50 Hz).
+  // A wave instruction whose points ALL fall inside that range (kb .. kb + span - 1, kb = lane 0's point,
+  // known at compile time per call) does not fetch them: its base pointer -- an SGPR pair, chosen by a
+  // scalar select -- is moved so that the same lane offsets land on ONE fixed chunk of stored zeros at
+  // the start of the range (512 B / 1 KB per column: L1 hits after the first touch).  No branch, no VALU
+  // instruction and no VGPR: a skip branch around each load pair made the compiler wait for every pair
+  // before issuing the next (24 serial round trips per wave), and per-lane selects of the offset or of
+  // the loaded value cost one VGPR per load and split the gather in two at 128 VGPRs.  Instructions
+  // that straddle a band edge load what is stored (zeros included).
+  const int za = (g.band_hi >= k2) ? (g.band_hi - k2) / g.N2 + 1 : 0;
+  const int zb = (g.N - g.band_hi - k2 + g.N2 - 1) / g.N2 - 1;
+  const int zev = (za + 1) & ~1;                                  // first even index inside the range
+  const bool zok = zb - zev + 1 >= 2 * kWNT;                      // room for the zero chunk of a 16-byte wave load
+  auto zbase = [=](const cf* base, int kb, int span) -> const cf* {
+    const bool uz = zok && kb >= za && kb + span - 1 <= zb;       // wave-uniform
+    return uz ? base + (zev - kb) : base;
+  };
+  auto in = [=](int k1, int kb) -> cf {
 #ifdef XCX_SKIP_XLD
     k1 &= 15;                                    // ablation: every load hits the same 128 bytes
 #endif
-    if constexpr (MODE == 2) {
-      return *uoff(A, (unsigned)k1);
-    } else {
+    if constexpr (MODE == 1) {
       cf acc = cmulc(*uoff(A, (unsigned)k1), *uoff(Bp, (unsigned)k1));
-      if constexpr (MODE == 1) {
-        for (int w = 1; w < nstack; ++w)
-          acc = cadd(acc, cmulc(A[k1 + w * sstride], Bp[k1 + w * sstride]));
-      }
+      for (int w = 1; w < nstack; ++w)
+        acc = cadd(acc, cmulc(A[k1 + w * sstride], Bp[k1 + w * sstride]));
       return acc;
+    } else if constexpr (MODE == 2) {
+      return *uoff(zbase(A, kb, kWNT), (unsigned)k1);
+    } else {
+      return cmulc(*uoff(zbase(A, kb, kWNT), (unsigned)k1), *uoff(zbase(Bp, kb, kWNT), (unsigned)k1));
     }
   };
 #endif
   cf* __restrict__ Tc = T + k2 * kWRB;
+#if XCX_TST_AUX >= 0
+  // experiment: T stores as buffer stores with an explicit cache policy (aux: 2 = nt, 16 = sc1, 18 = both)
+  const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(Tc, 0, 0x7fffffff, 0x00020000);
+#endif
   const int trow = (N2h + 1) * kTR;           // float2 per 64-row tile
   const int qrow = (N2h + 1) * kWRB;          // float2 per 16-row quarter
   auto roff = [=](int r64) -> unsigned {      // row r64 of a tile (this wave's k2): quarter, row inside it
@@ -558,8 +584,16 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
 #ifdef XCX_SKIP_TST
         if (N2h == -1)                             // ablation: never true at run time
 #endif
+#if XCX_TST_AUX >= 0
+        {
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          const u32x4 w4 = {sx[0], sy[0], sx[1], sy[1]};
+          __builtin_amdgcn_raw_buffer_store_b128(w4, trsrc, (int)(o * 8u), 0, XCX_TST_AUX);
+        }
+#else
         *reinterpret_cast<float4*>(uoff(Tc, o)) =
             make_float4(__uint_as_float(sx[0]), __uint_as_float(sy[0]), __uint_as_float(sx[1]), __uint_as_float(sy[1]));
+#endif
       });
       (void)off0; (void)twrap; (void)wrapsz;
     } else {
@@ -584,13 +618,13 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
   };
 #if XCX_COL_WIDE && !defined(XCX_STAMPS) && !defined(XCX_ABLATE_MATH)
   if constexpr (MODE != 1) {
-    auto in2 = [=](int k1, cf& ra, cf& rb) {
+    auto in2 = [=](int k1, cf& ra, cf& rb, int kb) {
       typedef float f32x4 __attribute__((ext_vector_type(4)));
-      const f32x4 qa = *reinterpret_cast<const f32x4*>(uoff(A, (unsigned)k1));
+      const f32x4 qa = *reinterpret_cast<const f32x4*>(uoff(zbase(A, kb, 2 * kWNT), (unsigned)k1));
       if constexpr (MODE == 2) {
         ra = make_float2(qa.x, qa.y); rb = make_float2(qa.z, qa.w);
       } else {
-        const f32x4 qb = *reinterpret_cast<const f32x4*>(uoff(Bp, (unsigned)k1));
+        const f32x4 qb = *reinterpret_cast<const f32x4*>(uoff(zbase(Bp, kb, 2 * kWNT), (unsigned)k1));
         ra = cmulc(make_float2(qa.x, qa.y), make_float2(qb.x, qb.y));
         rb = cmulc(make_float2(qa.z, qa.w), make_float2(qb.z, qb.w));
       }
@@ -658,6 +692,9 @@ template <bool SC1> XCX_DEV cf load_t(const cf* p) {
 // N2h+1 slots), output row `out`, block index blk
 #ifndef XCX_BUFSTORE
 #define XCX_BUFSTORE 1
+#endif
+#ifndef XCX_CCF_AUX
+#define XCX_CCF_AUX 2         // cache policy of the CCF stores: 2 = nt (streaming)
 #endif
 #ifndef XCX_ROW_PAIR
 #define XCX_ROW_PAIR 0        // 16-byte T loads by lane pairs + DPP swap in the row pass (experiment)
@@ -987,14 +1024,14 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
         if (uniform && o >= 0 && (unsigned)(o + 3) < Lout) {
           typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
           const u32x4 w4 = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-          __builtin_amdgcn_raw_buffer_store_b128(w4, rsrc, o * 4, 0, /*nt*/ 2);
+          __builtin_amdgcn_raw_buffer_store_b128(w4, rsrc, o * 4, 0, XCX_CCF_AUX);
         } else {
           const float ve[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int kk = s - ((r0 + e < shift) ? 1 : 0);
             if (kk >= half * KH && kk < (half + 1) * KH)
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ve[e]), rsrc, (o + e) * 4, 0, /*nt*/ 2);   // range-checked
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ve[e]), rsrc, (o + e) * 4, 0, XCX_CCF_AUX);   // range-checked
           }
         }
       }
@@ -1245,7 +1282,6 @@ void k_wpair_dual(WDualArgs a) {
   cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave * PG::kPerWave);
   const int x = blockIdx.x & 7;
   const int wgq = (int)(blockIdx.x >> 3);
-  const int Bm = a.Bc > a.Br ? a.Bc : a.Br;
   const int grp = wgq / (PG::CWX + PG::RWX), pos = wgq % (PG::CWX + PG::RWX);
 #ifdef XCX_STAMPS
   const int q = (int)blockIdx.x * kWPB + wave;
@@ -1266,10 +1302,15 @@ void k_wpair_dual(WDualArgs a) {
   } stamp_out{xst, a.stamps, q, pos < PG::CWX ? 1 : 2};
 #endif
   if (pos < PG::CWX) {
+    // the (N2h + 1) Bc column items (k2-major: consecutive items = one column of consecutive
+    // pair-windows, so a station column is re-read from the XCD's L2) are cut into 8 EQUAL shares,
+    // one per XCD label: with k2 = x mod 8, XCD 0 had 16 columns of 121 and the others 15
     const int ci = (grp * PG::CWX + pos) * kWPB + wave;
-    const int k2 = (ci / Bm) * 8 + x;
-    const int pwl = ci % Bm;
-    if (k2 > N2h || pwl >= a.Bc) return;
+    const int per = ((N2h + 1) * a.Bc + 7) >> 3;
+    const int item = x * per + ci;
+    if (ci >= per || item >= (N2h + 1) * a.Bc) return;
+    const int k2 = item / a.Bc;
+    const int pwl = item - k2 * a.Bc;
     pair_col_body<RXC, MODE>(lds, a.X, a.spec_pitch, a.pw_c[pwl], a.nstack, k2,
                               a.Tc + (size_t)pwl * N1 * (N2h + 1), a.tw_N1, a.tw_N, g XCX_ST_ARG);
   } else {

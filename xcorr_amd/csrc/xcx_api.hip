@@ -14,6 +14,7 @@
 #include "../../include/xcx.h"
 #include "cc_launch.h"
 #include "wave_launch.h"
+#include "pair_order.h"
 #include "xcx_internal.h"
 
 using namespace xcx;
@@ -419,6 +420,7 @@ struct xcx_plan {
   // workspaces
   DevBuf stats, Tm_f, Tn_f, spectra, T, descs, dtraces, dout, dpairs;
   std::vector<PwDesc> hdescs;
+  std::vector<int> bounds;   // launch-batch starts inside one window's P descriptors (pair_order.h); empty: fixed batches
   unsigned long long desc_key = 0;
   long long launches = 0, pair_windows = 0;
   // optional per-kernel HIP-event timing (xcx_plan_profile)
@@ -572,6 +574,7 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
   g.shift = (int)(((long long)n - 1 - idx_min) % g.N1);
   if (g.shift < 0) g.shift += g.N1;
   g.flags = flags & 0xffff;
+  g.band_hi = g.N;
   p->L = idx_max - idx_min;
   size_t sp = (size_t)g.N1 * g.N2h + g.N1;
   p->spec_pitch = (sp + 15) / 16 * 16;
@@ -653,6 +656,13 @@ extern "C" int xcx_plan_set_whiten(xcx_plan* p, double fs, double fmin,
   }
   p->fixed_norm = (float)sqrt(acc / N);
   p->whiten_set = true;
+  // whiten_gain() is 0 for every folded bin k > wb[3] (float compare, k exact below 2^24): those spectrum
+  // elements are stored as exact zeros by the forward column pass and the pair pass skips their loads
+  {
+    static const bool prune = !(getenv("XCX_BAND_PRUNE") && atoi(getenv("XCX_BAND_PRUNE")) == 0);
+    const double hi = floor((double)p->wb[3]);
+    p->g.band_hi = (prune && (p->g.flags & XCX_F_WHITEN) && hi >= 0 && hi < (double)N) ? (int)hi : N;
+  }
   return XCX_OK;
 }
 
@@ -943,10 +953,14 @@ static int dual_launch(xcx_plan* p, int chain, size_t d0, int Bc, int nstack, fl
 // run descriptors [first, first+count) through the dual pipelines: batches are
 // dealt round-robin to the chains; on return every chain has been drained and
 // the context's main stream waits for all of them
-static int dual_run(xcx_plan* p, size_t first, size_t count, int nstack, float* out, const cf* Xsrc = nullptr) {
+static int dual_run(xcx_plan* p, size_t first, size_t count, int nstack, float* out, const cf* Xsrc = nullptr,
+                    const std::vector<int>* bounds = nullptr) {
   xcx_ctx* ctx = p->ctx;
   int rc;
   const int B = p->batch;
+  // station-grouped batches: the descriptors are whole windows of P pairs, each cut at the same group starts
+  const size_t Pw = (bounds && bounds->size() >= 2) ? (size_t)bounds->back() : 0;
+  if (Pw == 0 || count % Pw != 0) bounds = nullptr;
   const int nch = p->nchains;
   for (int c = 0; c < nch; ++c) {
     xcx_plan::Chain& ch = p->chains[c];
@@ -966,9 +980,18 @@ static int dual_run(xcx_plan* p, size_t first, size_t count, int nstack, float* 
     for (int c = 0; c < nch; ++c) HIP_TRY(hipStreamWaitEvent(p->chains[c].stream, p->ev_fwd, 0));
   }
   size_t k = 0;
-  for (size_t d0 = first; d0 < first + count; d0 += B, ++k)
-    if ((rc = dual_launch(p, (int)(k % nch), d0, (int)std::min((size_t)B, first + count - d0), nstack, out, Xsrc)))
-      return rc;
+  if (bounds) {
+    for (size_t w0 = first; w0 < first + count; w0 += Pw)
+      for (size_t gi = 0; gi + 1 < bounds->size(); ++gi) {
+        const int b0 = (*bounds)[gi], b1 = (*bounds)[gi + 1];
+        for (int q0 = b0; q0 < b1; q0 += B, ++k)       // a group never exceeds B; the loop is a guard
+          if ((rc = dual_launch(p, (int)(k % nch), w0 + q0, std::min(B, b1 - q0), nstack, out, Xsrc))) return rc;
+      }
+  } else {
+    for (size_t d0 = first; d0 < first + count; d0 += B, ++k)
+      if ((rc = dual_launch(p, (int)(k % nch), d0, (int)std::min((size_t)B, first + count - d0), nstack, out, Xsrc)))
+        return rc;
+  }
   for (int c = 0; c < nch; ++c) {
     if (p->chains[c].B > 0 && (rc = dual_launch(p, c, 0, 0, 1, out, Xsrc))) return rc;   // rows of the last batch
     p->chains[c].B = 0;
@@ -1357,15 +1380,21 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
   const bool via_gram = stack && p->wave && p->gram && W > 1;     // descriptors come from stack_tables()
   if (!via_gram && (key != p->desc_key || p->hdescs.size() != ndesc)) {
     std::vector<int> perm(P);
-    for (int i = 0; i < P; ++i) perm[i] = i;
-    // station-tile edge of the processing order: a launch batch should cover whole tiles
-    // (25 pair-windows = one 5 x 5 tile = 10 distinct station spectra)
-    static const int tile = getenv("XCX_TILE") ? std::max(1, atoi(getenv("XCX_TILE"))) : 8;
-    std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
-      int ta = (pairs[2 * a] / tile) * 8192 + (pairs[2 * a + 1] / tile);
-      int tb = (pairs[2 * b] / tile) * 8192 + (pairs[2 * b + 1] / tile);
-      return ta < tb;
-    });
+    // processing order.  Dual pipelines: launch batches = station groups (pair_order.h: few distinct
+    // stations per launch, so few first-touch spectrum fetches); otherwise 8 x 8 station tiles.
+    static const bool grouped = !(getenv("XCX_GROUPS") && atoi(getenv("XCX_GROUPS")) == 0);
+    p->bounds.clear();
+    if (grouped && p->dual && !p->flow && !p->fused) {
+      pair_groups(pairs, S, P, p->batch, perm, p->bounds);
+    } else {
+      for (int i = 0; i < P; ++i) perm[i] = i;
+      static const int tile = getenv("XCX_TILE") ? std::max(1, atoi(getenv("XCX_TILE"))) : 8;
+      std::stable_sort(perm.begin(), perm.end(), [&](int a, int b) {
+        int ta = (pairs[2 * a] / tile) * 8192 + (pairs[2 * a + 1] / tile);
+        int tb = (pairs[2 * b] / tile) * 8192 + (pairs[2 * b + 1] / tile);
+        return ta < tb;
+      });
+    }
     p->hdescs.resize(ndesc);
     if (stack) {
       for (int q = 0; q < P; ++q) {
@@ -1414,7 +1443,7 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
     } else if (p->flow) {
       if ((rc = flow_run(p, 0, (size_t)P, ns, dout, src))) return rc;
     } else if (p->dual) {
-      if ((rc = dual_run(p, 0, (size_t)P, ns, dout, src))) return rc;
+      if ((rc = dual_run(p, 0, (size_t)P, ns, dout, src, via_gram ? nullptr : &p->bounds))) return rc;
     } else {
       for (size_t d0 = 0; d0 < (size_t)P; d0 += B)
         if ((rc = pair_batch(p, d0, (int)std::min((size_t)B, P - d0), dout, ns, src))) return rc;
@@ -1435,7 +1464,7 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
     } else if (p->flow) {
       if ((rc = flow_run(p, 0, ndesc, 1, dout))) return rc;
     } else if (p->dual) {
-      if ((rc = dual_run(p, 0, ndesc, 1, dout))) return rc;
+      if ((rc = dual_run(p, 0, ndesc, 1, dout, nullptr, &p->bounds))) return rc;
     } else {
       for (size_t d0 = 0; d0 < ndesc; d0 += B)
         if ((rc = pair_batch(p, d0, (int)std::min((size_t)B, ndesc - d0), dout, 1))) return rc;
@@ -1450,7 +1479,7 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
       } else if (p->flow) {
         if ((rc = flow_run(p, (size_t)w * P, (size_t)P, 1, dout))) return rc;
       } else if (p->dual) {
-        if ((rc = dual_run(p, (size_t)w * P, (size_t)P, 1, dout))) return rc;
+        if ((rc = dual_run(p, (size_t)w * P, (size_t)P, 1, dout, nullptr, &p->bounds))) return rc;
       } else {
         for (size_t q0 = 0; q0 < (size_t)P; q0 += B)
           if ((rc = pair_batch(p, (size_t)w * P + q0, (int)std::min((size_t)B, P - q0), dout, 1))) return rc;
