@@ -265,10 +265,15 @@ def main():
 
     # time-stack across ranks (configs[3]): the only exchange step of the path
     rccl = None
+    rccl_ranks = None
     if a.stack and world > 1:
         uid = rdzv.broadcast(X.Context.comm_unique_id() if rank == 0 else b'')
         ctx.comm_init(uid, world, rank)          # a failure here is fatal: no silent partial stacks
         rccl = 'reduce_scatter' if (nrows * ld) % world == 0 else 'all_reduce'
+        rccl_ranks, rccl_rank = ctx.comm_info()  # what RCCL itself says, not what we passed in
+        if rccl_ranks != world or rccl_rank != rank:
+            raise SystemExit(f'RCCL communicator spans {rccl_ranks} ranks (rank {rccl_rank}); '
+                             f'launcher says WORLD_SIZE={world}, RANK={rank}')
 
     def step():
         if not a.stack:
@@ -277,12 +282,16 @@ def main():
         if len(my_days) == 1 and world == 1:
             sd.step()                            # single stacked day: xcx_cc1d_pairs(XCX_STACK)
             return
-        for r in raws:
-            sd.raw = r
-            sd.front()
-            plan.stack_add(sd.view, pairs, W, hop, stride_s=T)
-        if raws:
-            plan.stack_finish(pairs, out=out, ld_out=ld)
+        try:
+            for r in raws:
+                sd.raw = r
+                sd.front()
+                plan.stack_add(sd.view, pairs, W, hop, stride_s=T)
+            if raws:
+                plan.stack_finish(pairs, out=out, ld_out=ld)
+        except BaseException:
+            plan.stack_reset()                   # do not leave the plan refusing every later call
+            raise
         else:
             out.zero()                           # more ranks than days: contributes zeros
         if rccl:
@@ -418,6 +427,7 @@ def main():
     }
     if a.stack:
         res['rccl_stack_reduce'] = rccl
+        res['rccl_ranks'] = rccl_ranks if rccl else None     # ncclCommCount of the communicator used
         res['config']['station_days'] = ndays
     if rank == 0:
         sha = lib_sha256()

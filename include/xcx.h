@@ -127,6 +127,9 @@ int xcx_cc1d_stack_add(xcx_plan* plan, const float* traces, int S, int W, long s
                        long stride_w, const int* pairs, int P, int on_device);
 int xcx_cc1d_stack_finish(xcx_plan* plan, const int* pairs, int P, float* out, long ld_out,
                           int on_device, long long* windows);
+/* Abandon an open accumulation (after a failed add or an error in the driver loop): clears the
+ * accumulator state so that the plan accepts xcx_cc1d_pairs or a new series of adds again. */
+int xcx_cc1d_stack_reset(xcx_plan* plan);
 
 /* Software pipelining across batches (station-days): compute the spectra of ALL S x W
  * windows of `traces` (device pointer) on a side stream, into a second spectra buffer,
@@ -357,6 +360,11 @@ int xcx_spectrogram_seg(xcx_ctx* ctx, const float* x, float* S, long batch, long
 int xcx_comm_unique_id(char* id_bytes128);
 int xcx_comm_init(xcx_ctx* ctx, const char* id_bytes128, int nranks, int rank);
 int xcx_comm_destroy(xcx_ctx* ctx);
+/* What RCCL itself reports for the communicator of `ctx` (ncclCommCount /
+ * ncclCommUserRank), not what the host passed to xcx_comm_init: the launcher's
+ * evidence that the reduce really spans WORLD_SIZE ranks.  XCX_EINVAL without a
+ * communicator. */
+int xcx_comm_info(xcx_ctx* ctx, int* nranks, int* rank);
 int xcx_stack_reduce(xcx_ctx* ctx, float* stack, size_t count,
                      int reduce_scatter);
 

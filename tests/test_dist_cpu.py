@@ -95,6 +95,34 @@ def test_file_rendezvous_three_ranks(tmp_path):
         assert got == [bytes([r]) * 3 for r in range(world)]
 
 
+def test_file_rendezvous_ignores_a_stale_directory(tmp_path):
+    """A crashed earlier launch with the same key left round files, a join / ack pair and an in_ file
+    behind: the next launch must neither pass a barrier early nor read the old broadcast."""
+    import multiprocessing as mp
+    d = tmp_path / 'xcx_rdzv_stale'
+    d.mkdir()
+    for name, payload in [('r0_0', b''), ('r0_1', b''), ('b1', b'OLD' * 40), ('deadbeefdeadbeef_r0_1', b''),
+                          ('deadbeefdeadbeef_b1', b'OLD' * 40), ('join_1_0123456789abcdef', b''),
+                          ('ack_1_0123456789abcdef', b'deadbeefdeadbeef'), ('in_deadbeefdeadbeef_1', b'')]:
+        (d / name).write_bytes(payload)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    world = 2
+    procs = [ctx.Process(target=_rdzv_worker, args=(r, world, 'stale', str(tmp_path), q)) for r in range(world)]
+    procs[1].start()                   # the non-zero rank first: it must wait for THIS launch's rank 0
+    import time
+    time.sleep(0.5)
+    procs[0].start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, uid, slow, got in res:
+        assert uid == bytes(range(128)) and slow == float(world)
+        assert got == [bytes([r]) * 3 for r in range(world)]
+    assert not d.exists()              # rank 0 removed it after every rank said bye
+
+
 def test_window_blocks_cover_the_day():
     """bench.py --shard windows: contiguous window blocks per rank, disjoint, covering all W."""
     for W_all in (47, 48, 5):

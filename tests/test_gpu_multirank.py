@@ -22,6 +22,7 @@ rd = FileRendezvous(rank, world, key, root=rdir, timeout=120)
 ctx = X.Context(rank)
 uid = rd.broadcast(X.Context.comm_unique_id() if rank == 0 else b'')
 ctx.comm_init(uid, world, rank)
+assert ctx.comm_info() == (world, rank), ctx.comm_info()
 S, n, hop, W = 6, 2000, 1000, 3
 from xcorr_amd.synth import synthetic_traces
 pairs = np.array([(i, j) for i in range(S) for j in range(i + 1, S)], np.int32)

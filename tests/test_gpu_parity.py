@@ -278,11 +278,12 @@ def test_baseline_config_checksum(ctx):
         assert relerr(got[p, w], ref) < TOL
 
 
-@pytest.mark.parametrize('env', [{'XCX_DUAL': '0'}, {'XCX_FUSED': '1'}, {'XCX_ENGINE': 'wg'}],
-                         ids=['two-launch', 'fused-xcd', 'workgroup-engine'])
+@pytest.mark.parametrize('env', [{'XCX_DUAL': '0'}, {'XCX_FLOW': '1'}, {'XCX_ENGINE': 'wg'}, {'XCX_GROUPS': '0'}],
+                         ids=['two-launch', 'flow-one-launch', 'workgroup-engine', 'tile-order'])
 def test_alternative_engines_agree(ctx, env, monkeypatch):
-    """The alternative kernel paths (separate I1/I2 launches, the XCD-local
-    fused kernel, the first-generation 256-thread engine) stay parity-green."""
+    """The alternative kernel paths (separate I1/I2 launches, the opt-in one-launch flow kernel with
+    its in-memory batch dependencies, the first-generation 256-thread engine, the plain station-tile
+    processing order) stay parity-green."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     monkeypatch.setenv('XCX_CHECK', '1')
@@ -304,6 +305,7 @@ def test_rccl_stack_reduce_single_rank(ctx):
     uid = X.Context.comm_unique_id()
     assert len(uid) == 128
     ctx.comm_init(uid, 1, 0)
+    assert ctx.comm_info() == (1, 0)          # ncclCommCount / ncclCommUserRank of the communicator
     a = np.arange(4096, dtype=np.float32).reshape(4, 1024)
     d = ctx.array(a)
     ctx.stack_reduce(d)
@@ -414,6 +416,13 @@ def test_stack_add_finish_equals_sum_of_days(ctx):
     assert nw == 8 and relerr(got, ref) < TOL
     with pytest.raises(XcxError):
         plan.stack_finish(pairs)                                  # accumulator is empty again
+    # an abandoned accumulation (driver error between adds): reset, then the plan works again
+    plan.stack_add(days[0][0], pairs, days[0][1], hop)
+    plan.stack_reset()
+    with pytest.raises(XcxError):
+        plan.stack_finish(pairs)
+    one = plan.pairs(days[1][0], pairs, days[1][1], hop)
+    assert relerr(one, R.cc_pairs(days[1][0], pairs, n, hop, dtype=np.float64).sum(axis=1)) < TOL
     # padded device output; the plan is reusable for a plain stacked call afterwards
     L = 2 * n - 1
     ld = (L + 31) // 32 * 32

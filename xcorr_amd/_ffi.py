@@ -95,11 +95,13 @@ SIGNATURES = {
     'xcx_ram_normalize': [_vp, _vp, _l, _l, _l, _i],
     'xcx_cc1d_stack_add': [_vp, _vp, _i, _i, _l, _l, _vp, _i, _i],
     'xcx_cc1d_stack_finish': [_vp, _vp, _i, _vp, _l, _i, _vp],
+    'xcx_cc1d_stack_reset': [_vp],
     'xcx_cc1d_prepare': [_vp, _vp, _i, _i, _l, _l],
     'xcx_cc1d_prepare_sync': [_vp],
     'xcx_comm_unique_id': [C.c_char_p],
     'xcx_comm_init': [_vp, C.c_char_p, _i, _i],
     'xcx_comm_destroy': [_vp],
+    'xcx_comm_info': [_vp, C.POINTER(_i), C.POINTER(_i)],
     'xcx_stack_reduce': [_vp, _vp, _sz, _i],
 }
 

@@ -48,6 +48,14 @@ extern "C" int xcx_comm_destroy(xcx_ctx* ctx) {
   return XCX_OK;
 }
 
+extern "C" int xcx_comm_info(xcx_ctx* ctx, int* nranks, int* rank) {
+  if (!ctx || !nranks || !rank) return set_err(XCX_EINVAL, "null argument");
+  if (!ctx->comm) return set_err(XCX_EINVAL, "xcx_comm_info: xcx_comm_init() not called on this context");
+  NCCL_TRY(ncclCommCount((ncclComm_t)ctx->comm, nranks));
+  NCCL_TRY(ncclCommUserRank((ncclComm_t)ctx->comm, rank));
+  return XCX_OK;
+}
+
 extern "C" int xcx_stack_reduce(xcx_ctx* ctx, float* stack, size_t count, int reduce_scatter) {
   if (!ctx || !stack) return set_err(XCX_EINVAL, "null argument");
   // No communicator is an error even for one rank: a multi-rank job whose xcx_comm_init failed

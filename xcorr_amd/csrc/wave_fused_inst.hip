@@ -1,4 +1,4 @@
-// wave_fused_inst.hip -- one instantiation of the fused XCD-local pair kernel.
+// wave_fused_inst.hip -- one (N1, N2h) instantiation of the dual and flow pair kernels.
 // Compile with -DXCX_FC_L=<N1> -DXCX_FC_R=<radices> -DXCX_FR_L=<N2h> -DXCX_FR_R=<radices>
 #include <algorithm>
 #include <cstdlib>
@@ -12,17 +12,6 @@ static_assert(RXC::L == XCX_FC_L && RXR::L == XCX_FR_L, "radices do not multiply
 
 #define XCX_CAT3_(a, b, c, d) a##b##c##d
 #define XCX_CAT3(a, b, c, d) XCX_CAT3_(a, b, c, d)
-
-hipError_t XCX_CAT3(launch_wfused_, XCX_FC_L, _, XCX_FR_L)(const WFusedArgs& a, int nblocks, hipStream_t s) {
-  constexpr size_t lc = lds_col_floats(RXC::L), lr = lds_row_floats(RXR::L);
-  constexpr size_t lds = sizeof(float) * (lc > lr ? lc : lr) * kWPB;
-  nblocks = (nblocks + kWPB - 1) / kWPB;
-  if (a.nstack > 1)
-    hipLaunchKernelGGL((k_wpair_fused<RXC, RXR, 1>), dim3(nblocks), dim3(kWNT * kWPB), lds, s, a);
-  else
-    hipLaunchKernelGGL((k_wpair_fused<RXC, RXR, 0>), dim3(nblocks), dim3(kWNT * kWPB), lds, s, a);
-  return hipGetLastError();
-}
 
 hipError_t XCX_CAT3(launch_wdual_, XCX_FC_L, _, XCX_FR_L)(const WDualArgs& a, hipStream_t s) {
   using PG = PairGeom<RXC, RXR>;

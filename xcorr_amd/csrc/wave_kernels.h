@@ -60,12 +60,6 @@ XCX_DEV unsigned long long stamp_nowait(float pin) {
 #define XCX_STAMP_NW(i, pin)
 #endif
 
-#ifdef XCX_ABLATE_WIDE
-#define XCX_ABLATE_WIDE_X 1
-#define XCX_ABLATE_WIDE_TS 1
-#define XCX_ABLATE_WIDE_TL 1
-#endif
-
 // minimum waves per SIMD the register allocator must leave room for
 #ifndef XCX_COL_WAVES
 #define XCX_COL_WAVES 1
@@ -74,21 +68,6 @@ XCX_DEV unsigned long long stamp_nowait(float pin) {
 #define XCX_ROW_WAVES 1
 #endif
 constexpr int kWRB = 16;     // rows per wave
-// wave priority experiment (XCX_PRIO_MODE 1: high while the first loads are issued, low after they
-// arrived; 2: the reverse); 0 = no s_setprio at all
-#ifndef XCX_PRIO_MODE
-#define XCX_PRIO_MODE 0
-#endif
-#if XCX_PRIO_MODE == 1
-#define XCX_PRIO_START() __builtin_amdgcn_s_setprio(3)
-#define XCX_PRIO_DATA() __builtin_amdgcn_s_setprio(0)
-#elif XCX_PRIO_MODE == 2
-#define XCX_PRIO_START() __builtin_amdgcn_s_setprio(0)
-#define XCX_PRIO_DATA() __builtin_amdgcn_s_setprio(3)
-#else
-#define XCX_PRIO_START() ((void)0)
-#define XCX_PRIO_DATA() ((void)0)
-#endif
 constexpr int kTR = 64;      // rows per T tile: T = [res >> 6][(res >> 4) & 3][k2 in 0..N2h][res & 15]: the four
                              // row waves of a workgroup own the four 16-row quarters of one tile, and a quarter
                              // ([k2][16 rows], 15.5 KB) is contiguous so that its wave streams it with 16-byte loads
@@ -98,9 +77,7 @@ constexpr int kWPB = 4;      // independent waves packed into one 256-thread wor
 // per-wave LDS footprints (floats), 16-byte aligned
 constexpr int lds_col_floats(int L) { return (L + (L >> 3) + 1 + 3) & ~3; }
 constexpr int lds_row_exch_floats(int L) { return ((L + (L >> 3) + 1) * 16 + 3) & ~3; }
-// ... or the transpose buffer of the wide T loads: up to 8 wave loads of 1 KB (64 k2 x 16 rows x 8 B)
-constexpr int lds_row_wide_floats(int L) { return ((L + 1 + 7) / 8 < 8 ? (L + 1 + 7) / 8 : 8) * 256; }
-constexpr int lds_row_floats(int L) { return lds_row_exch_floats(L) > lds_row_wide_floats(L) ? lds_row_exch_floats(L) : lds_row_wide_floats(L); }
+constexpr int lds_row_floats(int L) { return lds_row_exch_floats(L); }
 constexpr int lds_frow_floats(int L) { return L * 16 * 2; }
 // wave-uniform BY CONSTRUCTION: readfirstlane tells the compiler so, and everything derived from it
 // (work item, descriptor, column / tile base pointers) lives in SGPRs -- descriptor loads become
@@ -206,7 +183,6 @@ XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in
     }
   }
 #endif
-  XCX_PRIO_DATA();
   cf v1[G1::IT][R1];
   if constexpr (RX::S == 2) {
     stage_exchange_pad8<L, R0, 1, R1, kWNT, WIDE0>(ldsf, v0, v1, ltid);
@@ -433,7 +409,7 @@ struct WI1Args {
   Geom g;
 };
 
-// column body shared by k_wpair_cols and the fused kernel: pair-window
+// column body shared by the pair kernels (separate, dual, flow): pair-window
 // descriptor d, column k2, T slot base `T`
 // MODE 0: C = X_a conj X_b;  1: sum of that over nstack consecutive slots;
 // 2: C is read from a precomputed cross-spectrum (slot_a of the Gram buffer)
@@ -449,7 +425,6 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
   const unsigned kk = (unsigned)k2;
   const int shift = g.shift;
   using CG = ColGeom<RX>;
-  XCX_PRIO_START();
   // four-step factors w_N^{-(j0 + t*NSL) k2}: base per (lane, iteration) and
   // the wave-uniform step g = w_N^{-NSL k2}; powers by multiplication
   // last-stage slots rotated so that lane l holds the residues res = l (mod 64): every T store
@@ -470,25 +445,6 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
     f0[it] = twN_lookup(twN, (unsigned)((j - k) * CG::RL + k) * kk);
   }
   const cf gstep = twN_lookup(twN, (unsigned)CG::NSL * kk);
-#if defined(XCX_ABLATE_MATH) && defined(XCX_ABLATE_WIDE_X)
-  // bandwidth experiment (values are garbage in this build anyway): the same 2 x 12 KB of column
-  // data as 16-byte loads, two adjacent points per lane
-  int ncall = 0;
-  float4 wa = make_float4(0.f, 0.f, 0.f, 0.f), wb = wa;
-  auto in = [&](int, int) -> cf {
-    cf r;
-    if ((ncall & 1) == 0) {
-      const unsigned e = 2u * (unsigned)tid_of<kWNT>() + 128u * (unsigned)(ncall >> 1);
-      wa = *reinterpret_cast<const float4*>(uoff(A, e));
-      wb = *reinterpret_cast<const float4*>(uoff(Bp, e));
-      r = cmulc(make_float2(wa.x, wa.y), make_float2(wb.x, wb.y));
-    } else {
-      r = cmulc(make_float2(wa.z, wa.w), make_float2(wb.z, wb.w));
-    }
-    ++ncall;
-    return r;
-  };
-#else
   // Band-limited spectra (whitened plans, Geom::band_hi): column k2 is exactly zero for k1 in [za, zb],
   // i.e. where both k = k1 N2 + k2 and N - k lie above the band (60 % of a 0.1-10 Hz band at 50 Hz).
   // A wave instruction whose points ALL fall inside that range (kb .. kb + span - 1, kb = lane 0's point,
@@ -508,9 +464,6 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
     return uz ? base + (zev - kb) : base;
   };
   auto in = [=](int k1, int kb) -> cf {
-#ifdef XCX_SKIP_XLD
-    k1 &= 15;                                    // ablation: every load hits the same 128 bytes
-#endif
     if constexpr (MODE == 1) {
       cf acc = cmulc(*uoff(A, (unsigned)k1), *uoff(Bp, (unsigned)k1));
       for (int w = 1; w < nstack; ++w)
@@ -522,7 +475,6 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
       return cmulc(*uoff(zbase(A, kb, kWNT), (unsigned)k1), *uoff(zbase(Bp, kb, kWNT), (unsigned)k1));
     }
   };
-#endif
   cf* __restrict__ Tc = T + k2 * kWRB;
 #if XCX_TST_AUX >= 0
   // experiment: T stores as buffer stores with an explicit cache policy (aux: 2 = nt, 16 = sc1, 18 = both)
@@ -581,9 +533,6 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
         int tile = a0 + 2 * u + up;
         if (tile >= NT) tile -= NT;
         const unsigned o = (unsigned)tile * (unsigned)trow + roff(2 * (lane & 31));
-#ifdef XCX_SKIP_TST
-        if (N2h == -1)                             // ablation: never true at run time
-#endif
 #if XCX_TST_AUX >= 0
         {
           typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -604,9 +553,6 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
         if constexpr (CG::NSL % kTR == 0) {
           constexpr unsigned dstep = (unsigned)(CG::NSL / kTR);
           const unsigned o = off0 + (unsigned)t * dstep * (unsigned)trow - ((t >= twrap) ? wrapsz : 0u);
-#ifdef XCX_SKIP_TST
-          if (N2h == -1)
-#endif
           *uoff(Tc, o) = v[t];
         } else {
           int res = j0 + t * CG::NSL + shift;
@@ -661,24 +607,15 @@ void k_wpair_cols(WI1Args a) {
 // residues [16b, 16b+16): the T tile b, read exactly once.
 // ---------------------------------------------------------------------------
 struct WI2Args {
-  const cf* T; const PwDesc* pw; float* out; float* trash;
+  const cf* T; const PwDesc* pw; float* out;
   const cf* tw_sub;          // W_{N2h}
   const cf* tw_unt;          // W_{N2}[k]
   Geom g;
 };
 
 // T loads of the row body: plain, or sc1 (L1 bypass, served by the XCD's L2)
-// when the producer ran in the same launch on the same XCD (fused kernel)
+// when the producer ran in the same launch (flow kernel)
 template <bool SC1> XCX_DEV cf load_t(const cf* p) {
-#ifdef XCX_SKIP_TLD
-  p = reinterpret_cast<const cf*>(reinterpret_cast<unsigned long long>(p) & ~0xfffffULL);   // ablation: one hot line per MB
-#endif
-#ifdef XCX_T_NT_LOAD
-  if constexpr (!SC1) {
-    const unsigned long long u = __builtin_nontemporal_load(reinterpret_cast<const unsigned long long*>(p));
-    return make_float2(__uint_as_float((unsigned)u), __uint_as_float((unsigned)(u >> 32)));
-  }
-#endif
   if constexpr (SC1) {
     const unsigned long long u = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p),
                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -688,19 +625,10 @@ template <bool SC1> XCX_DEV cf load_t(const cf* p) {
   }
 }
 
-// row body shared by k_wpair_rows and the fused kernel: tile `Tt` (16 rows,
+// row body shared by the pair kernels: tile `Tt` (16 rows,
 // N2h+1 slots), output row `out`, block index blk
-#ifndef XCX_BUFSTORE
-#define XCX_BUFSTORE 1
-#endif
 #ifndef XCX_CCF_AUX
 #define XCX_CCF_AUX 2         // cache policy of the CCF stores: 2 = nt (streaming)
-#endif
-#ifndef XCX_ROW_PAIR
-#define XCX_ROW_PAIR 0        // 16-byte T loads by lane pairs + DPP swap in the row pass (experiment)
-#endif
-#ifndef XCX_ROW_WIDE
-#define XCX_ROW_WIDE 0        // 16-byte T loads + LDS transpose in the row pass (0: one 8-byte load per butterfly input)
 #endif
 // COOP: the four waves of the workgroup own the four quarters of ONE 64-row tile (blk = 4 wgblk +
 // wave) of one pair-window and store the CCF together: every wave parks its 16 x 2 N2h values in
@@ -710,9 +638,9 @@ template <bool SC1> XCX_DEV cf load_t(const cf* p) {
 // traffic mix (tools/micro/fabric2.hip) 4-byte segmented stores cap the pass at 1.12 M
 // pair-windows/s, 16-byte 256-byte runs at 1.57 M.  `stg` = workgroup-wide staging buffer
 // (lds_stage_floats(N2h) floats, may alias the waves' exchange buffers); contains __syncthreads().
-template <class RX, bool SC1, bool UNBIAS, bool COOP = false>
+template <class RX, bool SC1, bool UNBIAS>
 XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, float* __restrict__ out, int blk,
-                           const cf* __restrict__ tw_sub, const cf* __restrict__ twu, float* __restrict__ trash,
+                           const cf* __restrict__ tw_sub, const cf* __restrict__ twu,
                            float* __restrict__ stg, const Geom& g XCX_ST_PARAM) {
   constexpr int N2h = RX::L;
   constexpr int R = RX::R0;
@@ -723,7 +651,6 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
   const int N1 = g.N1, N = g.N, n = g.n;
   const int lane = tid_of<kWNT>();
   static_assert(RX::S == 2, "row configs have two stages");
-  XCX_PRIO_START();
   cf b1[StageGeom<N2h, RX::R1, RX::R0, kWRB, kWNT>::IT];
   stage_tw_base<N2h, RX::R1, RX::R0, kWRB, kWNT>(tw_sub, b1);
 
@@ -765,99 +692,7 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
 #pragma unroll
     for (int t = 0; t < R; ++t) { s0a[it][t] = uj[t]; s0b[it][t] = ujp[t]; }
   };
-  if constexpr (!SC1 && XCX_ROW_WIDE) {
-    // The quarter ([k2][16 rows], (N2h + 1) x 128 bytes, contiguous) streams in as 16-byte loads,
-    // 1 KB per wave instruction, and is transposed to the butterfly inputs through the wave's own
-    // LDS slice, 64 k2 (8 loads) at a time.  8-byte loads of 128-byte runs (one per butterfly
-    // input) cost the no-arithmetic build 8.5 of 80 ms more (profiles/r02_ablation.txt).
-    constexpr int NK = N2h + 1;
-    constexpr int NL = (NK + 7) / 8;               // wave loads
-    constexpr int NP = (NL + 7) / 8;               // LDS passes
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    f32x4 q[NL];
-    static_for<NL>([&](auto uc) {
-      constexpr int u = decltype(uc)::value;
-      unsigned e = (unsigned)(u * 128) + 2u * (unsigned)lane;
-      constexpr unsigned emax = (unsigned)(NK * kWRB - 2);
-      if constexpr (u * 128 + 126 > NK * kWRB - 2) e = e < emax ? e : emax;     // last load: stay inside the quarter
-      q[u] = *reinterpret_cast<const f32x4*>(uoff(Tt, e));
-    });
-    cf av[IT][R], bv[IT][R];
-    float ny[IT];
-    f32x4* __restrict__ ldsq = reinterpret_cast<f32x4*>(lds);
-    static_for<NP>([&](auto pc) {
-      constexpr int p = decltype(pc)::value;
-      static_for<(NL - p * 8 < 8 ? NL - p * 8 : 8)>([&](auto uc) {
-        constexpr int u = decltype(uc)::value;
-        ldsq[u * 64 + lane] = q[p * 8 + u];
-      });
-      group_sync<kWNT>();
-      static_for<IT>([&](auto ic) {
-        constexpr int it = decltype(ic)::value;
-        const int w = lane + it * kWNT;
-        if ((TOTAL % kWNT) == 0 || w < TOTAL) {
-          const int r = w % kWRB;
-          const int j = w / kWRB;                  // 0..S/2
-          const int jp = (j == 0) ? 0 : (S - j);
-          static_for<R>([&](auto tc) {
-            constexpr int t = decltype(tc)::value;
-            const int ka = j + S * t, kb = jp + S * t;
-            if ((ka >> 6) == p) av[it][t] = lds[(ka - 64 * p) * kWRB + r];
-            if (jp != j && (kb >> 6) == p) bv[it][t] = lds[(kb - 64 * p) * kWRB + r];
-          });
-          if constexpr ((N2h >> 6) == p) ny[it] = lds[(N2h - 64 * p) * kWRB + r].x;
-        }
-      });
-      group_sync<kWNT>();
-    });
-    XCX_STAMP(1, av[0][0].x);                      // T quarter has arrived
-    static_for<IT>([&](auto ic) {
-      constexpr int it = decltype(ic)::value;
-      const int w = lane + it * kWNT;
-      if ((TOTAL % kWNT) == 0 || w < TOTAL) {
-        const int j = w / kWRB;
-        const int jp = (j == 0) ? 0 : (S - j);
-        untangle(it, j, jp == j, av[it], bv[it], ny[it]);
-      }
-    });
-    XCX_STAMP(2, s0a[0][0].x);
-  } else if constexpr (!SC1 && XCX_ROW_PAIR && (TOTAL % kWNT) == 0) {
-    // Lane pairs (rows r, r+1 of one butterfly pair j): the even lane loads rows (r, r+1) of the
-    // inputs k2 = j + S t as 16 bytes, the odd lane the same rows of the mirror inputs k2 = S-j + S t;
-    // one DPP swap inside the pair hands every lane both input sets of ITS row.  Half the load
-    // instructions of the 8-byte form, no LDS.
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    const bool odd = lane & 1;
-    auto swp = [](float v) -> float {               // value of the partner lane (l ^ 1)
-      return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, false));
-    };
-#pragma unroll
-    for (int it = 0; it < IT; ++it) {
-      const int w = lane + it * kWNT;
-      const int r = w % kWRB;
-      const int j = w / kWRB;                       // 0..S/2
-      const int jp = (j == 0) ? 0 : (S - j);
-      const bool single = jp == j;
-      const unsigned base = (unsigned)((odd ? jp : j) * kWRB + (r & ~1));
-      cf av[R], bv[R];
-      f32x4 q[R];
-#pragma unroll
-      for (int t = 0; t < R; ++t) q[t] = *reinterpret_cast<const f32x4*>(uoff(Tt, base + (unsigned)(S * t * kWRB)));
-      float ny = 0.f;
-      if (j == 0) ny = load_t<SC1>(uoff(Tt, (unsigned)(N2h * kWRB + r))).x;
-#pragma unroll
-      for (int t = 0; t < R; ++t) {
-        // even lane: own = (A_r, A_r+1), needs B_r = partner's low half
-        // odd lane : own = (B_r-1, B_r), needs A_r = partner's high half
-        const float sx = odd ? q[t].x : q[t].z, sy = odd ? q[t].y : q[t].w;      // what the partner needs
-        const float rx = swp(sx), ry = swp(sy);
-        av[t] = odd ? make_float2(rx, ry) : make_float2(q[t].x, q[t].y);
-        bv[t] = odd ? make_float2(q[t].z, q[t].w) : make_float2(rx, ry);
-      }
-      untangle(it, j, single, av, bv, ny);
-    }
-    XCX_STAMP(2, s0a[0][0].x);
-  } else {
+  {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int w = lane + it * kWNT;
@@ -879,7 +714,6 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
     }
     XCX_STAMP(2, s0a[0][0].x);
   }
-  XCX_PRIO_DATA();
   float* __restrict__ ldsf = reinterpret_cast<float*>(lds);
   using G1 = StageGeom<N2h, RX::R1, RX::R0, kWRB, kWNT>;
   cf v1[G1::IT][RX::R1];
@@ -938,31 +772,19 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
   stage_compute<N2h, RX::R1, RX::R0, kWRB, kWNT, true>(v1, b1);
   XCX_STAMP(4, v1[G1::IT - 1][RX::R1 - 1].y);
   // ---- second stage + output ---------------------------------------------
-  // Branch-free stores: a lag outside [idx_min, idx_max) (the N-(2n-1) padding
-  // lags, or a clipped slice) is redirected to a per-lane trash word instead
-  // of masking the store, so the whole epilogue is one basic block.
   const int idx_min = g.idx_min;
   const unsigned Lout = (unsigned)(g.idx_max - g.idx_min);
   const int shift = g.shift;
-  int m1 = blk * kWRB + (lane & 15) - shift;
-  if (m1 < 0) m1 += N1;
-  const int base = m1 + (n - 1) - idx_min;        // output index of (m = 0, h = 0) before the wrap
-#if XCX_BUFSTORE
   // Buffer stores through a resource that spans exactly the retained lags of this output
   // row: the hardware range check drops every out-of-range lag (negative indices wrap to
   // huge unsigned offsets), so a store needs a 32-bit offset and no compare / select /
-  // 64-bit address arithmetic (10 -> 4 VALU instructions per stored lag).
-  (void)trash;
+  // 64-bit address arithmetic.
   const unsigned long long ob = reinterpret_cast<unsigned long long>(out);
   const unsigned ob_hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(ob >> 32));
   const unsigned ob_lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)ob);   // unsigned: no sign extension
   float* out_u = reinterpret_cast<float*>(((unsigned long long)ob_hi << 32) | (unsigned long long)ob_lo);
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(out_u, 0, (int)(Lout * 4u), 0x00020000);
-#else
-  float* __restrict__ trash_l = trash + lane;
-#endif
-#if XCX_BUFSTORE
-  if constexpr (COOP) {
+  {
     // Row res = 16 blk + c of the tile holds, for kk = 2 m + h, the lag o = res + N1 (kk + wr + q0)
     // (before the circular wrap), wr = 1 for the rows whose m1 + shift passed N1 (res < shift),
     // q0 = floor((n - 1 - idx_min) / N1).  Lag block s = kk + wr is therefore common to all 64 rows.
@@ -1010,9 +832,6 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
       for (int i = tid; i < (KH + 1) * (kTR / 4); i += kWNT * kWPB) {
         const int sl = i >> 4, gq = i & 15;
         const int s = sl + half * KH;
-#ifdef XCX_SKIP_CCF
-        if (n != -1) continue;                     // ablation: always true at run time
-#endif
         const float4 v = *reinterpret_cast<const float4*>(stg + sl * kTR + 4 * gq);
         const int r0 = res0 + 4 * gq;                          // residues r0 .. r0 + 3
         int o = r0 + N1 * (s + q0);
@@ -1036,68 +855,6 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
         }
       }
     }
-    XCX_STAMP_NW(7, v1[0][0].x);
-    XCX_STAMP(8, v1[0][0].x);
-    return;
-  }
-#endif
-  auto out_f = [=](int m, int, cf u) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int o = base + N1 * (2 * m + h);
-      if (o >= N - idx_min) o -= N;               // circular lag index
-      float v = h ? u.y : u.x;
-      if constexpr (UNBIAS) {
-        int lag = o + idx_min - (n - 1);
-        lag = lag < 0 ? -lag : lag;
-        v *= (float)n / (float)(n - lag);
-      }
-      // streaming (nt) stores: the CCFs are written once and never re-read, so they
-      // must not displace the T ring from L2 / the Infinity Cache (+8 % measured)
-#if XCX_BUFSTORE
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, o * 4, 0, /*nt*/ 2);
-#else
-      float* dst = ((unsigned)o < Lout) ? out + o : trash_l;
-      __builtin_nontemporal_store(v, dst);
-#endif
-    }
-  };
-#if XCX_BUFSTORE
-  // circular lag index in BYTES without a compare/select: x = 4 (base + N1 k) wraps to x - 4N once
-  // x >= 4 (N - idx_min).  min_u32(x, x - 4N) picks the wrapped value exactly when it is in range:
-  // below the wrap point x - 4N underflows to a huge offset (min = x); from 4N on x - 4N < x; in
-  // between (only when idx_min > 0) both candidates are >= 4 (N - idx_min) >= 4 Lout and the buffer
-  // range check drops the store, as it must (lag below idx_min).  Negative indices (idx_min > n-1)
-  // are huge either way.  One running byte offset per butterfly: 3 VALU instructions per lag.
-  const unsigned NB = 4u * (unsigned)N, N1b = 4u * (unsigned)N1;
-  const unsigned base4 = 4u * (unsigned)base;
-#endif
-#pragma unroll
-  for (int it = 0; it < G1::IT; ++it) {
-    const int b = lane + it * kWNT;
-    if (!G1::GUARD || b < G1::NBF) {
-      const int j = b / kWRB;
-      const int k = j % RX::R0;
-      const int j0 = (j - k) * RX::R1 + k;
-#if XCX_BUFSTORE
-      if constexpr (!UNBIAS) {
-        const unsigned mb = base4 + 2u * N1b * (unsigned)j0;
-#pragma unroll
-        for (int t = 0; t < RX::R1; ++t) {
-#pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const unsigned x = mb + N1b * (unsigned)(2 * t * RX::R0 + h);
-            const unsigned y = x - NB;
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h ? v1[it][t].y : v1[it][t].x), rsrc,
-                                                  (int)(x < y ? x : y), 0, /*nt*/ 2);
-          }
-        }
-        continue;
-      }
-#endif
-#pragma unroll
-      for (int t = 0; t < RX::R1; ++t) out_f(j0 + t * RX::R0, 0, v1[it][t]);
-    }
   }
   XCX_STAMP_NW(7, v1[0][0].x);                       // CCF stores issued
   XCX_STAMP(8, v1[0][0].x);                          // ... and acknowledged
@@ -1117,115 +874,9 @@ void k_wpair_rows(WI2Args a) {
   StampArr xst;
 #endif
   if (g.flags & XCX_F_UNBIAS)
-    pair_row_body<RX, false, true, true>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, a.trash, stg, g XCX_ST_ARG);
+    pair_row_body<RX, false, true>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, stg, g XCX_ST_ARG);
   else
-    pair_row_body<RX, false, false, true>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, a.trash, stg, g XCX_ST_ARG);
-}
-
-// ---------------------------------------------------------------------------
-// Fused pair kernel: both passes of a pair-window run on ONE XCD so that the
-// intermediate T (1.5 MB) lives in that XCD's 4 MiB L2 and never makes the
-// round trip through HBM.  Persistent single-wave workgroups read their XCD
-// id (HW_REG_XCC_ID) and pull tickets from that XCD's queue.  XCD x owns the
-// pair-windows pw with (pw >> 3) & 7 == x (the 8 pairs of a station-tile row:
-// they share a station, so its columns are re-read from the same L2); its
-// k-th pair-window is pw(k) = ((k >> 3) << 6) | (x << 3) | (k & 7).
-// Ticket order per XCD:   C(0) C(1) R(0) C(2) R(1) C(3) R(2) ...
-// (C = N2h+1 column waves, R = N1/16 row waves).  A wave only ever waits for
-// tickets drawn before its own (R(k) for C(k); C(k) for R(k-3), whose T ring
-// slot it overwrites), and every drawn ticket is held by a running wave, so
-// progress never depends on residency or placement.  Same-XCD visibility:
-// producers' plain stores land in the shared L2 (s_waitcnt vmcnt(0) before
-// the completion count), consumers read T with sc1 loads that bypass the
-// CU-private L1.  Every spin is bounded; a timeout raises *err.
-// ---------------------------------------------------------------------------
-struct WFusedArgs {
-  const cf* X; size_t spec_pitch;
-  const PwDesc* pw; int B; int nstack;
-  cf* Tring;                 // [8][3][N1*(N2h+1)]
-  float* out;
-  const cf* tw_N1; const cf* tw_N2h; const cf* tw_unt; const cf* tw_N;
-  int* ticket;               // [8][32]: one counter per 128-byte line
-  int* cdone; int* rdone;    // [B]
-  int* err; float* trash;
-  Geom g;
-};
-
-XCX_DEV void spin_until(const int* p, int target, int* err) {
-  for (int i = 0; i < 400000; ++i) {
-    if (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      return;
-    }
-    __builtin_amdgcn_s_sleep(16);
-  }
-  if (tid_of<kWNT>() == 0) *err = 1;
-}
-
-template <class RXC, class RXR, int MODE>
-__global__ __launch_bounds__(kWNT * kWPB) void k_wpair_fused(WFusedArgs a) {
-  extern __shared__ __attribute__((aligned(16))) cf lds_all[];
-  const Geom g = a.g;
-  constexpr int N1 = RXC::L;
-  constexpr int N2h = RXR::L;
-  constexpr int kPerWave = lds_col_floats(N1) > lds_row_floats(N2h) ? lds_col_floats(N1) : lds_row_floats(N2h);
-  cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave_in_group() * kPerWave);
-  constexpr int NC = N2h + 1;            // column tickets per pair-window
-  constexpr int NR = N1 / kWRB;          // row tickets per pair-window
-  unsigned xcc;
-  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-  const int x = (int)(xcc & 7u);
-  // pair-windows of this XCD
-  const int B = a.B;
-  int rem = (B & 63) - 8 * x;
-  rem = rem < 0 ? 0 : (rem > 8 ? 8 : rem);
-  const int M = (B >> 6) * 8 + rem;
-  if (M == 0) return;
-  const int total = M * (NC + NR);
-  const size_t tslot = (size_t)N1 * NC;
-  cf* __restrict__ Tx = a.Tring + (size_t)x * 3 * tslot;
-  int* tick = a.ticket + x * 32;
-#ifdef XCX_STAMPS
-  StampArr xst;
-#endif
-  for (;;) {
-    int t = 0;
-    if (tid_of<kWNT>() == 0) t = __hip_atomic_fetch_add(tick, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    t = __builtin_amdgcn_readfirstlane(t);
-    if (t >= total) break;
-    // decode: C(0) | [C(g+1) R(g)] for g = 0..M-2 | R(M-1)
-    bool is_col; int k, sub;
-    if (t < NC) { is_col = true; k = 0; sub = t; }
-    else {
-      const int tt = t - NC;
-      const int grp = tt / (NC + NR), r = tt % (NC + NR);
-      if (grp >= M - 1) { is_col = false; k = M - 1; sub = tt - (M - 1) * (NC + NR); }
-      else if (r < NC) { is_col = true; k = grp + 1; sub = r; }
-      else { is_col = false; k = grp; sub = r - NC; }
-    }
-    const int pw = ((k >> 3) << 6) | (x << 3) | (k & 7);
-    cf* __restrict__ T = Tx + (size_t)(k % 3) * tslot;
-    if (is_col) {
-      if (k >= 3) {
-        const int kp = k - 3;
-        spin_until(a.rdone + (((kp >> 3) << 6) | (x << 3) | (kp & 7)), NR, a.err);
-      }
-      pair_col_body<RXC, MODE>(lds, a.X, a.spec_pitch, a.pw[pw], a.nstack, sub, T, a.tw_N1, a.tw_N, g XCX_ST_ARG);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // T stores are in L2
-      if (tid_of<kWNT>() == 0) __hip_atomic_fetch_add(a.cdone + pw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      spin_until(a.cdone + pw, NC, a.err);
-      if (g.flags & XCX_F_UNBIAS)
-        pair_row_body<RXR, true, true>(lds, t_quarter(T, sub, N2h), a.out + a.pw[pw].out_off, sub,
-                                       a.tw_N2h, a.tw_unt, a.trash, nullptr, g XCX_ST_ARG);
-      else
-        pair_row_body<RXR, true, false>(lds, t_quarter(T, sub, N2h), a.out + a.pw[pw].out_off, sub,
-                                        a.tw_N2h, a.tw_unt, a.trash, nullptr, g XCX_ST_ARG);
-      // all T loads of this wave have returned (their values were consumed)
-      if (tid_of<kWNT>() == 0) __hip_atomic_fetch_add(a.rdone + pw, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    group_sync<kWNT>();
-  }
+    pair_row_body<RX, false, false>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, stg, g XCX_ST_ARG);
 }
 
 // ---------------------------------------------------------------------------
@@ -1238,7 +889,7 @@ __global__ __launch_bounds__(kWNT * kWPB) void k_wpair_fused(WFusedArgs a) {
 struct WDualArgs {
   const cf* X; size_t spec_pitch;
   const PwDesc* pw_c; int Bc; int nstack; cf* Tc;       // column pass: batch b
-  const PwDesc* pw_r; int Br; const cf* Tr; float* out; float* trash; // row pass: batch b-1
+  const PwDesc* pw_r; int Br; const cf* Tr; float* out;               // row pass: batch b-1
   const cf* tw_N1; const cf* tw_N2h; const cf* tw_unt; const cf* tw_N;
   Geom g;
 #ifdef XCX_STAMPS
@@ -1322,9 +973,9 @@ void k_wpair_dual(WDualArgs a) {
     const cf* __restrict__ Tt = t_quarter(a.Tr + (size_t)pwl * N1 * (N2h + 1), blk, N2h);
     float* stg = reinterpret_cast<float*>(lds_all);
     if (g.flags & XCX_F_UNBIAS)
-      pair_row_body<RXR, false, true, true>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, a.trash, stg, g XCX_ST_ARG);
+      pair_row_body<RXR, false, true>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG);
     else
-      pair_row_body<RXR, false, false, true>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, a.trash, stg, g XCX_ST_ARG);
+      pair_row_body<RXR, false, false>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG);
   }
 }
 
@@ -1362,16 +1013,12 @@ struct WFlowArgs {
   int R;                            // ring size in batches
   int nstack;
   cf* T;                            // [R][B][N1/16][N2h+1][16], uncached
-  float* out; float* trash;
+  float* out;
   int* cdone; int* rdone;           // [batches][8 shards][32 ints], zeroed before the launch
   int* err;
   const cf* tw_N1; const cf* tw_N2h; const cf* tw_unt; const cf* tw_N;
   Geom g;
   int lag;                          // rows of batch g-lag ride in group g (kFlowLag by default)
-  int local;                        // 1: XCD-local assignment -- pair-window pwl of a batch is processed entirely by
-                                    // the workgroups with blockIdx.x % 8 == pwl % 8 (B % 8 == 0), so its T stays in
-                                    // ONE XCD's L2 (sc1 loads are L2-served).  Only coherent with a cached T if those
-                                    // workgroups really share an XCD: experiment switch (XCX_FLOW_LOCAL)
 };
 
 // completion counters are sharded by the XCD label of the signalling wave (8 words, one 128-byte
@@ -1379,8 +1026,6 @@ struct WFlowArgs {
 // batch -- longer than the batch itself.  A waiter reads the 8 shards with one wave instruction.
 constexpr int kFlowShardInts = 32;                           // ints per shard (one cache line)
 constexpr int kFlowLag = 2;                                  // rows of batch g-2 ride in group g
-
-XCX_DEV int flow_npw_x(int Bc, int x) { return Bc > x ? (Bc - x + 7) / 8 : 0; }   // pair-windows pwl < Bc with pwl % 8 == x
 
 XCX_DEV bool flow_wait8(const int* shards, int target_lane, int* err) {
   const int lane = tid_of<kWNT>();
@@ -1428,14 +1073,13 @@ void k_wpair_flow(WFlowArgs a) {
     if (b >= nbatch) return;
     const int Bc = min(B, a.count - b * B);
     const int ci = (grp * PG::CWX + pos) * kWPB + wave;
-    int k2 = (ci / B) * 8 + x;
-    int pwl = ci % B;
-    if (a.local) { k2 = ci % (N2h + 1); pwl = (ci / (N2h + 1)) * 8 + x; }
+    const int k2 = (ci / B) * 8 + x;
+    const int pwl = ci % B;
     if (k2 > N2h || pwl >= Bc) return;
     if (b >= a.R) {                                           // ring slot consumed?
       const int bp = b - a.R;
       const int Bp = min(B, a.count - bp * B);
-      const int tgt = a.local ? ((lane == x) ? PG::NRW * kWPB * flow_npw_x(Bp, x) : 0) : nrx * Bp;
+      const int tgt = nrx * Bp;
       if (!flow_wait8(a.rdone + (size_t)bp * 8 * kFlowShardInts, tgt, a.err)) return;
     }
     cf* Tb = a.T + (size_t)(b % a.R) * B * N1 * (N2h + 1);
@@ -1449,22 +1093,21 @@ void k_wpair_flow(WFlowArgs a) {
     if (b < 0 || b >= nbatch) return;
     const int Br = min(B, a.count - b * B);
     const int ri = grp * PG::RWX + (pos - PG::CWX);
-    int pwl = ri / PG::RWX;
-    int wgblk = (ri % PG::RWX) * 8 + x;
-    if (a.local) { pwl = (ri / PG::NRW) * 8 + x; wgblk = ri % PG::NRW; }
+    const int pwl = ri / PG::RWX;
+    const int wgblk = (ri % PG::RWX) * 8 + x;
     if (wgblk >= PG::NRW || pwl >= Br) return;               // workgroup-uniform
     const int blk = wgblk * kWPB + wave;
     // a timed-out wait must not leave the workgroup's barriers one wave short: all four waves
     // poll the same counters and agree
-    const int ctgt = a.local ? ((lane == x) ? (N2h + 1) * flow_npw_x(Br, x) : 0) : ncx * Br;
+    const int ctgt = ncx * Br;
     if (!flow_wait8(a.cdone + (size_t)b * 8 * kFlowShardInts, ctgt, a.err)) return;
     const cf* __restrict__ Tt = t_quarter(a.T + ((size_t)(b % a.R) * B + pwl) * (size_t)N1 * (N2h + 1), blk, N2h);
     float* o = a.out + a.pw[b * B + pwl].out_off;
     float* stg = reinterpret_cast<float*>(lds_all);
     if (g.flags & XCX_F_UNBIAS)
-      pair_row_body<RXR, true, true, true>(lds, Tt, o, blk, a.tw_N2h, a.tw_unt, a.trash, stg, g XCX_ST_ARG);
+      pair_row_body<RXR, true, true>(lds, Tt, o, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG);
     else
-      pair_row_body<RXR, true, false, true>(lds, Tt, o, blk, a.tw_N2h, a.tw_unt, a.trash, stg, g XCX_ST_ARG);
+      pair_row_body<RXR, true, false>(lds, Tt, o, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG);
     // every T load of this wave has returned (the values were consumed by the stores above)
     if (lane == 0)
       __hip_atomic_fetch_add(a.rdone + ((size_t)b * 8 + x) * kFlowShardInts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -59,7 +59,7 @@ static const WColEntry kWCols[] = {XCX_WCOL_LIST(XCX_WCOL_ROW)};
 static const WRowEntry kWRows[] = {XCX_WROW_LIST(XCX_WROW_ROW)};
 static const int kNWCols = sizeof(kWCols) / sizeof(kWCols[0]);
 static const int kNWRows = sizeof(kWRows) / sizeof(kWRows[0]);
-#define XCX_WFUSED_ROW(C, R) {C, R, launch_wfused_##C##_##R, launch_wdual_##C##_##R, launch_wflow_##C##_##R},
+#define XCX_WFUSED_ROW(C, R) {C, R, launch_wdual_##C##_##R, launch_wflow_##C##_##R},
 static const WFusedEntry kWFused[] = {XCX_WFUSED_LIST(XCX_WFUSED_ROW)};
 static const int kNWFused = sizeof(kWFused) / sizeof(kWFused[0]);
 
@@ -263,7 +263,7 @@ extern "C" int xcx_host_alloc(xcx_ctx* ctx, size_t bytes, void** hptr) {
   return XCX_OK;
 }
 extern "C" int xcx_host_free(xcx_ctx* ctx, void* hptr) {
-  if (!ctx) return set_err(XCX_EINVAL, "null ctx");
+  (void)ctx;                       // may be null: a result array can outlive its context, hipHostFree needs none
   if (!hptr) return XCX_OK;
   HIP_TRY(hipHostFree(hptr));
   return XCX_OK;
@@ -362,12 +362,8 @@ struct xcx_plan {
   const WColEntry* wcol = nullptr;
   const WRowEntry* wrow = nullptr;
   bool wave = true;          // one-wave-per-workgroup engine (default)
-  const WFusedEntry* fused = nullptr;   // XCD-local fused pair kernel, if built for (N1, N2h)
-  DevBuf Tring, fsync;       // T ring [8][3][slot], ticket / completion counters
   DevBuf gramC, gramTiles, gramPidx;   // time-stack cross-spectra [P][spec_pitch], tile list, pair lookup
   bool gram = true;          // stack via the Gram kernel (XCX_GRAM=0: per-element loop)
-  DevBuf trash;              // 64 floats: sink of out-of-range lags (branch-free stores)
-  int fused_blocks = 0;
   const WFusedEntry* dual = nullptr;    // one-launch I2(b-1) + I1(b) kernel, if built for (N1, N2h)
   // windows too long for one transform (n + max|lag| beyond the planner's table, e.g. the reference's
   // production setting window_length = 86400 s, clip_lag = (0, 9 h): scripts/cc.py:25-29): the
@@ -394,7 +390,6 @@ struct xcx_plan {
   hipEvent_t prep_done = nullptr, pairs_done[2] = {nullptr, nullptr};
   bool prep_valid = false; unsigned long long pairs_count = 0;   // pair phases recorded in pairs_done[count & 1]
   const float* prep_traces = nullptr; int prep_S = 0, prep_W = 0; long prep_ss = 0, prep_sw = 0;
-  size_t fused_err_off = 0;  // index of the error flag inside fsync
 #ifdef XCX_STAMPS
   DevBuf stampbuf; size_t stamp_waves = 0;
 #endif
@@ -405,7 +400,6 @@ struct xcx_plan {
   // through ONE Gram update (the read-modify-write of the P x N/2 accumulator is amortised over them)
   int acc_pending = 0, acc_W = 0, acc_cap = 1, acc_grams = 0;
   int fwd_slot_w = 0, fwd_slot_ld = 0;               // forward(): station-major slot mapping (0: dense)
-  bool fused_ran = false;
   DevBuf psum, psq;          // partial statistics of a forward chunk
   int L = 0;                 // retained lags
   int batch = 512;           // pair-windows per launch batch
@@ -538,13 +532,6 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
   g.N2 = 2 * g.N2h;
   if (const char* ge = getenv("XCX_GRAM")) p->gram = strcmp(ge, "0") != 0;
   if (wave) {
-    if (p->trash.ensure(ctx, sizeof(float) * 64)) { delete p; return XCX_ENOMEM; }
-    // opt-in (XCX_FUSED=1): parity-green but not yet faster than the two-launch
-    // path -- waves that hold a row ticket spin while their columns finish
-    const char* fe = getenv("XCX_FUSED");
-    if (fe && strcmp(fe, "1") == 0)
-      for (int i = 0; i < kNWFused; ++i)
-        if (kWFused[i].N1 == g.N1 && kWFused[i].N2h == g.N2h) p->fused = &kWFused[i];
     const char* de = getenv("XCX_DUAL");
     if (!(de && strcmp(de, "0") == 0))
       for (int i = 0; i < kNWFused; ++i)
@@ -558,16 +545,13 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
     }
     if (!p->dual) p->nchains = 1;
     if (p->dual) {
-      // batch so that the whole T ring (chains x 2 buffers) is ~144 MB: it then stays
-      // in the 256 MiB Infinity Cache next to the spectra, and T traffic stops at the cache
+      // batch so that the whole T ring (chains x 2 buffers) is ~160 MB: it then stays
+      // in the 256 MiB Infinity Cache next to the spectra, and T traffic stops at the cache.
+      // (160 MB = 28 pair-windows at N = 368 640: the 28 pairs among 8 stations, pair_order.h)
       const size_t tm_bytes = sizeof(cf) * (size_t)g.N1 * (g.N2h + 1);
-      const size_t ring = (size_t)144 << 20;
+      static const size_t ring = (size_t)(getenv("XCX_RING_MB") ? std::max(16, atoi(getenv("XCX_RING_MB"))) : 160) << 20;
       p->batch = (int)std::max<size_t>(4, std::min<size_t>(512, ring / (2 * (size_t)p->nchains * tm_bytes)));
     }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess)
-      p->fused_blocks = prop.multiProcessorCount * 12;
-    else p->fused_blocks = 256 * 12;
   }
   g.idx_min = idx_min;
   g.idx_max = idx_max;
@@ -623,7 +607,7 @@ extern "C" int xcx_plan_destroy(xcx_plan* p) {
   }
   DevBuf* bufs[] = {&p->tw_N1, &p->tw_N2h, &p->tw_unt, &p->tw_N, &p->stats,
                     &p->Tm_f, &p->Tn_f, &p->spectra, &p->T, &p->descs,
-                    &p->dtraces, &p->dout, &p->dpairs, &p->psum, &p->psq, &p->Tring, &p->fsync, &p->trash, &p->gramC, &p->gramTiles, &p->gramPidx};
+                    &p->dtraces, &p->dout, &p->dpairs, &p->psum, &p->psq, &p->gramC, &p->gramTiles, &p->gramPidx};
   for (DevBuf* b : bufs) b->release();
   delete p;
   return XCX_OK;
@@ -852,7 +836,6 @@ static int pair_batch(xcx_plan* p, size_t d0, int B, float* out, int nstack, con
     r.T = (const cf*)p->T.ptr;
     r.pw = a.pw;
     r.out = out;
-    r.trash = (float*)p->trash.ptr;
     r.tw_sub = (const cf*)p->tw_N2h.ptr;
     r.tw_unt = (const cf*)p->tw_unt.ptr;
     r.g = g;
@@ -918,7 +901,6 @@ static int dual_launch(xcx_plan* p, int chain, size_t d0, int Bc, int nstack, fl
   a.Br = ch.B;
   a.Tr = Tbase + (size_t)ch.slot * tm_per * p->batch;
   a.out = out;
-  a.trash = (float*)p->trash.ptr;
   a.tw_N1 = (const cf*)p->tw_N1.ptr;
   a.tw_N2h = (const cf*)p->tw_N2h.ptr;
   a.tw_unt = (const cf*)p->tw_unt.ptr;
@@ -1009,11 +991,8 @@ static int flow_run(xcx_plan* p, size_t first, size_t count, int nstack, float* 
   const Geom& g = p->g;
   int rc;
   if ((rc = flow_check(ctx))) return rc;                     // a previous launch timed out?
-  // experiment (XCX_FLOW_LOCAL=1 with XCX_FLOW_T=plain): XCD-local pair-windows, batches of XCX_FLOW_B (multiple of 8)
-  static const bool local = getenv("XCX_FLOW_LOCAL") && atoi(getenv("XCX_FLOW_LOCAL")) != 0;
-  static const int localB = getenv("XCX_FLOW_B") ? std::max(8, atoi(getenv("XCX_FLOW_B")) / 8 * 8) : 8;
   static const int lag = getenv("XCX_FLOW_LAG") ? std::max(1, atoi(getenv("XCX_FLOW_LAG"))) : kFlowLag;
-  const int B = local ? localB : p->batch, R = std::max(p->flow_R, lag + 2);
+  const int B = p->batch, R = std::max(p->flow_R, lag + 2);
   const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
   const size_t tbytes = sizeof(cf) * tm_per * (size_t)B * R;
   if (ctx->flow_T_bytes < tbytes) {
@@ -1044,7 +1023,6 @@ static int flow_run(xcx_plan* p, size_t first, size_t count, int nstack, float* 
   a.nstack = nstack;
   a.T = (cf*)ctx->flow_T;
   a.out = out;
-  a.trash = (float*)p->trash.ptr;
   a.cdone = (int*)p->flow_sync.ptr;
   a.rdone = a.cdone + nsync;
   a.err = ctx->flow_err_dev;
@@ -1054,7 +1032,6 @@ static int flow_run(xcx_plan* p, size_t first, size_t count, int nstack, float* 
   a.tw_N = (const cf*)p->tw_N.ptr;
   a.g = g;
   a.lag = lag;
-  a.local = local ? 1 : 0;
   {
     ProfScope phase(p, KID_PAIR_PHASE, (int)count);
     ProfScope ps(p, KID_PAIR_FUSED, (int)count);
@@ -1069,62 +1046,11 @@ static int flow_run(xcx_plan* p, size_t first, size_t count, int nstack, float* 
   return XCX_OK;
 }
 
-// fused XCD-local pass over descriptors [d0, d0+B): one persistent launch
-static int pair_fused(xcx_plan* p, size_t d0, int B, float* out, int nstack) {
-  xcx_ctx* ctx = p->ctx;
-  const Geom& g = p->g;
-  const size_t tslot = (size_t)g.N1 * (g.N2h + 1);
-  int rc;
-  if ((rc = p->Tring.ensure(ctx, sizeof(cf) * tslot * 24))) return rc;
-  const size_t nsync = 8 * 32 + 2 * (size_t)B + 32;
-  if ((rc = p->fsync.ensure(ctx, sizeof(int) * nsync))) return rc;
-  HIP_TRY(hipMemsetAsync(p->fsync.ptr, 0, sizeof(int) * nsync, ctx->stream));
-  WFusedArgs a{};
-  a.X = (const cf*)p->spectra.ptr;
-  a.spec_pitch = p->spec_pitch;
-  a.pw = (const PwDesc*)p->descs.ptr + d0;
-  a.B = B;
-  a.nstack = nstack;
-  a.Tring = (cf*)p->Tring.ptr;
-  a.out = out;
-  a.tw_N1 = (const cf*)p->tw_N1.ptr;
-  a.tw_N2h = (const cf*)p->tw_N2h.ptr;
-  a.tw_unt = (const cf*)p->tw_unt.ptr;
-  a.tw_N = (const cf*)p->tw_N.ptr;
-  a.ticket = (int*)p->fsync.ptr;
-  a.cdone = a.ticket + 8 * 32;
-  a.rdone = a.cdone + B;
-  a.err = a.rdone + B;
-  a.trash = (float*)p->trash.ptr;
-  p->fused_err_off = 8 * 32 + 2 * (size_t)B;
-  a.g = g;
-  {
-    ProfScope ps(p, KID_PAIR_FUSED, B);
-    HIP_TRY(p->fused->run(a, p->fused_blocks, ctx->stream));
-  }
-  p->launches += 1;
-  p->pair_windows += B;
-  p->fused_ran = true;
-  return XCX_OK;
-}
-
-static int fused_check(xcx_plan* p) {
-  int err = 0;
-  if (!p->fsync.ptr || !p->fused_ran) return XCX_OK;
-  p->fused_ran = false;
-  HIP_TRY(hipMemcpyAsync(&err, (int*)p->fsync.ptr + p->fused_err_off, sizeof(int), hipMemcpyDeviceToHost,
-                         p->ctx->stream));
-  HIP_TRY(hipStreamSynchronize(p->ctx->stream));
-  if (err) return set_err(XCX_EHIP, "fused pair kernel: a producer/consumer wait timed out");
-  return XCX_OK;
-}
-
 static unsigned long long fnv(const void* data, size_t bytes, unsigned long long h) {
   const unsigned char* c = (const unsigned char*)data;
   for (size_t i = 0; i < bytes; ++i) { h ^= c[i]; h *= 1099511628211ULL; }
   return h;
 }
-
 
 // ---------------------------------------------------------------------------
 // Time-stack through the cross-spectrum ("Gram") buffer:
@@ -1282,6 +1208,15 @@ extern "C" int xcx_cc1d_stack_add(xcx_plan* p, const float* traces, int S, int W
   return XCX_OK;
 }
 
+extern "C" int xcx_cc1d_stack_reset(xcx_plan* p) {
+  if (!p) return set_err(XCX_EINVAL, "null plan");
+  // abandon an accumulation (a failed add, an exception in the driver loop): the plan takes
+  // xcx_cc1d_pairs / a new accumulation again; the accumulator is overwritten by the next first flush
+  if (p->ctx) (void)hipStreamSynchronize(p->ctx->stream);
+  p->acc_count = 0; p->acc_pending = 0; p->acc_grams = 0; p->acc_windows = 0; p->acc_key = 0;
+  return XCX_OK;
+}
+
 extern "C" int xcx_cc1d_stack_finish(xcx_plan* p, const int* pairs, int P, float* out, long ld_out,
                                      int on_device, long long* windows) {
   if (!p || !pairs || !out) return set_err(XCX_EINVAL, "null argument");
@@ -1384,7 +1319,7 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
     // stations per launch, so few first-touch spectrum fetches); otherwise 8 x 8 station tiles.
     static const bool grouped = !(getenv("XCX_GROUPS") && atoi(getenv("XCX_GROUPS")) == 0);
     p->bounds.clear();
-    if (grouped && p->dual && !p->flow && !p->fused) {
+    if (grouped && p->dual && !p->flow) {
       pair_groups(pairs, S, P, p->batch, perm, p->bounds);
     } else {
       for (int i = 0; i < P; ++i) perm[i] = i;
@@ -1438,9 +1373,7 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
       src = (const cf*)p->gramC.ptr;
       ns = -1;
     }
-    if (p->fused && ns > 0) {
-      if ((rc = pair_fused(p, 0, P, dout, ns))) return rc;
-    } else if (p->flow) {
+    if (p->flow) {
       if ((rc = flow_run(p, 0, (size_t)P, ns, dout, src))) return rc;
     } else if (p->dual) {
       if ((rc = dual_run(p, 0, (size_t)P, ns, dout, src, via_gram ? nullptr : &p->bounds))) return rc;
@@ -1458,10 +1391,7 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
       if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)S * W))) return rc;
       if ((rc = forward(p, dtr, stride_s, stride_w, W, 0, 0, S * W, 0))) return rc;
     }
-    if (p->fused) {
-      for (int w = 0; w < W; ++w)
-        if ((rc = pair_fused(p, (size_t)w * P, P, dout, 1))) return rc;
-    } else if (p->flow) {
+    if (p->flow) {
       if ((rc = flow_run(p, 0, ndesc, 1, dout))) return rc;
     } else if (p->dual) {
       if ((rc = dual_run(p, 0, ndesc, 1, dout, nullptr, &p->bounds))) return rc;
@@ -1474,9 +1404,7 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
     for (int w = 0; w < W; ++w) {
       // one window of every station: sw = s*1 + 0 with window index w
       if ((rc = forward(p, dtr, stride_s, stride_w, 1, w, 0, S, 0))) return rc;
-      if (p->fused) {
-        if ((rc = pair_fused(p, (size_t)w * P, P, dout, 1))) return rc;
-      } else if (p->flow) {
+      if (p->flow) {
         if ((rc = flow_run(p, (size_t)w * P, (size_t)P, 1, dout))) return rc;
       } else if (p->dual) {
         if ((rc = dual_run(p, (size_t)w * P, (size_t)P, 1, dout, nullptr, &p->bounds))) return rc;
@@ -1485,9 +1413,6 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
           if ((rc = pair_batch(p, (size_t)w * P + q0, (int)std::min((size_t)B, P - q0), dout, 1))) return rc;
       }
     }
-  }
-  if (p->fused && (!on_device || getenv("XCX_CHECK"))) {
-    if ((rc = fused_check(p))) return rc;
   }
   if (p->pairs_done[0]) {                             // a later xcx_cc1d_prepare must not overwrite these spectra early
     HIP_TRY(hipEventRecord(p->pairs_done[p->pairs_count & 1], ctx->stream));
@@ -1781,7 +1706,13 @@ static int seg_plan_create(xcx_ctx* ctx, int n, int idx_min, int idx_max, int fl
   if (!p->seg) { delete p; return set_err(XCX_ENOMEM, "host allocation failed"); }
   // block geometry on the tuned transform N' = 368 640 = Bk + 2 Kb (XCX_SEG_N overrides)
   long Np = 368640;
-  if (const char* e = getenv("XCX_SEG_N")) Np = atol(e);
+  if (const char* e = getenv("XCX_SEG_N")) {
+    Np = atol(e);
+    if (Np < 4096 || Np % 4 != 0) {
+      delete p;
+      return set_err(XCX_EINVAL, "XCX_SEG_N=%s: the block transform length must be a multiple of 4 and >= 4096", e);
+    }
+  }
   p->seg->Kb = (int)(Np / 4);
   p->seg->Bk = (int)(Np / 2);
   p->seg->npr = p->seg->Bk + p->seg->Kb;

@@ -104,6 +104,7 @@ class Context:
         self.device = int(device)
         self._children = weakref.WeakSet()      # plans and arrays that must go first
         self._pin_pool = {}                     # capacity -> [addresses] of idle page-locked blocks
+        self._pin_idle = 0                      # bytes held by those idle blocks
         self._plans = {}                        # (n, lag slice, flags) -> CCPlan kept for repeated driver calls
 
     def plan(self, n, index_min=0, index_max=None, **flags):
@@ -127,6 +128,7 @@ class Context:
                 for addr in blocks:
                     _ffi.lib().xcx_host_free(self.handle, C.c_void_p(addr))
             self._pin_pool = {}
+            self._pin_idle = 0
             _ffi.lib().xcx_destroy(self.handle)
             self.handle = None
 
@@ -150,33 +152,48 @@ class Context:
         return DeviceArray(self, a.shape, a.dtype).copy_from(a)
 
     # --- page-locked result arrays ------------------------------------------
+    PIN_MAX = 2 << 30          # larger results come back in ordinary (pageable) numpy memory
+    PIN_IDLE_MAX = 4 << 30     # idle page-locked bytes kept for reuse, per context
+    PIN_GRANULE = 2 << 20
+
     def pinned_empty(self, shape, dtype=np.float32):
         """numpy array in page-locked host memory (xcx_host_alloc): the library's D2H into it runs at
         PCIe speed.  Blocks are recycled through a small per-context pool when the array is
-        garbage-collected (page-locking 100 MB costs as much as copying it)."""
+        garbage-collected (page-locking 100 MB costs as much as copying it).
+
+        Page-locked memory cannot be swapped, so the pool is bounded: requests are rounded up to 2 MiB
+        (not to a power of two), results above PIN_MAX and requests the driver refuses fall back to
+        ``np.empty``, at most PIN_IDLE_MAX idle bytes (and 4 blocks per size) are kept, and a block
+        whose array outlives the context is still freed (hipHostFree needs no context)."""
         dtype = np.dtype(dtype)
         nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
-        cap = max(1 << 20, 1 << (max(nbytes, 1) - 1).bit_length())        # pool classes: powers of two
+        if nbytes > self.PIN_MAX or not self.handle:
+            return np.empty(shape, dtype)
+        g = self.PIN_GRANULE
+        cap = max(g, (nbytes + g - 1) // g * g)
         pool = self._pin_pool.setdefault(cap, [])
         if pool:
             addr = pool.pop()
+            self._pin_idle -= cap
         else:
             p = C.c_void_p()
-            check(_ffi.lib().xcx_host_alloc(self.handle, cap, C.byref(p)))
+            if _ffi.lib().xcx_host_alloc(self.handle, cap, C.byref(p)) != 0 or not p.value:
+                return np.empty(shape, dtype)            # driver refused (limits, fragmentation): pageable result
             addr = p.value
         buf = (C.c_char * nbytes).from_address(addr)
         arr = np.frombuffer(buf, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape)
         ctx_ref = weakref.ref(self)
+        idle_max = self.PIN_IDLE_MAX
 
         def _release(addr=addr, cap=cap):
             c = ctx_ref()
-            if c is None or not c.handle:
-                return
-            lst = c._pin_pool.setdefault(cap, [])
-            if len(lst) < 4 and cap <= (1 << 32):
-                lst.append(addr)
-            else:
-                _ffi.lib().xcx_host_free(c.handle, C.c_void_p(addr))
+            if c is not None and c.handle:
+                lst = c._pin_pool.setdefault(cap, [])
+                if len(lst) < 4 and c._pin_idle + cap <= idle_max:
+                    lst.append(addr)
+                    c._pin_idle += cap
+                    return
+            _ffi.lib().xcx_host_free(c.handle if c is not None and c.handle else None, C.c_void_p(addr))
         weakref.finalize(buf, _release)
         return arr
 
@@ -200,6 +217,12 @@ class Context:
 
     def comm_init(self, uid, nranks, rank):
         check(_ffi.lib().xcx_comm_init(self.handle, uid, nranks, rank))
+
+    def comm_info(self):
+        """(nranks, rank) as RCCL reports them for this context's communicator."""
+        n, r = C.c_int(0), C.c_int(0)
+        check(_ffi.lib().xcx_comm_info(self.handle, C.byref(n), C.byref(r)))
+        return n.value, r.value
 
     def stack_reduce(self, stack, count=None, reduce_scatter=False):
         n = int(count if count is not None else np.prod(stack.shape))
@@ -371,6 +394,10 @@ class CCPlan:
             traces = np.ascontiguousarray(traces, dtype=np.float32)
         check(_ffi.lib().xcx_cc1d_stack_add(self.handle, ptr(traces), S, int(W), int(stride_s),
                                             int(stride_w), ptr(pairs), len(pairs), int(on_dev)))
+
+    def stack_reset(self):
+        """Abandon an open accumulation (xcx_cc1d_stack_reset): call it from the error path of a driver loop."""
+        check(_ffi.lib().xcx_cc1d_stack_reset(self.handle))
 
     def stack_finish(self, pairs, out=None, ld_out=0):
         """Inverse-transform the accumulated cross-spectra -> (out [P, L], windows summed)."""

@@ -41,10 +41,25 @@ def ncfile(pair, time, root=None):
     return os.path.join(base, '{p}.{y:04d}.{d:03d}.nc'.format(p=pair, y=t.year, d=t.timetuple().tm_yday))
 
 
+# The digest lives under its OWN attribute name: the reference's ``sha256_hash`` is ``hash_Dataset`` over
+# metadata and every variable of a NetCDF-4 file (xcorr/io/write.py:88-137) -- a different scheme over a
+# different container, so reusing the name would make each side reject the other's files as corrupt.
+HASH_ATTR = 'xcorr_amd_sha256'
+
+
 def _data_hash(ds):
+    """sha256 over every variable and coordinate of the dataset (native byte order, C order)."""
     h = hashlib.sha256()
-    h.update(np.ascontiguousarray(ds.cc).view(np.uint8))
-    h.update(np.ascontiguousarray(ds.status).view(np.uint8))
+    h.update('\x00'.join(ds.pair).encode())
+    for name in ('time', 'lag', 'cc', 'status', 'pair_offset', 'time_offset'):
+        a = np.ascontiguousarray(getattr(ds, name))
+        h.update(name.encode())
+        h.update(a.astype(a.dtype.newbyteorder('=')).view(np.uint8))
+    if getattr(ds, 'hash', None) is not None:
+        h.update(b'hash')
+        for row in ds.hash:
+            for v in row:
+                h.update(str(v).ljust(64)[:64].encode())
     return h.hexdigest()
 
 
@@ -129,7 +144,7 @@ def write(data, path, close=True, force_write=False, hash_data=True, verb=0):
             nc.Conventions = 'CF-1.9'
             nc.xcorr_amd_format = 'NetCDF-3 64-bit offset; layout of xcorr/core/init.py:237-320'
             if hash_data:
-                nc.sha256_hash = _data_hash(data)
+                setattr(nc, HASH_ATTR, _data_hash(data))
         os.replace(tmp, path)
     except BaseException:
         if os.path.exists(tmp):
@@ -189,7 +204,7 @@ def read(path, fast=False, quick_and_dirty=False, extract=False):
         ds.time_is_datetime = attrs(tv).get('units') == _EPOCH
         ds.pair_attrs = attrs(nc.variables['pair'])
         ga = attrs(nc)
-        stored = ga.pop('sha256_hash', None)
+        stored = ga.pop(HASH_ATTR, None)
         ds.attrs = ga
     if stored is not None and not quick_and_dirty and stored != _data_hash(ds):
         raise ValueError(f'{path}: data sha256 hash does not match the stored one')
@@ -250,7 +265,7 @@ def merge(*datasets, extract=False, quick_and_dirty=False):
             out.time_offset[row, cols] = d.time_offset[ip, take]
             if out.hash is not None and getattr(d, 'hash', None) is not None:
                 out.hash[row, cols] = d.hash[ip, take]
-    out.attrs = {k: v for k, v in first.attrs.items() if k != 'sha256_hash'}
+    out.attrs = {k: v for k, v in first.attrs.items() if k != HASH_ATTR}
     t0, t1 = _utc(times[0]), _utc(times[-1])
     s0, s1 = t0.strftime('%Y.%j'), t1.strftime('%Y.%j')
     title = str(out.attrs.get('title', '')).split(' - ')[0]

@@ -17,27 +17,97 @@ __all__ = ['FileRendezvous', 'from_env']
 
 
 class FileRendezvous:
+    """Rounds of small files in one directory.
+
+    The directory name is predictable (launcher pid + port) and may survive a crashed run or be
+    reused by the next launch from the same shell, so nothing in it is trusted by name alone:
+    rank 0 draws a fresh session nonce S and hands it to the others through a join / ack / in
+    handshake, and every later file carries S in its name.
+
+      rank r > 0 : publish  join_<r>_<own nonce>   (re-published while waiting: rank 0 may wipe stale files)
+                   wait for ack_<r>_<own nonce>    (content = S)
+                   publish  in_<S>_<r>
+      rank 0     : wipe the directory, then acknowledge every join file it sees (stale ones too:
+                   nobody reads those acks) until in_<S>_<r> exists for every r -- S is fresh, so
+                   an in_ file can only come from a rank of THIS launch.
+
+    close(): every rank's last action is bye_<S>_<r>; rank 0 waits for all of them (bounded) and
+    then removes the directory, so no rank can still be polling a file that disappears.
+    """
+
     def __init__(self, rank, world, key, root=None, timeout=600.0):
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
         root = root or os.environ.get('XCX_RDZV_DIR') or '/tmp'
         self.dir = os.path.join(root, f'xcx_rdzv_{key}')
-        os.makedirs(self.dir, exist_ok=True)
+        os.makedirs(self.dir, mode=0o700, exist_ok=True)
+        try:
+            os.chmod(self.dir, 0o700)
+        except OSError:
+            pass
         self.seq = 0
+        self.session = self._handshake()
+
+    def _path(self, name):
+        return os.path.join(self.dir, name)
+
+    def _handshake(self):
+        t0 = time.monotonic()
+
+        def expired():
+            if time.monotonic() - t0 > self.timeout:
+                raise TimeoutError(f'rendezvous: rank {self.rank} could not join {self.dir} within {self.timeout:.0f} s')
+
+        if self.rank == 0:
+            for f in os.listdir(self.dir):                   # leftovers of an earlier run
+                try:
+                    os.unlink(self._path(f))
+                except OSError:
+                    pass
+            S = os.urandom(8).hex()
+            acked = set()
+            while True:
+                for f in os.listdir(self.dir):
+                    if f.startswith('join_') and f not in acked:
+                        self._publish('ack_' + f[5:], S.encode())
+                        acked.add(f)
+                if all(os.path.exists(self._path(f'in_{S}_{r}')) for r in range(1, self.world)):
+                    return S
+                expired()
+                time.sleep(1e-3)
+        mine = f'{self.rank}_{os.urandom(8).hex()}'
+        while True:
+            if not os.path.exists(self._path('join_' + mine)):
+                try:
+                    self._publish('join_' + mine)
+                except OSError:                              # rank 0's wipe took the temporary file: try again
+                    pass
+            try:
+                with open(self._path('ack_' + mine), 'rb') as fh:
+                    S = fh.read().decode()
+                if S:
+                    break
+            except OSError:
+                pass
+            expired()
+            time.sleep(1e-3)
+        self._publish(f'in_{S}_{self.rank}')
+        return S
 
     # every collective is one "round": each rank publishes one file, then reads what it needs
     def _publish(self, name, payload=b''):
-        tmp = os.path.join(self.dir, f'.{name}.{self.rank}.tmp')
+        tmp = self._path(f'.{name}.{self.rank}.tmp')
         with open(tmp, 'wb') as fh:
             fh.write(payload)
-        os.replace(tmp, os.path.join(self.dir, name))        # atomic: readers never see a partial file
+        os.replace(tmp, self._path(name))                    # atomic: readers never see a partial file
 
-    def _wait(self, name):
-        path = os.path.join(self.dir, name)
+    def _wait(self, name, timeout=None):
+        path = self._path(name)
+        timeout = self.timeout if timeout is None else timeout
         t0 = time.monotonic()
         nap = 2e-4
         while not os.path.exists(path):
-            if time.monotonic() - t0 > self.timeout:
-                raise TimeoutError(f'rendezvous: rank {self.rank} waited {self.timeout:.0f} s for {name} in {self.dir}')
+            if time.monotonic() - t0 > timeout:
+                raise TimeoutError(f'rendezvous: rank {self.rank} waited {timeout:.0f} s for {name} in {self.dir}')
             time.sleep(nap)
             nap = min(nap * 1.5, 5e-3)
         with open(path, 'rb') as fh:
@@ -46,8 +116,8 @@ class FileRendezvous:
     def allgather(self, payload=b''):
         k = self.seq
         self.seq += 1
-        self._publish(f'r{k}_{self.rank}', payload)
-        return [self._wait(f'r{k}_{r}') for r in range(self.world)]
+        self._publish(f'{self.session}_r{k}_{self.rank}', payload)
+        return [self._wait(f'{self.session}_r{k}_{r}') for r in range(self.world)]
 
     def barrier(self):
         self.allgather()
@@ -59,19 +129,20 @@ class FileRendezvous:
         k = self.seq
         self.seq += 1
         if self.rank == src:
-            self._publish(f'b{k}', payload)
+            self._publish(f'{self.session}_b{k}', payload)
             return payload
-        return self._wait(f'b{k}')
+        return self._wait(f'{self.session}_b{k}')
 
     def close(self):
-        """Leave; the last rank out removes the directory."""
+        """Leave.  A rank's last action is its bye file; rank 0 removes the directory once it has every rank's."""
         try:
-            self.allgather()
+            self._publish(f'bye_{self.session}_{self.rank}')
             if self.rank == 0:
-                time.sleep(0.05)
+                for r in range(1, self.world):
+                    self._wait(f'bye_{self.session}_{r}', timeout=min(self.timeout, 60.0))
                 for f in os.listdir(self.dir):
                     try:
-                        os.unlink(os.path.join(self.dir, f))
+                        os.unlink(self._path(f))
                     except OSError:
                         pass
                 os.rmdir(self.dir)
