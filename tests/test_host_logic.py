@@ -423,3 +423,43 @@ def test_container_methods_mirror_the_dataset_accessor(tmp_path):
     m = ds.merge(path)
     assert np.array_equal(m.status, ds.status) and m.attrs['history'].startswith('Merged @')
     assert callable(ds.process) and callable(ds.postprocess)
+
+
+class _FakeVar:
+    """Just enough of an xarray.DataArray for CCDataset.from_xarray / update_xarray (values + attrs)."""
+
+    def __init__(self, values, attrs=None):
+        self.values = np.asarray(values)
+        self.attrs = dict(attrs or {})
+
+
+class _FakeXrDataset(dict):
+    attrs = {}
+
+
+def test_ccdataset_xarray_conversion_on_a_duck_typed_dataset():
+    """``from_xarray`` reads exactly the names xcorr/core/init.py:153-320 lays out and ``update_xarray`` writes
+    the processed variables back in place.  xarray itself is not installable here: this exercises
+    the conversion logic on an object with the same attribute surface, not xarray."""
+    import importlib
+    cinit = importlib.import_module('xcorr_amd.core.init')
+    ds0 = cinit.init('AA.S1..HHZ-AA.S2..HHZ', 0., 7200., sampling_rate=50., window_length=3600., window_overlap=0.5,
+                     clip_lag=(-10., 10.), hash_waveforms=True)
+    x = _FakeXrDataset()
+    x.attrs = dict(ds0.attrs)
+    x['pair'] = _FakeVar(ds0.pair, {'units': '-'})
+    x['time'] = _FakeVar((ds0.time * 1e9).astype('datetime64[ns]'), ds0.time_attrs)
+    x['lag'] = _FakeVar(ds0.lag, {**ds0.lag_attrs, 'npts': np.int64(ds0.lag_attrs['npts'])})
+    x['cc'] = _FakeVar(ds0.cc.copy(), ds0.cc_attrs)
+    for k in ('status', 'pair_offset', 'time_offset', 'hash'):
+        x[k] = _FakeVar(getattr(ds0, k).copy())
+    back = cinit.CCDataset.from_xarray(x)
+    assert back.time_is_datetime and np.allclose(back.time, ds0.time)
+    assert list(back.pair) == list(ds0.pair) and back.lag_attrs['npts'] == ds0.lag_attrs['npts']
+    assert isinstance(back.lag_attrs['npts'], int) and back.cc.shape == ds0.cc.shape and back.hash is not None
+    back.cc[...] = 1.5
+    back.status[...] = 1
+    back.hash[...] = 'h'
+    back.update_xarray(x)
+    assert (x['cc'].values == 1.5).all() and (x['status'].values == 1).all() and (x['hash'].values == 'h').all()
+    assert not cinit.is_xarray_dataset(x)            # the real type check needs the real xarray

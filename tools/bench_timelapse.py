@@ -16,6 +16,45 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def _cpu_worker(args):
+    """one tile pair through the oracle's restatement of signal/correlate.py:230-246 (float64 numpy, padded to
+    exactly (2F-1) x (2L-1) like the reference), peak value + position as scripts/timelapse.py:255-267 keeps them"""
+    seed, F, L, reps = args
+    for v in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS'):
+        os.environ[v] = '1'
+    from oracle import ref_numpy as R
+    rng = np.random.default_rng(seed)
+    a = np.square(rng.standard_normal((F, L))).astype(np.float32)
+    b = np.square(rng.standard_normal((F, L))).astype(np.float32)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        cc = R.correlate2d(a, b, normalize=True)
+        np.unravel_index(int(np.argmax(cc)), cc.shape)
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(F, L, reps=2):
+    import multiprocessing as mp
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            cores = max(1, min(cores, -(-int(q) // int(per))))
+    except (OSError, ValueError):
+        pass
+    cores = int(os.environ.get('XCX_CPU_CORES', cores))
+    with mp.get_context('spawn').Pool(cores) as pool:
+        t0 = time.perf_counter()
+        pool.map(_cpu_worker, [(50 + i, F, L, reps) for i in range(cores)])
+        wall = time.perf_counter() - t0
+    return {'value': cores * reps / wall, 'unit': 'tile-pairs/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{cores * reps} tile pairs {F}x{L} ({reps} per core) of oracle.ref_numpy.correlate2d '
+                      f'(float64, fft2 at {2 * F - 1}x{2 * L - 1}) + argmax in {wall:.1f} s'}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -23,6 +62,7 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--from-ccf', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
     a = ap.parse_args()
     rank = int(os.environ.get('RANK', '0')); world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
@@ -58,15 +98,32 @@ def main():
         run()
     rdzv.barrier()
     ctx.sync(); t0 = time.perf_counter()
+    ctx.timer_start()                          # HIP events on the stream the kernels are launched on
     for _ in range(a.steps):
         peak, idx = run()
+    ev_ms = ctx.timer_stop()
     ctx.sync()
     rdzv.barrier()
     dt = rdzv.max(time.perf_counter() - t0)
     if rank == 0:
         ms = dt / a.steps * 1e3
-        # algorithmic bytes per pair: 2 spectra in + intermediate out/in = 67 MB
+        # Per tile pair: the pair-dependent work is ONE inverse 2-D transform of the product
+        # spectrum at the padded size P1 x P2 = 512 x 8192 (Hermitian half: 512 x 4097 complex) --
+        #   k2d_cols<inv>: reads two spectra (2 x 16.8 MB), multiplies, 4097 column IFFTs of 512, writes 16.8 MB
+        #   k2d_rows_inv : reads 16.8 MB, 512 C2R row transforms of 8192, arg-max (no store)
+        # algorithmic bytes 67.1 MB; flops 5 N log2 N of the real 2-D transform = 2.5 * P1 * P2 * log2(P1 * P2).
+        P1, P2 = 512, 8192
+        bytes_pair = 4 * (P1 * (P2 // 2 + 1) * 8)
+        flop_pair = 2.5 * P1 * P2 * np.log2(P1 * P2) + 6.0 * P1 * (P2 // 2 + 1)
+        us_pair = ev_ms * 1e3 / (a.steps * max(len(pairs), 1))              # includes the per-step tile transforms (3 %)
+        roof = {'bound': 'hbm', 'achieved': bytes_pair / us_pair * 1e-3, 'peak': 8000.0, 'unit': 'GB/s',
+                'frac': bytes_pair / us_pair * 1e-3 / 8000.0, 'traffic': None,
+                'kernel': 'k2d_cols<inv> + k2d_rows_inv (one inverse 2-D transform per tile pair)',
+                'us_per_tile_pair': us_pair, 'algorithmic_bytes_per_tile_pair': bytes_pair,
+                'gflops': flop_pair / us_pair * 1e-3, 'frac_of_fp32_peak': flop_pair / us_pair * 1e-3 / 157300.0}
+        cpu = None if a.no_cpu_baseline else cpu_baseline(F, L)
         print(json.dumps({
+            'roofline': roof, 'cpu_baseline': cpu,
             'metric': 'tile-pairs/s', 'value': len(allp) * a.steps / dt, 'unit': 'tile-pairs/s', 'n_gpus': world,
             'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': ms, 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',

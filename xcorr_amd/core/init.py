@@ -11,7 +11,7 @@ import numpy as np
 
 from ..util import cc as ucc
 
-__all__ = ['init', 'CCDataset']
+__all__ = ['init', 'CCDataset', 'is_xarray_dataset']
 
 
 class CCDataset:
@@ -53,12 +53,18 @@ class CCDataset:
         return merge(self, *others, **kwargs)
 
     def to_xarray(self):
+        """The container as the reference's ``xarray.Dataset`` (variable, coordinate and attribute names of
+        xcorr/core/init.py:153-320).  NOTE: xarray is not installable in this project's build and test
+        images, so neither this method nor :meth:`from_xarray` has ever executed there; both are
+        written against the reference's layout and against xarray's documented API only."""
         import xarray as xr
         ds = xr.Dataset()
         ds.coords['pair'] = self.pair
         ds.coords['time'] = (self.time * 1e9).astype('datetime64[ns]') if getattr(self, 'time_is_datetime', False) \
             else self.time
         ds.coords['lag'] = ('lag', self.lag, self.lag_attrs)
+        ds['time'].attrs = dict(self.time_attrs)
+        ds['pair'].attrs = dict(getattr(self, 'pair_attrs', {}))
         ds['cc'] = (('pair', 'time', 'lag'), self.cc, self.cc_attrs)
         ds['status'] = (('pair', 'time'), self.status)
         ds['pair_offset'] = (('pair', 'time'), self.pair_offset)
@@ -67,6 +73,54 @@ class CCDataset:
             ds['hash'] = (('pair', 'time'), self.hash)
         ds.attrs = dict(self.attrs)
         return ds
+
+    @classmethod
+    def from_xarray(cls, ds):
+        """A :class:`CCDataset` holding the data of a reference-style ``xarray.Dataset`` (the output of
+        ``xcorr.init`` / ``xcorr.read``: core/init.py:153-320).  Only duck-typed attribute access is used
+        (``ds.pair.values``, ``ds.lag.attrs`` ...), so any object with that shape converts.  See the note in
+        :meth:`to_xarray`: not executed in any environment available to this project."""
+        t = np.asarray(ds['time'].values)
+        is_dt = np.issubdtype(t.dtype, np.datetime64)
+        time = t.astype('datetime64[ns]').astype(np.int64) * 1e-9 if is_dt else t.astype(np.float64)
+        la = dict(ds['lag'].attrs)
+        for k in ('npts', 'index_min', 'index_max'):
+            la[k] = int(la[k])
+        for k in ('sampling_rate', 'delta'):
+            la[k] = float(la[k])
+        ta = dict(ds['time'].attrs)
+        cc = np.asarray(ds['cc'].values)
+        out = cls([str(p) for p in np.asarray(ds['pair'].values).reshape(-1)], time, np.asarray(ds['lag'].values, np.float64),
+                  la, dict(ds['cc'].attrs), ta, dtype=cc.dtype, hash_waveforms='hash' in ds)
+        out.time_is_datetime = bool(is_dt)
+        out.pair_attrs = dict(ds['pair'].attrs)
+        out.cc[...] = cc
+        out.status[...] = np.asarray(ds['status'].values)
+        out.pair_offset[...] = np.asarray(ds['pair_offset'].values)
+        out.time_offset[...] = np.asarray(ds['time_offset'].values)
+        if out.hash is not None:
+            out.hash[...] = np.asarray(ds['hash'].values)
+        out.attrs = dict(ds.attrs)
+        return out
+
+    def update_xarray(self, ds):
+        """Write the processed variables back into `ds` in place (what ``xcorr.process`` does to its
+        argument, core/process.py:82-165): cc, status, offsets, hashes and the ``unbiased`` flag."""
+        ds['cc'].values[...] = self.cc
+        ds['cc'].attrs.update(self.cc_attrs)
+        ds['status'].values[...] = self.status
+        ds['pair_offset'].values[...] = self.pair_offset
+        ds['time_offset'].values[...] = self.time_offset
+        if self.hash is not None and 'hash' in ds:
+            ds['hash'].values[...] = self.hash
+        return ds
+
+
+def is_xarray_dataset(obj):
+    """True for an ``xarray.Dataset`` (without importing xarray when it is absent)."""
+    import sys
+    xr = sys.modules.get('xarray')
+    return xr is not None and isinstance(obj, xr.Dataset)
 
 
 def _seconds(t):

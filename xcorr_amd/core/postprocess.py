@@ -58,6 +58,10 @@ def postprocess(ds, lag_lim=None, lag_min=None, lag_max=None, filter_kwargs=None
     (their cc is zero-filled here, status kept), the lag axis is cut to
     [lag_min, lag_max], and -- like the reference's rfft-based timeshift -- an
     odd number of lags loses its last sample."""
+    from .init import is_xarray_dataset
+    if is_xarray_dataset(ds):            # the reference's argument type (core/postprocess.py:21): convert in, convert out
+        return postprocess(CCDataset.from_xarray(ds), lag_lim=lag_lim, lag_min=lag_min, lag_max=lag_max,
+                           filter_kwargs=filter_kwargs, ctx=ctx).to_xarray()
     if 'postprocess' in ds.cc_attrs:
         return ds
     if lag_lim is not None:

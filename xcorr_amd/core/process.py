@@ -33,7 +33,8 @@ def process(dataset, client, inventory=None, retry_missing=False,
             ctx=None, **kwargs):
     """Process the container in place and return it.
 
-    dataset : :class:`xcorr_amd.core.CCDataset` (see ``init``)
+    dataset : :class:`xcorr_amd.core.CCDataset` (see ``init``) or, where xarray is installed, the
+        reference's ``xarray.Dataset`` (converted with ``CCDataset.from_xarray`` and updated in place)
     client  : object with ``get_pair_processed_waveforms(pair, time, duration,
         ...)`` returning two (data, starttime_seconds) items or None
         (stream/client.py:1116-1149; :class:`ArrayClient` here).
@@ -43,6 +44,14 @@ def process(dataset, client, inventory=None, retry_missing=False,
         rebuilt from the pair string, the start times and the sampling rate).
     """
     from ..util import hasher
+    from .init import CCDataset, is_xarray_dataset
+    if is_xarray_dataset(dataset):
+        # the reference's calling convention (core/process.py:23-30): an xarray.Dataset from xcorr.init /
+        # xcorr.read, processed IN PLACE and returned -- converted in, run, written back
+        work = CCDataset.from_xarray(dataset)
+        process(work, client, inventory=inventory, retry_missing=retry_missing, test_run=test_run,
+                hash_waveforms=hash_waveforms, metadata_hash=metadata_hash, verb=verb, ctx=ctx, **kwargs)
+        return work.update_xarray(dataset)
     hash_waveforms = hash_waveforms and getattr(dataset, 'hash', None) is not None
     la = dataset.lag_attrs
     npts, imin, imax = la['npts'], la['index_min'], la['index_max']

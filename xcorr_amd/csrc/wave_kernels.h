@@ -16,10 +16,10 @@
 // Layouts (all chosen so that every global access of a wave instruction is a
 // run of full 128-byte lines):
 //   Tf / X : [k2 in 0..N2h][N1]        column-major, Nyquist = column N2h
-//   T      : [res >> 6][(res >> 4) & 3][k2 in 0..N2h][res & 15]   64-row tiles of
-//            four contiguous 16-row quarters, where res = (m1 + shift) mod N1 is
+//   T      : [res / 128][k2 in 0..N2h][res % 128]   where res = (m1 + shift) mod N1 is
 //            the OUTPUT residue of row m1 (slots k2 = 0 and N2h are real: only
-//            .x is consumed); a row wave owns one quarter
+//            .x is consumed); a column wave stores 1 KB runs, a row wave (16 rows)
+//            reads 128-byte runs
 //
 // The C2R row kernel reads each T element exactly once: butterflies j and
 // S-j of its first stage are computed by the same lane, which therefore holds
@@ -68,9 +68,13 @@ XCX_DEV unsigned long long stamp_nowait(float pin) {
 #define XCX_ROW_WAVES 1
 #endif
 constexpr int kWRB = 16;     // rows per wave
-constexpr int kTR = 64;      // rows per T tile: T = [res >> 6][(res >> 4) & 3][k2 in 0..N2h][res & 15]: the four
-                             // row waves of a workgroup own the four 16-row quarters of one tile, and a quarter
-                             // ([k2][16 rows], 15.5 KB) is contiguous so that its wave streams it with 16-byte loads
+constexpr int kTR = 64;      // rows per row workgroup (cooperative CCF store): four waves x 16 rows
+// T layout of one pair-window: [res / TC][k2 in 0..N2h][res % TC], res = output residue of row m1,
+// TC = 128 rows (64 when N1 is not a multiple of 128).  A column wave (one k2) stores 16 bytes per lane
+// = two adjacent rows: lanes 0..31 cover one 64-row half of a chunk, lanes 32..63 the next -- one
+// contiguous 1 KB run per store instruction when they share a chunk, two 512-byte runs otherwise.
+// A row wave reads, per k2, the 128 bytes of its 16 rows (1 KB apart from one k2 to the next).
+constexpr int t_chunk(int N1) { return (N1 % 128 == 0) ? 128 : 64; }
 constexpr int kWNT = 64;     // one wave
 constexpr int kWPB = 4;      // independent waves packed into one 256-thread workgroup
 
@@ -85,9 +89,13 @@ constexpr int lds_frow_floats(int L) { return L * 16 * 2; }
 // per-lane 64-bit addresses
 XCX_DEV int wave_in_group() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
-// the 16-row quarter `blk & 3` of T tile `blk >> 2` of one pair-window: [k2][16 rows], contiguous
-XCX_DEV const cf* t_quarter(const cf* __restrict__ Tpw, int blk, int N2h) {
-  return Tpw + (size_t)((blk >> 2) * (N2h + 1)) * kTR + (size_t)(blk & 3) * (N2h + 1) * kWRB;
+// element offset of residue `res` inside a pair-window's T for k2 = 0 (add k2 * TC)
+XCX_DEV unsigned t_off(int res, int TC, int N2h) {
+  return (unsigned)((res / TC) * ((N2h + 1) * TC) + (res % TC));
+}
+// first element (k2 = 0, row 0) of the 16 rows `blk` of one pair-window; k2 advances by TC elements
+XCX_DEV const cf* t_rows16(const cf* __restrict__ Tpw, int blk, int N2h, int TC) {
+  return Tpw + t_off(blk * kWRB, TC, N2h);
 }
 // staging buffer of the workgroup-cooperative CCF store: (N2h + 1) lag blocks x 64 rows of float
 constexpr int lds_stage_floats(int N2h) { return (N2h + 1) * kTR; }
@@ -475,29 +483,18 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
       return cmulc(*uoff(zbase(A, kb, kWNT), (unsigned)k1), *uoff(zbase(Bp, kb, kWNT), (unsigned)k1));
     }
   };
-  cf* __restrict__ Tc = T + k2 * kWRB;
+  constexpr int TC = t_chunk(N1);
+  cf* __restrict__ Tc = T + k2 * TC;
 #if XCX_TST_AUX >= 0
   // experiment: T stores as buffer stores with an explicit cache policy (aux: 2 = nt, 16 = sc1, 18 = both)
   const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(Tc, 0, 0x7fffffff, 0x00020000);
 #endif
-  const int trow = (N2h + 1) * kTR;           // float2 per 64-row tile
-  const int qrow = (N2h + 1) * kWRB;          // float2 per 16-row quarter
-  auto roff = [=](int r64) -> unsigned {      // row r64 of a tile (this wave's k2): quarter, row inside it
-    return (unsigned)((r64 >> 4) * qrow + (r64 & 15));
-  };
-  // Pair stores (round 2): every lane ends up with two adjacent rows of one tile and stores 16 bytes;
-  // a wave instruction writes lanes 0..31 to one tile and lanes 32..63 to the next, in lane order,
-  // as eight full 128-byte lines.  Measured neutral against 8-byte stores (the write side of this
-  // pass is not what limits it, profiles/r02_ablation.txt); kept because it halves the store
-  // instructions of the column wave.
+  const int crow = (N2h + 1) * TC;            // float2 per chunk of TC rows
+  // Pair stores: every lane ends up with two adjacent rows and stores 16 bytes; lanes 0..31 cover one
+  // 64-row half chunk, lanes 32..63 the next one, in lane order.
   auto epi = [=](int it, int j0, int, cf (&v)[CG::RL]) {
     cf g8 = gstep, f = f0[it];
     if constexpr (CG::RL > 8) g8 = csq(csq(csq(gstep)));
-    int res0 = j0 + shift;
-    if (res0 >= N1) res0 -= N1;
-    const unsigned off0 = (unsigned)((res0 >> 6) * trow) + roff(res0 & 63);
-    const int twrap = (N1 - res0 + CG::NSL - 1) / CG::NSL;            // first t whose residue wraps
-    const unsigned wrapsz = (unsigned)(N1 / kTR) * (unsigned)trow;
     static_for<CG::RL>([&](auto tc) {                                 // four-step factors, in place
       constexpr int t = decltype(tc)::value;
       if constexpr (t > 0) {
@@ -532,7 +529,8 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
         const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(w[2 * u].y), __float_as_uint(w[2 * u + 1].y), false, false);
         int tile = a0 + 2 * u + up;
         if (tile >= NT) tile -= NT;
-        const unsigned o = (unsigned)tile * (unsigned)trow + roff(2 * (lane & 31));
+        const unsigned o = (TC == 128) ? (unsigned)(tile >> 1) * (unsigned)crow + (unsigned)((tile & 1) * 64 + 2 * (lane & 31))
+                                       : (unsigned)tile * (unsigned)crow + (unsigned)(2 * (lane & 31));
 #if XCX_TST_AUX >= 0
         {
           typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -544,21 +542,12 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
             make_float4(__uint_as_float(sx[0]), __uint_as_float(sy[0]), __uint_as_float(sx[1]), __uint_as_float(sy[1]));
 #endif
       });
-      (void)off0; (void)twrap; (void)wrapsz;
     } else {
       static_for<CG::RL>([&](auto tc) {
         constexpr int t = decltype(tc)::value;
-        // res = (j0 + shift + t NSL) mod N1; with NSL a multiple of 64 the tile offset advances by a
-        // constant per t and wraps once: offset = off0 + t dstep - (t >= twrap ? wrapsz : 0)
-        if constexpr (CG::NSL % kTR == 0) {
-          constexpr unsigned dstep = (unsigned)(CG::NSL / kTR);
-          const unsigned o = off0 + (unsigned)t * dstep * (unsigned)trow - ((t >= twrap) ? wrapsz : 0u);
-          *uoff(Tc, o) = v[t];
-        } else {
-          int res = j0 + t * CG::NSL + shift;
-          if (res >= N1) res -= N1;
-          *uoff(Tc, (unsigned)((res >> 6) * trow) + roff(res & 63)) = v[t];
-        }
+        int res = j0 + t * CG::NSL + shift;
+        if (res >= N1) res -= N1;
+        *uoff(Tc, t_off(res, TC, N2h)) = v[t];
       });
     }
   };
@@ -638,7 +627,8 @@ template <bool SC1> XCX_DEV cf load_t(const cf* p) {
 // traffic mix (tools/micro/fabric2.hip) 4-byte segmented stores cap the pass at 1.12 M
 // pair-windows/s, 16-byte 256-byte runs at 1.57 M.  `stg` = workgroup-wide staging buffer
 // (lds_stage_floats(N2h) floats, may alias the waves' exchange buffers); contains __syncthreads().
-template <class RX, bool SC1, bool UNBIAS>
+// TCT: T chunk rows (t_chunk(N1)) when N1 is known at compile time, 0 = from g.N1
+template <class RX, bool SC1, bool UNBIAS, int TCT = 0>
 XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, float* __restrict__ out, int blk,
                            const cf* __restrict__ tw_sub, const cf* __restrict__ twu,
                            float* __restrict__ stg, const Geom& g XCX_ST_PARAM) {
@@ -649,6 +639,7 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
   constexpr int TOTAL = NITEM * kWRB;
   constexpr int IT = (TOTAL + kWNT - 1) / kWNT;
   const int N1 = g.N1, N = g.N, n = g.n;
+  const int TC = TCT ? TCT : t_chunk(N1);          // elements from one k2 to the next
   const int lane = tid_of<kWNT>();
   static_assert(RX::S == 2, "row configs have two stages");
   cf b1[StageGeom<N2h, RX::R1, RX::R0, kWRB, kWNT>::IT];
@@ -703,13 +694,13 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
       const bool single = jp == j;
       cf av[R], bv[R];
 #pragma unroll
-      for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(uoff(Tt, (unsigned)((j + S * t) * kWRB + r)));
+      for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(uoff(Tt, (unsigned)((j + S * t) * TC + r)));
       if (!single) {
 #pragma unroll
-        for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(uoff(Tt, (unsigned)((jp + S * t) * kWRB + r)));
+        for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(uoff(Tt, (unsigned)((jp + S * t) * TC + r)));
       }
       float ny = 0.f;
-      if (j == 0) ny = load_t<SC1>(uoff(Tt, (unsigned)(N2h * kWRB + r))).x;
+      if (j == 0) ny = load_t<SC1>(uoff(Tt, (unsigned)(N2h * TC + r))).x;
       untangle(it, j, single, av, bv, ny);
     }
     XCX_STAMP(2, s0a[0][0].x);
@@ -868,7 +859,7 @@ void k_wpair_rows(WI2Args a) {
   cf* __restrict__ lds = reinterpret_cast<cf*>(reinterpret_cast<float*>(lds_all) + wave_in_group() * lds_row_floats(RX::L));
   // the four waves of a workgroup = the four quarters of one 64-row tile (cooperative CCF store)
   const int pwl = blockIdx.y, blk = blockIdx.x * kWPB + wave_in_group();
-  const cf* __restrict__ Tt = t_quarter(a.T + (size_t)pwl * g.N1 * (RX::L + 1), blk, RX::L);
+  const cf* __restrict__ Tt = t_rows16(a.T + (size_t)pwl * g.N1 * (RX::L + 1), blk, RX::L, t_chunk(g.N1));
   float* stg = reinterpret_cast<float*>(lds_all);
 #ifdef XCX_STAMPS
   StampArr xst;
@@ -970,12 +961,12 @@ void k_wpair_dual(WDualArgs a) {
     const int wgblk = (ri % PG::RWX) * 8 + x;
     if (wgblk >= PG::NRW || pwl >= a.Br) return;             // workgroup-uniform
     const int blk = wgblk * kWPB + wave;
-    const cf* __restrict__ Tt = t_quarter(a.Tr + (size_t)pwl * N1 * (N2h + 1), blk, N2h);
+    const cf* __restrict__ Tt = t_rows16(a.Tr + (size_t)pwl * N1 * (N2h + 1), blk, N2h, t_chunk(N1));
     float* stg = reinterpret_cast<float*>(lds_all);
     if (g.flags & XCX_F_UNBIAS)
-      pair_row_body<RXR, false, true>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG);
+      pair_row_body<RXR, false, true, t_chunk(N1)>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG);
     else
-      pair_row_body<RXR, false, false>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG);
+      pair_row_body<RXR, false, false, t_chunk(N1)>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG);
   }
 }
 
@@ -1101,13 +1092,13 @@ void k_wpair_flow(WFlowArgs a) {
     // poll the same counters and agree
     const int ctgt = ncx * Br;
     if (!flow_wait8(a.cdone + (size_t)b * 8 * kFlowShardInts, ctgt, a.err)) return;
-    const cf* __restrict__ Tt = t_quarter(a.T + ((size_t)(b % a.R) * B + pwl) * (size_t)N1 * (N2h + 1), blk, N2h);
+    const cf* __restrict__ Tt = t_rows16(a.T + ((size_t)(b % a.R) * B + pwl) * (size_t)N1 * (N2h + 1), blk, N2h, t_chunk(N1));
     float* o = a.out + a.pw[b * B + pwl].out_off;
     float* stg = reinterpret_cast<float*>(lds_all);
     if (g.flags & XCX_F_UNBIAS)
-      pair_row_body<RXR, true, true>(lds, Tt, o, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG);
+      pair_row_body<RXR, true, true, t_chunk(N1)>(lds, Tt, o, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG);
     else
-      pair_row_body<RXR, true, false>(lds, Tt, o, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG);
+      pair_row_body<RXR, true, false, t_chunk(N1)>(lds, Tt, o, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG);
     // every T load of this wave has returned (the values were consumed by the stores above)
     if (lane == 0)
       __hip_atomic_fetch_add(a.rdone + ((size_t)b * 8 + x) * kFlowShardInts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -39,6 +39,7 @@ class DeviceArray:
         v.nbytes = 0
         v.ptr = self.ptr + int(col0) * self.dtype.itemsize
         v._owner = self                      # keeps the allocation alive; the view frees nothing
+        v._pitch = getattr(self, '_pitch', self.shape[1] * self.dtype.itemsize)    # bytes from row to row
         return v
 
     def free(self):
@@ -82,7 +83,9 @@ class DeviceArray:
 
     def rows_to_host(self, row0, nrows, width):
         """Copy rows [row0, row0+nrows) of a 2-D buffer, first `width` cols."""
-        pitch = self.shape[-1] * self.dtype.itemsize
+        pitch = getattr(self, '_pitch', self.shape[-1] * self.dtype.itemsize)       # a column view keeps its owner's pitch
+        if width > self.shape[-1] or row0 < 0 or row0 + nrows > self.shape[0]:
+            raise ValueError('rows_to_host: rows / width outside the buffer')
         out = np.empty((nrows, width), dtype=self.dtype)
         check(_ffi.lib().xcx_memcpy2d_d2h(
             self.ctx.handle, ptr(out), width * self.dtype.itemsize,
