@@ -189,6 +189,10 @@ int xcx_detrend_linear(xcx_ctx* ctx, float* x, long batch, long n,
  * original that has to stay (raw traces, re-processed with other settings) needs no copy
  * first.  linear: 0 = subtract the mean, 1 = subtract the least-squares line. */
 int xcx_detrend_to(xcx_ctx* ctx, const float* src, float* dst, long batch, long n, int linear);
+/* The same, writing only columns [col0, col1) of dst: the mean / trend are those of the WHOLE row
+ * (window-sharded front end: a rank needs the preprocessed samples of its window block only). */
+int xcx_detrend_to_cols(xcx_ctx* ctx, const float* src, float* dst, long batch, long n, int linear,
+                        long col0, long col1);
 int xcx_taper(xcx_ctx* ctx, float* x, long batch, long n, long nmax,
               int wtype, int on_device);
 int xcx_unbias(xcx_ctx* ctx, float* x, long batch, long npts, long idx_min,
@@ -218,6 +222,15 @@ int xcx_sosfiltfilt(xcx_ctx* ctx, float* x, long batch, long n,
                     const double* sos, int n_sections, int on_device);
 int xcx_sosfilt(xcx_ctx* ctx, float* x, long batch, long n, const double* sos,
                 int n_sections, int on_device);
+/* Columns [col0, col1) of xcx_sosfilt on device rows [batch][n], without filtering the whole row: the
+ * recursion starts from rest `warm` samples before col0, where warm (xcx_sosfilt_warmup) is the
+ * smallest multiple of 1024 with ||A^warm||_inf <= 2^-64 (A = the cascade's zero-input transition):
+ * the start state at col0 then equals the from-rest state to below float64 rounding.  Columns
+ * [*first_col, col0) are overwritten with intermediate values; columns outside [*first_col, col1)
+ * are untouched.  warm < 0 (not stable) or warm >= col0: the row is filtered from its start. */
+int xcx_sosfilt_warmup(const double* sos, int n_sections, long* warm);
+int xcx_sosfilt_cols(xcx_ctx* ctx, float* x, long batch, long n, const double* sos, int n_sections,
+                     long col0, long col1, long* first_col);
 /* ObsPy Trace.filter(..., zerophase=True) (xcorr/stream/process.py:279-282 ->
  * obspy.signal.filter): sosfilt from rest, then sosfilt of the reversed result
  * from rest, reversed back.  No padding and no steady-state start values, so it

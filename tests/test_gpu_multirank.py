@@ -123,3 +123,74 @@ def test_window_blocks_over_rank_processes(tmp_path):
     got = np.concatenate([np.load(tmp_path / f'block_{r}.npy') for r in range(world)], axis=1)
     assert got.shape == ref.shape == (15, W, 2 * n - 1)
     assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-5
+
+
+_RANK_WINDOWS_PRE = r'''
+import os, sys, numpy as np
+sys.path.insert(0, {root!r})
+import ctypes as C
+import xcorr_amd as X
+from xcorr_amd import _ffi, workload
+from xcorr_amd.rendezvous import FileRendezvous
+from xcorr_amd.synth import synthetic_traces
+rank, world, key, rdir = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+rd = FileRendezvous(rank, world, key, root=rdir, timeout=120)
+nd = C.c_int(0)
+_ffi.check(_ffi.lib().xcx_device_count(C.byref(nd)))
+ctx = X.Context(rank % max(nd.value, 1))
+S, n, hop, W = 5, 30000, 15000, 12
+T = hop * (W - 1) + n
+raw = synthetic_traces(S, T, day=3)
+pairs = np.array([(i, j) for i in range(S) for j in range(i + 1, S)], np.int32)
+w0, w1 = (W * rank) // world, (W * (rank + 1)) // world        # bench.py --shard windows
+sd = workload.StationDay(ctx, S, T, n, hop, pairs, w_first=w0, W=w1 - w0).load(raw)
+sd.step()
+sd.step()
+ctx.sync()
+blk = sd.out.rows_to_host(0, sd.nrows, sd.L).reshape(len(pairs), w1 - w0, sd.L)
+np.save(os.path.join(rdir, f'pre_block_{{rank}}.npy'), blk)
+np.save(os.path.join(rdir, f'pre_rows_{{rank}}.npy'), sd.work.rows_to_host(0, S, T)[:, w0 * hop:(w1 - 1) * hop + n])
+open(os.path.join(rdir, f'pre_warm_{{rank}}.txt'), 'w').write(str(sd.warm))
+rd.barrier()
+'''
+
+
+def test_window_blocks_with_the_preprocess_chain(ctx, tmp_path):
+    """--shard windows with the config-3 front end: a rank demeans with the mean of the WHOLE day but
+    tapers / band-passes only its own block of windows plus the filter's warm-up (xcx_sosfilt_cols), so
+    the replicated part of an N-rank step is one read of the day, not the whole front end.  The blocks of
+    three rank processes must reproduce the single-process station-day: the preprocessed samples to the
+    rounding noise of the float64 recursion, the CCFs to 1e-5 (one-bit sign flips counted)."""
+    import subprocess
+    from xcorr_amd import workload
+    from xcorr_amd.synth import synthetic_traces
+    world = 3
+    script = tmp_path / 'rank_p.py'
+    script.write_text(_RANK_WINDOWS_PRE.format(root=ROOT))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), str(world), 'winp', str(tmp_path)], env=env)
+             for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    S, n, hop, W = 5, 30000, 15000, 12
+    T = hop * (W - 1) + n
+    raw = synthetic_traces(S, T, day=3)
+    pairs = np.array([(i, j) for i in range(S) for j in range(i + 1, S)], np.int32)
+    sd = workload.StationDay(ctx, S, T, n, hop, pairs).load(raw)
+    sd.step()
+    ctx.sync()
+    ref = sd.out.rows_to_host(0, sd.nrows, sd.L).reshape(len(pairs), W, sd.L)
+    ref_rows = sd.work.rows_to_host(0, S, T)
+    sd.close()
+    warm = int((tmp_path / 'pre_warm_1.txt').read_text())
+    assert 0 < warm < (W // world) * hop                     # the later blocks really start from a warm-up, not from 0
+    flips = 0
+    for r in range(world):
+        w0, w1 = (W * r) // world, (W * (r + 1)) // world
+        rows = np.load(tmp_path / f'pre_rows_{r}.npy')
+        want = ref_rows[:, w0 * hop:(w1 - 1) * hop + n]
+        assert np.abs(rows - want).max() <= 2e-7 * np.abs(want).max()          # isolated last-bit differences at most
+        flips += int(np.count_nonzero(np.sign(rows) != np.sign(want)))
+    got = np.concatenate([np.load(tmp_path / f'pre_block_{r}.npy') for r in range(world)], axis=1)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 1e-5 + 5e-4 * flips

@@ -68,6 +68,7 @@ SIGNATURES = {
     'xcx_demean': [_vp, _vp, _l, _l, _i],
     'xcx_detrend_linear': [_vp, _vp, _l, _l, _i],
     'xcx_detrend_to': [_vp, _vp, _vp, _l, _l, _i],
+    'xcx_detrend_to_cols': [_vp, _vp, _vp, _l, _l, _i, _l, _l],
     'xcx_taper': [_vp, _vp, _l, _l, _l, _i, _i],
     'xcx_unbias': [_vp, _vp, _l, _l, _l, _l, _i],
     'xcx_onebit': [_vp, _vp, _l, _l, _i],
@@ -76,6 +77,8 @@ SIGNATURES = {
     'xcx_post_prep': [_vp, _vp, _l, _l, _l, _l, _i, _l, _i, _i],
     'xcx_sosfiltfilt': [_vp, _vp, _l, _l, _vp, _i, _i],
     'xcx_sosfilt': [_vp, _vp, _l, _l, _vp, _i, _i],
+    'xcx_sosfilt_warmup': [_vp, _i, C.POINTER(_l)],
+    'xcx_sosfilt_cols': [_vp, _vp, _l, _l, _vp, _i, _l, _l, C.POINTER(_l)],
     'xcx_sosfilt_zerophase': [_vp, _vp, _l, _l, _vp, _i, _i],
     'xcx_snr': [_vp, _vp, _l, _l, _vp, _vp, _vp, _vp, _vp, _i],
     'xcx_timeshift': [_vp, _vp, _vp, _l, _l, _vp, C.c_double, _i],

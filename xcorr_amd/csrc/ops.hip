@@ -104,13 +104,15 @@ __global__ __launch_bounds__(NT) void k_row_partial(const float* __restrict__ x,
 }
 
 // src -> dst (dst may be src): out of place the separate copy of an untouched original is saved
+// [c0, c1): the columns written (the statistics are always those of the whole row)
 template <int OP>
-__global__ __launch_bounds__(NT) void k_row_apply(const float* src, float* dst, long n, const double* __restrict__ part) {
+__global__ __launch_bounds__(NT) void k_row_apply(const float* src, float* dst, long n, const double* __restrict__ part,
+                                                  long c0, long c1) {
   const float* rin = src + (size_t)blockIdx.y * n;
   float* row = dst + (size_t)blockIdx.y * n;
   const int tid = threadIdx.x;
-  const long per = (n + kParts - 1) / kParts;
-  const long lo = blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+  const long per = (c1 - c0 + kParts - 1) / kParts;
+  const long lo = c0 + blockIdx.x * per, hi = (lo + per < c1) ? lo + per : c1;
   double s0 = 0.0, s1 = 0.0;
   for (int p = 0; p < kParts; ++p) {
     s0 += part[((size_t)blockIdx.y * kParts + p) * 2];
@@ -344,7 +346,7 @@ template <int OP> int row_op(xcx_ctx* ctx, float* x, long batch, long n, int on_
     if ((rc = ctx->scratch[0].ensure(ctx, sizeof(double) * 2 * kParts * (size_t)batch))) return rc;
     double* part = (double*)ctx->scratch[0].ptr;
     hipLaunchKernelGGL(k_row_partial<OP>, dim3(kParts, (unsigned)batch), dim3(NT), 0, ctx->stream, st.dev, n, part);
-    hipLaunchKernelGGL(k_row_apply<OP>, dim3(kParts, (unsigned)batch), dim3(NT), 0, ctx->stream, (const float*)st.dev, st.dev, n, part);
+    hipLaunchKernelGGL(k_row_apply<OP>, dim3(kParts, (unsigned)batch), dim3(NT), 0, ctx->stream, (const float*)st.dev, st.dev, n, part, 0L, n);
     HIP_TRY(hipGetLastError());
     return st.end();
   }
@@ -354,16 +356,18 @@ template <int OP> int row_op(xcx_ctx* ctx, float* x, long batch, long n, int on_
 }
 
 // device rows src -> dst; the source stays untouched
-template <int OP> int row_op_to(xcx_ctx* ctx, const float* src, float* dst, long batch, long n) {
+template <int OP> int row_op_to(xcx_ctx* ctx, const float* src, float* dst, long batch, long n, long c0 = 0, long c1 = -1) {
   if (!ctx || !src || !dst) return set_err(XCX_EINVAL, "null argument");
   if (batch < 1 || n < 1) return set_err(XCX_EINVAL, "batch and n must be >= 1");
+  if (c1 < 0) c1 = n;
+  if (c0 < 0 || c1 > n || c0 >= c1) return set_err(XCX_EINVAL, "bad column range [%ld, %ld) of %ld", c0, c1, n);
   HIP_TRY(hipSetDevice(ctx->device));
   int rc;
-  if (batch < 1024 && n >= 65536) {
+  if ((batch < 1024 && n >= 65536) || c0 != 0 || c1 != n) {
     if ((rc = ctx->scratch[0].ensure(ctx, sizeof(double) * 2 * kParts * (size_t)batch))) return rc;
     double* part = (double*)ctx->scratch[0].ptr;
     hipLaunchKernelGGL(k_row_partial<OP>, dim3(kParts, (unsigned)batch), dim3(NT), 0, ctx->stream, src, n, part);
-    hipLaunchKernelGGL(k_row_apply<OP>, dim3(kParts, (unsigned)batch), dim3(NT), 0, ctx->stream, src, dst, n, part);
+    hipLaunchKernelGGL(k_row_apply<OP>, dim3(kParts, (unsigned)batch), dim3(NT), 0, ctx->stream, src, dst, n, part, c0, c1);
     HIP_TRY(hipGetLastError());
     return XCX_OK;
   }
@@ -386,6 +390,11 @@ extern "C" int xcx_detrend_linear(xcx_ctx* ctx, float* x, long batch, long n, in
 }
 extern "C" int xcx_detrend_to(xcx_ctx* ctx, const float* src, float* dst, long batch, long n, int linear) {
   return linear ? row_op_to<OP_DETREND>(ctx, src, dst, batch, n) : row_op_to<OP_DEMEAN>(ctx, src, dst, batch, n);
+}
+extern "C" int xcx_detrend_to_cols(xcx_ctx* ctx, const float* src, float* dst, long batch, long n, int linear,
+                                   long col0, long col1) {
+  return linear ? row_op_to<OP_DETREND>(ctx, src, dst, batch, n, col0, col1)
+                : row_op_to<OP_DEMEAN>(ctx, src, dst, batch, n, col0, col1);
 }
 
 extern "C" int xcx_taper(xcx_ctx* ctx, float* x, long batch, long n, long nmax, int wtype, int on_device) {

@@ -7,6 +7,8 @@ These are the numpy-level kernels underneath the reference's
 ``xr.apply_ufunc`` closures; ``xcorr_amd.signal`` wraps them with the
 reference's labelled-array interface.
 """
+import ctypes as C
+
 import numpy as np
 
 from . import _ffi
@@ -62,10 +64,18 @@ def _detrend_to(ctx, x, out, linear):
     return out
 
 
-def demean(ctx, x, out=None):
+def demean(ctx, x, out=None, cols=None):
     """x - mean(x) (xcorr/signal/detrend.py:110).  In place; with ``out`` (device arrays) the
-    source stays untouched and no copy of it is needed first."""
+    source stays untouched and no copy of it is needed first.  ``cols=(c0, c1)`` (with ``out``):
+    write only those columns -- the mean is still that of the whole row."""
     ctx = _ctx(ctx, x)
+    if cols is not None:
+        if out is None or not isinstance(x, DeviceArray) or not isinstance(out, DeviceArray) or out.nbytes != x.nbytes:
+            raise ValueError('cols= needs DeviceArray source and out= of the same size')
+        n = x.shape[-1]
+        b = int(np.prod(x.shape[:-1])) if len(x.shape) > 1 else 1
+        check(_ffi.lib().xcx_detrend_to_cols(ctx.handle, ptr(x), ptr(out), b, n, 0, int(cols[0]), int(cols[1])))
+        return out
     if out is not None:
         return _detrend_to(ctx, x, out, 0)
     buf, b, n, dev, _ = _prep(x)
@@ -161,10 +171,28 @@ def sosfiltfilt(ctx, x, sos):
     return buf
 
 
-def sosfilt(ctx, x, sos):
-    """scipy.signal.sosfilt(sos, x, axis=-1) from rest."""
+def sosfilt_warmup(sos):
+    """Samples after which the cascade has forgotten its start state to below float64 rounding
+    (xcx_sosfilt_warmup: ||A^warm||_inf <= 2^-64); -1 when it never does."""
+    sos = _sos(sos)
+    w = C.c_long(0)
+    check(_ffi.lib().xcx_sosfilt_warmup(ptr(sos), sos.shape[0], C.byref(w)))
+    return w.value
+
+
+def sosfilt(ctx, x, sos, cols=None):
+    """scipy.signal.sosfilt(sos, x, axis=-1) from rest.  ``cols=(c0, c1)`` (device rows): only those
+    columns are produced, from a warm-up that starts ``sosfilt_warmup(sos)`` samples before c0 (the
+    returned first column; what lies between it and c0 is overwritten with intermediate values)."""
     ctx = _ctx(ctx, x)
     sos = _sos(sos)
+    if cols is not None:
+        if not isinstance(x, DeviceArray) or len(x.shape) != 2:
+            raise ValueError('cols= needs a 2-D DeviceArray')
+        first = C.c_long(0)
+        check(_ffi.lib().xcx_sosfilt_cols(ctx.handle, ptr(x), x.shape[0], x.shape[1], ptr(sos), sos.shape[0],
+                                          int(cols[0]), int(cols[1]), C.byref(first)))
+        return first.value
     buf, b, n, dev, _ = _prep(x)
     check(_ffi.lib().xcx_sosfilt(ctx.handle, ptr(buf), b, n, ptr(sos),
                                  sos.shape[0], dev))

@@ -59,6 +59,7 @@ class StationDay:
         self.out = ctx.empty((self.nrows, self.ld))
         self.sos = band_sos() if self.preprocess else None
         self.taper_n = taper_samples(self.T)
+        self.warm = None
 
     def load(self, raw_host):
         """Make a day of raw traces resident (outside any timed region)."""
@@ -77,9 +78,21 @@ class StationDay:
         ctx = ctx or self.ctx
         if not self.preprocess:
             return
-        ops.demean(ctx, self.raw, out=self.work)          # raw -> work: no separate copy of the day
-        ops.taper(ctx, self.work, self.taper_n, wtype='cosine')
-        ops.sosfilt(ctx, self.work, self.sos)
+        c0, c1 = self.w_first * self.hop, (self.w_first + self.W - 1) * self.hop + self.n
+        if c0 == 0 and c1 >= self.T:
+            ops.demean(ctx, self.raw, out=self.work)          # raw -> work: no separate copy of the day
+            ops.taper(ctx, self.work, self.taper_n, wtype='cosine')
+            ops.sosfilt(ctx, self.work, self.sos)
+            return
+        # A block of windows (bench.py --shard windows): only the samples the block needs.  The day mean
+        # is still that of the whole row (one read of the day); the band-pass runs over the block plus the
+        # warm-up after which its state equals the from-rest state to below float64 rounding (ops.sosfilt).
+        if self.warm is None:
+            self.warm = ops.sosfilt_warmup(self.sos)
+        lo = 0 if (self.warm < 0 or self.warm >= c0) else c0 - self.warm
+        ops.demean(ctx, self.raw, out=self.work, cols=(lo, c1))
+        ops.taper(ctx, self.work, self.taper_n, wtype='cosine')   # touches the day's two flanks only
+        ops.sosfilt(ctx, self.work, self.sos, cols=(c0, c1))
 
     def correlate(self):
         self.plan.pairs(self.view, self.pairs, self.W, self.hop, out=self.out, ld_out=self.ld,
