@@ -21,3 +21,24 @@ t('taper', lambda: ops.taper(ctx, work, 1500, wtype='cosine'))
 t('sosfilt', lambda: ops.sosfilt(ctx, work, sos))
 t('ram', lambda: ops.ram_normalize(ctx, work, 250))
 t('decimate5', lambda: ops.decimate(ctx, work, 5, sos))
+# ---- bench.py --shard windows: the front end of ONE rank's window block ----------------
+from xcorr_amd import workload
+W_all = (T - n) // hop + 1
+pairs = np.array([(0, 1)], np.int32)
+for world in (1, 2, 4, 8):
+    worst = 0.0
+    for rank in sorted({0, world // 2, world - 1}):
+        w0, w1 = (W_all * rank) // world, (W_all * (rank + 1)) // world
+        sd = workload.StationDay(ctx, S, T, n, hop, pairs, w_first=w0, W=w1 - w0)
+        sd.raw, sd.work = raw, work
+        sd.view = work
+        sd.front(); ctx.sync()
+        t0 = time.perf_counter()
+        for _ in range(5): sd.front()
+        ctx.sync()
+        ms = (time.perf_counter() - t0) / 5 * 1e3
+        worst = max(worst, ms)
+        print(f'front end of rank {rank} of {world} (windows {w0}..{w1 - 1}): {ms:7.3f} ms', flush=True)
+        sd.raw = sd.work = None
+        sd.plan.close(); sd.out.free()
+    print(f'  -> slowest rank of {world}: {worst:.3f} ms', flush=True)

@@ -40,7 +40,7 @@ namespace {
 struct BsGeom {
   long nin, nout, n, np;   // np = nin + nout - 1
   int sign;                // -1 forward, +1 inverse
-  int in_complex;          // input rows are interleaved complex (else real)
+  int in_complex;          // 1: input rows are interleaved complex; 2: real rows taken as (even, odd) pairs; 0: real
   int half_weights;        // irfft: double every bin except DC and Nyquist (bin n/2)
   long in_pitch;           // elements (floats or complex) between input rows
   // partial transform (long axes are split): inputs m0 .. m0+nin, outputs k0 .. k0+nout of the
@@ -69,7 +69,10 @@ __global__ void k_bs_pre(const float* __restrict__ in, BsGeom g, long B, float* 
       if (t < g.nin) {
         const long m = g.m0 + t;
         double vr, vi = 0.0;
-        if (g.in_complex) {
+        if (g.in_complex == 2) {                 // real rows read as (even, odd) sample pairs; pitch in floats
+          vr = in[b * g.in_pitch + 2 * m];
+          vi = in[b * g.in_pitch + 2 * m + 1];
+        } else if (g.in_complex) {
           const float2 v = reinterpret_cast<const float2*>(in)[b * g.in_pitch + m];
           vr = v.x; vi = v.y;
         } else {
@@ -114,7 +117,7 @@ __global__ void k_bs_post(const float* __restrict__ R, long ld, BsGeom g, long B
   }
 }
 
-constexpr long kBsMaxNp = (737280 + 1) / 2;          // 2 np - 1 <= 737280, the longest correlation plan
+constexpr long kBsMaxNp = 737280;                    // np <= N of the longest tuned correlation plan (kPlanShortOperand)
 
 int bluestein_core(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom g, double scale, int real_only,
                    int in_dev, int out_dev) {
@@ -132,7 +135,9 @@ int bluestein_core(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom
     slot = ctx->bs_next;
     ctx->bs_next ^= 1;
     if (ctx->bs_plan[slot]) { xcx_plan_destroy(ctx->bs_plan[slot]); ctx->bs_plan[slot] = nullptr; }
-    if ((rc = xcx_plan_cc1d(ctx, (int)g.np, 0, (int)imin, (int)imax, XCX_STACK, &ctx->bs_plan[slot]))) return rc;
+    // station A is zero beyond its first nin samples and the retained lags are -(nout-1) .. 0: a transform of
+    // N >= np points is alias-free for them (kPlanShortOperand), not np + max|lag|
+    if ((rc = xcx_plan_cc1d(ctx, (int)g.np, 0, (int)imin, (int)imax, XCX_STACK | kPlanShortOperand, &ctx->bs_plan[slot]))) return rc;
     ctx->bs_key[slot][0] = g.np; ctx->bs_key[slot][1] = imin; ctx->bs_key[slot][2] = imax;
   }
   xcx_plan* plan = ctx->bs_plan[slot];
@@ -142,7 +147,7 @@ int bluestein_core(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom
   DevBuf &tr = ctx->scratch[1], &lin = ctx->scratch[2], &din = ctx->scratch[4], &dout = ctx->scratch[5];
   if ((rc = tr.ensure(ctx, sizeof(float) * 2 * g.np * (chunk + 2)))) return rc;
   if ((rc = lin.ensure(ctx, sizeof(float) * ld * 2 * chunk))) return rc;
-  const size_t in_row = (size_t)g.in_pitch * (g.in_complex ? 8 : 4);
+  const size_t in_row = (size_t)g.in_pitch * (g.in_complex == 1 ? 8 : 4);
   const size_t out_row = (size_t)(g.out_pitch ? g.out_pitch : g.nout) * (real_only ? 4 : 8);
   const bool stage_in = !in_dev, stage_out = !out_dev;
   const float* ind = in;
@@ -204,7 +209,7 @@ int bluestein(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom g, d
   }
   HIP_TRY(hipSetDevice(ctx->device));
   int rc;
-  const size_t in_row = (size_t)g.in_pitch * (g.in_complex ? 8 : 4);
+  const size_t in_row = (size_t)g.in_pitch * (g.in_complex == 1 ? 8 : 4);
   const size_t out_row = (size_t)(g.out_pitch ? g.out_pitch : g.nout) * (real_only ? 4 : 8);
   void *din = nullptr, *dout = nullptr;                     // own buffers: the core uses the context scratch
   auto done = [&](int r) { (void)hipFree(din); (void)hipFree(dout); return r; };
@@ -252,14 +257,109 @@ extern "C" int xcx_ifft(xcx_ctx* ctx, const float* in, float* out, long batch, l
   return bluestein(ctx, in, out, batch, g, n > 0 ? 1.0 / (double)n : 0.0, 0, on_device, on_device);
 }
 
+// ---------------------------------------------------------------------------
+// Real transforms of EVEN length n = 2m through ONE complex transform of length m (the lag axis
+// 359 998 = 2 x 179 999: a chirp convolution of 2m - 1 = 359 997 points fits the tuned N = 368 640
+// plan, where the unpacked real transform needed 540 k points, i.e. two partial transforms):
+//   z[j] = x[2j] + i x[2j+1],  Z = DFT_m(z),  E = DFT_m(x_even) = (Z[k] + conj Z[m-k]) / 2,
+//   O = DFT_m(x_odd) = (Z[k] - conj Z[m-k]) / 2i,  X[k] = E[k] + w^k O[k],  w = exp(-2 pi i / n),
+// and back:  E = (X[k] + conj X[m-k]) / 2,  O = w^-k (X[k] - conj X[m-k]) / 2,  Z = E + i O,
+// z = IDFT_m(Z): the n real samples are the interleaved (re, im) of z.
+// ---------------------------------------------------------------------------
+namespace {
+__global__ void k_rfft_unpack(const float2* __restrict__ Z, long m, float2* __restrict__ X, long batch) {
+  const long nh = m + 1, total = batch * nh;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / nh, k = i % nh;
+    const float2 a = Z[b * m + (k == m ? 0 : k)];
+    const float2 c = Z[b * m + ((k == 0 || k == m) ? 0 : m - k)];
+    const double er = 0.5 * ((double)a.x + c.x), ei = 0.5 * ((double)a.y - c.y);        // E = (a + conj c) / 2
+    const double orr = 0.5 * ((double)a.y + c.y), oi = -0.5 * ((double)a.x - c.x);     // O = (a - conj c) / 2i
+    double s, co;
+    sincospi(-(double)k / (double)m, &s, &co);                                         // w^k = exp(-i pi k / m)
+    X[i] = make_float2((float)(er + co * orr - s * oi), (float)(ei + co * oi + s * orr));
+  }
+}
+
+// X rows [batch][in_pitch] (bins 0..m used; imaginary parts of bins 0 and m ignored, as numpy.fft.irfft does)
+__global__ void k_irfft_pack(const float2* __restrict__ X, long in_pitch, long m, float2* __restrict__ Z, long batch) {
+  const long total = batch * m;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / m, k = i % m;
+    float2 a = X[b * in_pitch + k], c = X[b * in_pitch + m - k];
+    if (k == 0) { a.y = 0.f; c.y = 0.f; }
+    const double er = 0.5 * ((double)a.x + c.x), ei = 0.5 * ((double)a.y - c.y);        // E = (a + conj c) / 2
+    const double dr = 0.5 * ((double)a.x - c.x), di = 0.5 * ((double)a.y + c.y);        // (a - conj c) / 2
+    double s, co;
+    sincospi((double)k / (double)m, &s, &co);                                          // w^-k
+    const double orr = co * dr - s * di, oi = co * di + s * dr;                        // O
+    Z[i] = make_float2((float)(er - oi), (float)(ei + orr));                           // E + i O
+  }
+}
+
+int launch_rows(xcx_ctx* ctx, long total) { (void)ctx; return (int)std::min<long>((total + 255) / 256, 256L * 16); }
+
+// rfft of even n: x rows [batch][pitch floats] (device or host) -> X rows [batch][n/2+1] complex
+int rfft_even(xcx_ctx* ctx, const float* x, long pitch, float* out, long batch, long n, int in_dev, int out_dev) {
+  const long m = n / 2;
+  HIP_TRY(hipSetDevice(ctx->device));
+  DevBuf &zb = ctx->scratch[8], &xb = ctx->scratch[9];
+  int rc;
+  if ((rc = zb.ensure(ctx, sizeof(float2) * m * batch))) return rc;
+  BsGeom g{m, m, m, 0, -1, 2, 0, pitch};
+  if ((rc = bluestein(ctx, x, (float*)zb.ptr, batch, g, 1.0, 0, in_dev, 1))) return rc;
+  float* dst = out;
+  if (!out_dev) {
+    if ((rc = xb.ensure(ctx, sizeof(float2) * (m + 1) * batch))) return rc;
+    dst = (float*)xb.ptr;
+  }
+  hipLaunchKernelGGL(k_rfft_unpack, dim3(launch_rows(ctx, batch * (m + 1))), dim3(256), 0, ctx->stream,
+                     (const float2*)zb.ptr, m, (float2*)dst, batch);
+  HIP_TRY(hipGetLastError());
+  if (!out_dev) {
+    HIP_TRY(hipMemcpyAsync(out, dst, sizeof(float2) * (m + 1) * batch, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+  }
+  return XCX_OK;
+}
+
+// irfft to even n = 2m: X rows [batch][in_pitch complex] -> n real samples per row, scaled by `scale` * n
+// (scale = 1/n gives numpy.fft.irfft)
+int irfft_even(xcx_ctx* ctx, const float* in, long in_pitch, float* x, long batch, long n, double scale, int in_dev, int out_dev) {
+  const long m = n / 2;
+  HIP_TRY(hipSetDevice(ctx->device));
+  DevBuf &zb = ctx->scratch[8], &xb = ctx->scratch[9];
+  int rc;
+  if ((rc = zb.ensure(ctx, sizeof(float2) * m * batch))) return rc;
+  const float* src = in;
+  if (!in_dev) {
+    if ((rc = xb.ensure(ctx, sizeof(float2) * in_pitch * batch))) return rc;
+    HIP_TRY(hipMemcpyAsync(xb.ptr, in, sizeof(float2) * in_pitch * batch, hipMemcpyHostToDevice, ctx->stream));
+    src = (const float*)xb.ptr;
+  }
+  hipLaunchKernelGGL(k_irfft_pack, dim3(launch_rows(ctx, batch * m)), dim3(256), 0, ctx->stream,
+                     (const float2*)src, in_pitch, m, (float2*)zb.ptr, batch);
+  HIP_TRY(hipGetLastError());
+  // z = IDFT_m(Z) * 2 scale: x[2j] + i x[2j+1] = (1/m) sum Z e^{+}, and numpy's 1/n = 1/(2m)
+  BsGeom g{m, m, m, 0, +1, 1, 0, m};
+  return bluestein(ctx, (const float*)zb.ptr, x, batch, g, 2.0 * scale, 0, 1, out_dev);
+}
+}  // namespace
+
 extern "C" int xcx_rfft(xcx_ctx* ctx, const float* x, float* out, long batch, long size, int on_device) {
+  if (!ctx || !x || !out) return set_err(XCX_EINVAL, "null argument");
   const long n = size - (size & 1);              // fft.py:357 drops the last sample of an odd axis
+  if (batch < 1 || n < 2) return set_err(XCX_EINVAL, "batch >= 1 and n >= 2 required");
+  if (n >= 4) return rfft_even(ctx, x, size, out, batch, n, on_device, on_device);
   BsGeom g{n, n / 2 + 1, n, 0, -1, 0, 0, size};
   return bluestein(ctx, x, out, batch, g, 1.0, 0, on_device, on_device);
 }
 
 extern "C" int xcx_irfft(xcx_ctx* ctx, const float* in, float* x, long batch, long m, int on_device) {
+  if (!ctx || !in || !x) return set_err(XCX_EINVAL, "null argument");
   const long n = 2 * m - 2;                       // fft.py:475
+  if (batch < 1 || n < 2) return set_err(XCX_EINVAL, "batch >= 1 and n >= 2 required");
+  if (n >= 4) return irfft_even(ctx, in, m, x, batch, n, 1.0 / (double)n, on_device, on_device);
   BsGeom g{m, n, n, 0, +1, 1, 1, m};
   return bluestein(ctx, in, x, batch, g, n > 0 ? 1.0 / (double)n : 0.0, 1, on_device, on_device);
 }
@@ -326,10 +426,68 @@ extern "C" int xcx_resample(xcx_ctx* ctx, const float* x, float* y, long batch, 
 
 // scipy.signal.hilbert along the last axis (xcorr/signal/hilbert.py:69, envelope :120):
 // one-sided spectrum (bins 0..n/2, doubled except DC and, for even n, Nyquist) transformed back
+namespace {
+// S[k] <- -i S[k] for 0 < k < m, S[0] = S[m] = 0: irfft of it is the Hilbert transform of the row
+__global__ void k_hilbert_spec(float2* __restrict__ S, long m, long batch) {
+  const long nh = m + 1, total = batch * nh;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long k = i % nh;
+    const float2 v = S[i];
+    S[i] = (k == 0 || k == m) ? make_float2(0.f, 0.f) : make_float2(v.y, -v.x);
+  }
+}
+// out = x + i H (complex) or |x + i H| (envelope)
+__global__ void k_hilbert_out(const float* __restrict__ x, const float* __restrict__ H, long total, int envelope,
+                              float* __restrict__ out) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const float a = x[i], b = H[i];
+    if (envelope) out[i] = (float)sqrt((double)a * a + (double)b * b);
+    else reinterpret_cast<float2*>(out)[i] = make_float2(a, b);
+  }
+}
+
+// even n: two packed real transforms (rfft_even, irfft_even) instead of an unpacked forward transform and a
+// complex inverse of length n; the real part of the analytic signal is the input itself
+int hilbert_even(xcx_ctx* ctx, const float* x, float* out, long batch, long n, int envelope, int on_device) {
+  const long m = n / 2, nh = m + 1;
+  HIP_TRY(hipSetDevice(ctx->device));
+  DevBuf &spec = ctx->scratch[6], &hb = ctx->scratch[7], &xin = ctx->scratch[3];
+  int rc;
+  const long rows = std::max<long>(1, std::min<long>(batch, ((long)512 << 20) / (8 * nh)));
+  if ((rc = spec.ensure(ctx, sizeof(float2) * nh * rows))) return rc;
+  if ((rc = hb.ensure(ctx, sizeof(float) * n * rows))) return rc;
+  if (!on_device && (rc = xin.ensure(ctx, sizeof(float) * n * rows * (envelope ? 2 : 3)))) return rc;
+  const size_t orow = (size_t)n * (envelope ? 4 : 8);
+  for (long r0 = 0; r0 < batch; r0 += rows) {
+    const long cnt = std::min(rows, batch - r0);
+    const float* xd = x + r0 * n;
+    float* od = (float*)((char*)out + orow * r0);
+    if (!on_device) {
+      HIP_TRY(hipMemcpyAsync(xin.ptr, x + r0 * n, sizeof(float) * n * cnt, hipMemcpyHostToDevice, ctx->stream));
+      xd = (const float*)xin.ptr;
+      od = (float*)xin.ptr + n * rows;
+    }
+    if ((rc = rfft_even(ctx, xd, n, (float*)spec.ptr, cnt, n, 1, 1))) return rc;
+    hipLaunchKernelGGL(k_hilbert_spec, dim3(launch_rows(ctx, cnt * nh)), dim3(256), 0, ctx->stream, (float2*)spec.ptr, m, cnt);
+    HIP_TRY(hipGetLastError());
+    if ((rc = irfft_even(ctx, (const float*)spec.ptr, nh, (float*)hb.ptr, cnt, n, 1.0 / (double)n, 1, 1))) return rc;
+    hipLaunchKernelGGL(k_hilbert_out, dim3(launch_rows(ctx, cnt * n)), dim3(256), 0, ctx->stream, xd, (const float*)hb.ptr,
+                       cnt * n, envelope, od);
+    HIP_TRY(hipGetLastError());
+    if (!on_device) {
+      HIP_TRY(hipMemcpyAsync((char*)out + orow * r0, od, orow * cnt, hipMemcpyDeviceToHost, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+  }
+  return XCX_OK;
+}
+}  // namespace
+
 extern "C" int xcx_hilbert(xcx_ctx* ctx, const float* x, float* out, long batch, long n, int envelope,
                            int on_device) {
-  if (!ctx) return set_err(XCX_EINVAL, "null argument");
+  if (!ctx || !x || !out) return set_err(XCX_EINVAL, "null argument");
   if (batch < 1 || n < 2) return set_err(XCX_EINVAL, "batch >= 1 and n >= 2 required");
+  if (n % 2 == 0 && n >= 4) return hilbert_even(ctx, x, out, batch, n, envelope, on_device);
   const long nh = n / 2 + 1;
   DevBuf& spec = ctx->scratch[6];
   int rc;

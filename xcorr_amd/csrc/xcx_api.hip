@@ -477,7 +477,10 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
   // as N >= n + max|lag|.  Full-lag plans need 2n-1 as ever; clipped plans (the reference's
   // clip_lag) get a proportionally shorter transform.
   const long long maxlag = std::max<long long>((long long)n - 1 - idx_min, (long long)idx_max - n);
-  const long long need = (long long)n + maxlag;
+  // kPlanShortOperand (library-internal, fftn.hip): the caller guarantees that the first operand is zero
+  // beyond its first idx_min + 1 samples and that only lags <= 0 are retained -- the aliases of the retained
+  // lags then fall outside the linear correlation's support as soon as N >= n (chirp convolutions).
+  const long long need = (flags & kPlanShortOperand) ? (long long)n : (long long)n + maxlag;
   // choose N = 2*N1*N2h: smallest supported >= need (or == nfft)
   const char* eng = getenv("XCX_ENGINE");
   const bool wave = !(eng && strcmp(eng, "wg") == 0);
@@ -1312,7 +1315,11 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
   key = fnv(hdr, sizeof hdr, key);
   key = fnv(&ld_out, sizeof ld_out, key) & ~1ULL;      // even: never equal to a stack_tables() key (odd)
   const size_t ndesc = stack ? (size_t)P : (size_t)P * W;
-  const bool via_gram = stack && p->wave && p->gram && W > 1;     // descriptors come from stack_tables()
+  // Stacks of very few windows (the chirp convolutions of fftn.hip stack W = 2) sum the products in the
+  // pair column pass itself (MODE 1: W x 2 column loads per pair): building, writing and re-reading a
+  // P x N/2 cross-spectrum buffer only pays once many windows share it (k_gram_mfma was 60 % of xcx_rfft).
+  static const int gram_min_w = getenv("XCX_GRAM_MIN_W") ? std::max(2, atoi(getenv("XCX_GRAM_MIN_W"))) : 4;
+  const bool via_gram = stack && p->wave && p->gram && W >= gram_min_w;     // descriptors come from stack_tables()
   if (!via_gram && (key != p->desc_key || p->hdescs.size() != ndesc)) {
     std::vector<int> perm(P);
     // processing order.  Dual pipelines: launch batches = station groups (pair_order.h: few distinct
@@ -1366,7 +1373,7 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
     if ((rc = forward(p, dtr, stride_s, stride_w, W, 0, 0, S * W, 0))) return rc;
     const cf* src = nullptr;
     int ns = W;
-    if (p->wave && p->gram && W > 1) {
+    if (via_gram) {
       // cgemm-style stack: G_k = A_k A_k^H per frequency, then one inverse per pair
       if ((rc = stack_tables(p, pairs, S, P, ld_out))) return rc;
       if ((rc = stack_gram(p, S, W, P, 0))) return rc;

@@ -5,6 +5,9 @@
 
 struct xcx_ctx;
 
+// library-internal plan flag (above the 16 public flag bits of include/xcx.h), see xcx_plan_cc1d
+constexpr int kPlanShortOperand = 0x10000;
+
 namespace xcx {
 int set_err(int code, const char* fmt, ...);
 
@@ -22,7 +25,7 @@ struct xcx_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   void* comm = nullptr;      // ncclComm_t
   int nranks = 1, rank = 0;
-  xcx::DevBuf scratch[8];    // grow-only workspaces of the row ops / filters
+  xcx::DevBuf scratch[10];   // grow-only workspaces of the row ops / filters / transforms
   struct xcx_plan* ts_plan = nullptr;   // cached plan of xcx_timeshift
   long ts_n = 0;
   struct xcx_plan* bs_plan[2] = {nullptr, nullptr};   // cached plans of the Bluestein FFTs (fftn.hip)
