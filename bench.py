@@ -77,19 +77,6 @@ def parse():
     return ap.parse_args()
 
 
-def fast_day(S, T, day):
-    """Cheap synthetic station-day for multi-day runs (float32 generator; same structure as
-    xcorr_amd.synth: common signal with 25-sample moveout + noise + offset)."""
-    rng = np.random.default_rng(777 + day)
-    c = rng.standard_normal(T + 25 * S, dtype=np.float32)
-    out = rng.standard_normal((S, T), dtype=np.float32)
-    for s in range(S):
-        off = 25 * (S - 1 - s)
-        out[s] += 0.5 * c[off:off + T]
-        out[s] += 3.0
-    return out
-
-
 # ---------------------------------------------------------------------------
 # CPU baseline: the oracle's faithful restatement of util/cc.py (complex FFT of
 # length 2n-1), one process per host core, bounded sample; plus the oracle's
@@ -204,7 +191,7 @@ def main():
 
     import xcorr_amd as X
     from xcorr_amd import _ffi, ops, workload
-    from xcorr_amd.synth import synthetic_traces
+    from xcorr_amd.synth import synthetic_traces, fast_day
     import ctypes as _C
     ndev = _C.c_int(0)
     _ffi.check(_ffi.lib().xcx_device_count(_C.byref(ndev)))
@@ -363,6 +350,12 @@ def main():
             ops.copy(ctx, dst_b, src_b)
         ctx.sync()
         extras['copy_GBps_measured'] = 5 * 2 * src_b.nbytes / (time.perf_counter() - t1) / 1e9
+        # ... and the write ceiling: the pass is output-dominated (1.44 MB of CCF per pair-window), so what
+        # the chip sustains for a pure stream of 16-byte non-temporal stores bounds it from above
+        wbytes = min(out.nbytes, 8 << 30)
+        wms = _C.c_float(0)
+        _ffi.check(_ffi.lib().xcx_stream_write_rate(ctx.handle, _C.c_void_p(out.ptr), wbytes, 3, _C.byref(wms)))
+        extras['nt_write_stream_GBps_measured'] = 3 * wbytes / (wms.value * 1e-3) / 1e9
         # PCIe-inclusive rate of the host-pointer form of the same call (bounded sample)
         try:
             S_h, W_h = min(S, 8), min(W, 3)
@@ -494,6 +487,10 @@ def main():
                 'kernels_us': {k: v['avg_us'] for k, v in kern.items()},
                 'traffic_GBps': (tr / (eff_us * 1e-6) / 1e9) if (tr and eff_us) else None,
                 'copy_GBps_measured': copy,
+                # the CCF stream alone (algorithmic output bytes / measured nt write rate) bounds the pass at:
+                'nt_write_stream_GBps_measured': extras.get('nt_write_stream_GBps_measured'),
+                'pair_windows_per_s_at_write_ceiling': (extras['nt_write_stream_GBps_measured'] * 1e9 / (4.0 * L))
+                if extras.get('nt_write_stream_GBps_measured') else None,
             }
             if 'pcie_inclusive' in extras:
                 res['pcie_inclusive'] = extras['pcie_inclusive']

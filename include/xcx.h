@@ -68,6 +68,10 @@ int xcx_memcpy_h2d(xcx_ctx* ctx, void* dst, const void* src, size_t bytes);
 int xcx_memcpy_d2h(xcx_ctx* ctx, void* dst, const void* src, size_t bytes);
 /* asynchronous on the context's stream */
 int xcx_memcpy_d2d(xcx_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* Measurement aid: overwrite `bytes` of device memory `reps` times with 16-byte-per-lane streaming
+ * (non-temporal) stores -- the access shape of the CCF store of the pair pass -- and return the elapsed
+ * milliseconds (HIP events): the write ceiling of an output-bound pass on this chip (bench.py). */
+int xcx_stream_write_rate(xcx_ctx* ctx, void* dptr, size_t bytes, int reps, float* ms);
 /* rows x width_bytes, with independent pitches (bytes) */
 int xcx_memcpy2d_d2h(xcx_ctx* ctx, void* dst, size_t dpitch, const void* src,
                      size_t spitch, size_t width_bytes, size_t rows);

@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 from oracle import ref_numpy as R                       # noqa: E402  (checker only)
 import xcorr_amd as X                                   # noqa: E402
+from xcorr_amd.synth import fast_day                    # noqa: E402
 
 TOL = 1e-5
 SAMPLED = [(0, 1), (0, 63), (62, 63), (31, 32), (5, 40), (17, 18), (0, 32), (10, 53), (20, 21), (7, 8),
@@ -23,13 +24,7 @@ SAMPLED = [(0, 1), (0, 63), (62, 63), (31, 32), (5, 40), (17, 18), (0, 32), (10,
 
 
 def _day(S, T, d):
-    rng = np.random.default_rng(4000 + d)
-    c = rng.standard_normal(T + 25 * S, dtype=np.float32)
-    x = rng.standard_normal((S, T), dtype=np.float32)
-    for s in range(S):
-        off = 25 * (S - 1 - s)
-        x[s] += 0.5 * c[off:off + T]
-    return x
+    return fast_day(S, T, d)              # the generator bench.py --stack --days uses
 
 
 def test_thirty_day_stack_full_pair_count(ctx):

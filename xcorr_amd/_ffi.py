@@ -46,6 +46,7 @@ SIGNATURES = {
     'xcx_memcpy_h2d': [_vp, _vp, _vp, _sz],
     'xcx_memcpy_d2h': [_vp, _vp, _vp, _sz],
     'xcx_memcpy_d2d': [_vp, _vp, _vp, _sz],
+    'xcx_stream_write_rate': [_vp, _vp, C.c_size_t, _i, C.POINTER(C.c_float)],
     'xcx_memcpy2d_d2h': [_vp, _vp, _sz, _vp, _sz, _sz, _sz],
     'xcx_sync': [_vp],
     'xcx_timer_start': [_vp],

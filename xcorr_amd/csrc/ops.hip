@@ -614,3 +614,36 @@ extern "C" int xcx_snr(xcx_ctx* ctx, const float* x, long batch, long n, const u
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   return XCX_OK;
 }
+
+// ---- measurement aid: what the chip writes ---------------------------------------------------
+// The pair pass is output-dominated (one 1.44 MB full-lag CCF per pair-window, written once with
+// streaming stores).  xcx_stream_write_rate fills `bytes` of device memory with 16-byte-per-lane
+// non-temporal stores -- the access shape of the CCF store -- and returns the elapsed time of `reps`
+// passes (HIP events on the context's stream): the ceiling an output-bound pass can reach on this
+// chip, reported by bench.py beside the nominal 8 TB/s.
+namespace {
+__global__ void k_stream_fill(float4* __restrict__ dst, size_t n16, float v) {
+  typedef float f32x4 __attribute__((ext_vector_type(4)));
+  const f32x4 w = {v, v, v, v};
+  f32x4* __restrict__ d = reinterpret_cast<f32x4*>(dst);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
+    __builtin_nontemporal_store(w, d + i);
+}
+}  // namespace
+
+extern "C" int xcx_stream_write_rate(xcx_ctx* ctx, void* dptr, size_t bytes, int reps, float* ms) {
+  if (!ctx || !dptr || !ms) return set_err(XCX_EINVAL, "null argument");
+  if (bytes < 16 || reps < 1) return set_err(XCX_EINVAL, "bytes >= 16 and reps >= 1 required");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t n16 = bytes / 16;
+  const unsigned grid = 256 * 16;
+  hipLaunchKernelGGL(k_stream_fill, dim3(grid), dim3(NT), 0, ctx->stream, (float4*)dptr, n16, 0.f);   // warm-up
+  HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+  for (int r = 0; r < reps; ++r)
+    hipLaunchKernelGGL(k_stream_fill, dim3(grid), dim3(NT), 0, ctx->stream, (float4*)dptr, n16, 0.f);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+  HIP_TRY(hipEventSynchronize(ctx->ev1));
+  HIP_TRY(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+  return XCX_OK;
+}
