@@ -278,12 +278,11 @@ def test_baseline_config_checksum(ctx):
         assert relerr(got[p, w], ref) < TOL
 
 
-@pytest.mark.parametrize('env', [{'XCX_DUAL': '0'}, {'XCX_FLOW': '1'}, {'XCX_ENGINE': 'wg'}, {'XCX_GROUPS': '0'}],
-                         ids=['two-launch', 'flow-one-launch', 'workgroup-engine', 'tile-order'])
+@pytest.mark.parametrize('env', [{'XCX_DUAL': '0'}, {'XCX_FLOW': '1'}, {'XCX_GROUPS': '0'}],
+                         ids=['two-launch', 'flow-one-launch', 'tile-order'])
 def test_alternative_engines_agree(ctx, env, monkeypatch):
     """The alternative kernel paths (separate I1/I2 launches, the opt-in one-launch flow kernel with
-    its in-memory batch dependencies, the first-generation 256-thread engine, the plain station-tile
-    processing order) stay parity-green."""
+    its in-memory batch dependencies, the plain station-tile processing order) stay parity-green."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     monkeypatch.setenv('XCX_CHECK', '1')

@@ -146,9 +146,6 @@ template <int NT> XCX_DEV void group_sync() {
 // ---------------------------------------------------------------------------
 // radix butterflies, in place on a register array v[R]
 // ---------------------------------------------------------------------------
-// XCX_ABLATE_MATH (diagnostic builds only, tools/ablate.sh): butterflies, twiddle chains and LDS
-// exchanges become no-ops / register copies, so that a kernel keeps its exact global-memory
-// access pattern but does (almost) no arithmetic: "how fast is the memory side alone?"
 template <int R, bool INV> struct Bfly;
 
 template <bool INV> struct Bfly<1, INV> {
@@ -157,9 +154,6 @@ template <bool INV> struct Bfly<1, INV> {
 
 template <bool INV> struct Bfly<2, INV> {
   static XCX_DEV void run(cf (&v)[2]) {
-#ifdef XCX_ABLATE_MATH
-    return;
-#endif
     cf a = cadd(v[0], v[1]), b = csub(v[0], v[1]);
     v[0] = a; v[1] = b;
   }
@@ -167,9 +161,6 @@ template <bool INV> struct Bfly<2, INV> {
 
 template <bool INV> struct Bfly<3, INV> {
   static XCX_DEV void run(cf (&v)[3]) {
-#ifdef XCX_ABLATE_MATH
-    return;
-#endif
     constexpr float s = 0.86602540378443864676f;
     cf t = cadd(v[1], v[2]);
     cf d = csub(v[1], v[2]);
@@ -184,9 +175,6 @@ template <bool INV> struct Bfly<3, INV> {
 
 template <bool INV> struct Bfly<4, INV> {
   static XCX_DEV void run(cf (&v)[4]) {
-#ifdef XCX_ABLATE_MATH
-    return;
-#endif
     cf a0 = cadd(v[0], v[2]), a1 = csub(v[0], v[2]);
     cf a2 = cadd(v[1], v[3]), a3 = csub(v[1], v[3]);
     cf r = INV ? cmul_pi(a3) : cmul_mi(a3);
@@ -199,9 +187,6 @@ template <bool INV> struct Bfly<4, INV> {
 
 template <bool INV> struct Bfly<5, INV> {
   static XCX_DEV void run(cf (&v)[5]) {
-#ifdef XCX_ABLATE_MATH
-    return;
-#endif
     constexpr float c1 = 0.30901699437494742410f;   // cos(2pi/5)
     constexpr float c2 = -0.80901699437494742410f;  // cos(4pi/5)
     constexpr float s1 = 0.95105651629515357212f;   // sin(2pi/5)
@@ -229,9 +214,6 @@ template <bool INV> struct Bfly<5, INV> {
 //   X[k1 + R1*k2] = sum_n2 w_R^{n2 k1} (sum_n1 x[n1*R2+n2] w_R1^{n1 k1}) w_R2^{n2 k2}
 template <int R1, int R2, bool INV> struct BflyCT {
   static XCX_DEV void run(cf (&v)[R1 * R2]) {
-#ifdef XCX_ABLATE_MATH
-    return;
-#endif
     cf a[R2][R1];
     static_for<R2>([&](auto n2c) {
       constexpr int n2 = decltype(n2c)::value;
@@ -372,10 +354,6 @@ XCX_DEV cf csq(cf a) { return make_float2(a.x * a.x - a.y * a.y, 2.f * a.x * a.y
 
 // v[t] *= w^t  (conjugated when INV), t = 1..R-1
 template <int R, bool INV> XCX_DEV void apply_tw_chain(cf (&v)[R], cf w1) {
-#ifdef XCX_ABLATE_MATH
-  v[R - 1].x += w1.x * 1e-30f;          // keeps the twiddle load alive
-  return;
-#endif
   cf w8 = w1, wt = w1;
   if constexpr (R > 8) w8 = csq(csq(csq(w1)));
   static_for<R - 1>([&](auto tc) {
@@ -496,14 +474,6 @@ XCX_DEV void stage_exchange_pad8(float* __restrict__ ldsf,
   constexpr bool WFAST = (NSA == 1) ? (RA % 8 == 0) : (NSA % 8 == 0);
   constexpr bool RFAST = (RD % 8 == 0);
   const int tid = tid_of<NT>();
-#ifdef XCX_ABLATE_MATH
-#pragma unroll
-  for (int it = 0; it < GB::IT; ++it)
-#pragma unroll
-    for (int t = 0; t < RB; ++t) dst[it][t] = src[(it * RB + t) / RA % GA::IT][(it * RB + t) % RA];
-  (void)ldsf; (void)tid;
-  return;
-#endif
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll

@@ -551,7 +551,7 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
       });
     }
   };
-#if XCX_COL_WIDE && !defined(XCX_STAMPS) && !defined(XCX_ABLATE_MATH)
+#if XCX_COL_WIDE && !defined(XCX_STAMPS)
   if constexpr (MODE != 1) {
     auto in2 = [=](int k1, cf& ra, cf& rb, int kb) {
       typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -708,16 +708,6 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
   float* __restrict__ ldsf = reinterpret_cast<float*>(lds);
   using G1 = StageGeom<N2h, RX::R1, RX::R0, kWRB, kWNT>;
   cf v1[G1::IT][RX::R1];
-#ifdef XCX_ABLATE_MATH
-#pragma unroll
-  for (int it = 0; it < G1::IT; ++it)
-#pragma unroll
-    for (int t = 0; t < RX::R1; ++t) {
-      const int e = it * RX::R1 + t;
-      v1[it][t] = (e & 1) ? s0b[(e / 2 / R) % IT][(e / 2) % R] : s0a[(e / 2 / R) % IT][(e / 2) % R];
-    }
-  (void)ldsf;
-#else
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -758,7 +748,6 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
     }
     group_sync<kWNT>();
   }
-#endif
   XCX_STAMP(3, v1[G1::IT - 1][RX::R1 - 1].y);
   stage_compute<N2h, RX::R1, RX::R0, kWRB, kWNT, true>(v1, b1);
   XCX_STAMP(4, v1[G1::IT - 1][RX::R1 - 1].y);

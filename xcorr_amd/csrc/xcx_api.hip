@@ -12,7 +12,7 @@
 #include <vector>
 
 #include "../../include/xcx.h"
-#include "cc_launch.h"
+#include "cc_kernels.h"
 #include "wave_launch.h"
 #include "pair_order.h"
 #include "xcx_internal.h"
@@ -47,12 +47,6 @@ int set_err(int code, const char* fmt, ...) {
 // ---------------------------------------------------------------------------
 // launch tables
 // ---------------------------------------------------------------------------
-#define XCX_COL_ROW(L) {L, launch_fwd_cols_##L, launch_pair_cols_##L},
-#define XCX_ROW_ROW(L) {L, launch_fwd_rows_##L, launch_pair_rows_##L},
-static const ColEntry kCols[] = {XCX_COL_LIST(XCX_COL_ROW)};
-static const RowEntry kRows[] = {XCX_ROW_LIST(XCX_ROW_ROW)};
-static const int kNCols = sizeof(kCols) / sizeof(kCols[0]);
-static const int kNRows = sizeof(kRows) / sizeof(kRows[0]);
 #define XCX_WCOL_ROW(L) {L, launch_wfwd_cols_##L, launch_wpair_cols_##L},
 #define XCX_WROW_ROW(L) {L, launch_wfwd_rows_##L, launch_wpair_rows_##L},
 static const WColEntry kWCols[] = {XCX_WCOL_LIST(XCX_WCOL_ROW)};
@@ -101,57 +95,6 @@ __global__ __launch_bounds__(kNT) void k_wstats(
     __syncthreads();
   }
   if (tid == 0) dst[swl * kStatParts + part] = red[0];
-}
-
-// ---------------------------------------------------------------------------
-// k_stats: one workgroup per station-window; mean (optional) and the scale
-//   1 / (||x'|| * sqrt(N))   with x' the demeaned / one-bit window
-// (normalize off: 1/sqrt(N)).  Double accumulation, fixed order.
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(kNT) void k_stats(
-    const float* __restrict__ traces, long stride_s, long stride_w, int W,
-    int w0, int sw0, int n, int N, int flags, float fixed_norm,
-    SwStat* __restrict__ stats) {
-  __shared__ double red[kNT];
-  const int sw = sw0 + blockIdx.x;    // s * W + wl
-  const int s = sw / W, wl = sw % W;
-  const float* x = traces + (long)s * stride_s + (long)(w0 + wl) * stride_w;
-  const int tid = threadIdx.x;
-  double mean = 0.0;
-  if (flags & XCX_F_DEMEAN) {
-    double acc = 0.0;
-    for (int i = tid; i < n; i += kNT) acc += (double)x[i];
-    red[tid] = acc;
-    __syncthreads();
-    for (int o = kNT / 2; o > 0; o >>= 1) {
-      if (tid < o) red[tid] += red[tid + o];
-      __syncthreads();
-    }
-    mean = red[0] / (double)n;
-    __syncthreads();
-  }
-  const float fmean = (float)mean;
-  double acc = 0.0;
-  for (int i = tid; i < n; i += kNT) {
-    float v = x[i] - fmean;
-    if (flags & XCX_F_ONEBIT) v = (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f);
-    acc += (double)v * (double)v;
-  }
-  red[tid] = acc;
-  __syncthreads();
-  for (int o = kNT / 2; o > 0; o >>= 1) {
-    if (tid < o) red[tid] += red[tid + o];
-    __syncthreads();
-  }
-  if (tid == 0) {
-    double nrm = 1.0;
-    if (flags & XCX_F_NORMALIZE)
-      nrm = (flags & XCX_F_WHITEN) ? (double)fixed_norm : sqrt(red[0]);
-    SwStat st;
-    st.mean = fmean;
-    st.scale = (float)(1.0 / (nrm * sqrt((double)N)));
-    stats[blockIdx.x] = st;
-  }
 }
 
 // ---------------------------------------------------------------------------
@@ -357,11 +300,8 @@ void DevBuf::release() {
 struct xcx_plan {
   xcx_ctx* ctx = nullptr;
   Geom g{};
-  const ColEntry* col = nullptr;
-  const RowEntry* row = nullptr;
   const WColEntry* wcol = nullptr;
   const WRowEntry* wrow = nullptr;
-  bool wave = true;          // one-wave-per-workgroup engine (default)
   DevBuf gramC, gramTiles, gramPidx;   // time-stack cross-spectra [P][spec_pitch], tile list, pair lookup
   bool gram = true;          // stack via the Gram kernel (XCX_GRAM=0: per-element loop)
   const WFusedEntry* dual = nullptr;    // one-launch I2(b-1) + I1(b) kernel, if built for (N1, N2h)
@@ -412,7 +352,7 @@ struct xcx_plan {
   // tables
   DevBuf tw_N1, tw_N2h, tw_unt, tw_N;
   // workspaces
-  DevBuf stats, Tm_f, Tn_f, spectra, T, descs, dtraces, dout, dpairs;
+  DevBuf Tm_f, spectra, T, descs, dtraces, dout, dpairs;
   std::vector<PwDesc> hdescs;
   std::vector<int> bounds;   // launch-batch starts inside one window's P descriptors (pair_order.h); empty: fixed batches
   unsigned long long desc_key = 0;
@@ -482,59 +422,52 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
   // lags then fall outside the linear correlation's support as soon as N >= n (chirp convolutions).
   const long long need = (flags & kPlanShortOperand) ? (long long)n : (long long)n + maxlag;
   // choose N = 2*N1*N2h: smallest supported >= need (or == nfft)
-  const char* eng = getenv("XCX_ENGINE");
-  const bool wave = !(eng && strcmp(eng, "wg") == 0);
   long long best = -1;
   int bi = -1, bj = -1;
-  const int nc = wave ? kNWCols : kNCols, nr = wave ? kNWRows : kNRows;
+  const int nc = kNWCols, nr = kNWRows;
   for (int i = 0; i < nc; ++i)
     for (int j = 0; j < nr; ++j) {
-      const int L1 = wave ? kWCols[i].L : kCols[i].L;
-      const int L2 = wave ? kWRows[j].L : kRows[j].L;
+      const int L1 = kWCols[i].L;
+      const int L2 = kWRows[j].L;
       long long N = 2LL * L1 * L2;
       if (N < need) continue;
       if (nfft > 0 && N != nfft) continue;
-      // among equal N: wave engine prefers long columns (one column per
-      // wave), the workgroup engine the most balanced split
+      // among equal N: long columns (one column per wave)
       bool better = best < 0 || N < best;
       if (!better && N == best) {
-        const int b1 = wave ? kWCols[bi].L : kCols[bi].L;
-        const int b2 = wave ? kWRows[bj].L : kRows[bj].L;
-        // wave engine: longest column up to 2048 (3072 runs at two waves per SIMD)
+        const int b1 = kWCols[bi].L;
+        // longest column up to 2048 (3072 runs at two waves per SIMD)
         auto pref = [](int l) { return l <= 2048 ? l : 1; };
-        better = wave ? (pref(L1) > pref(b1)) : (std::abs(L1 - L2) < std::abs(b1 - b2));
+        better = pref(L1) > pref(b1);
       }
       if (better) { best = N; bi = i; bj = j; }
     }
   // XCX_SEG_FORCE=1 (tests): segmented plan even where one transform would do
   const bool seg_force = getenv("XCX_SEG_FORCE") && atoi(getenv("XCX_SEG_FORCE")) != 0;      // read per call
-  if (seg_force && wave && nfft == 0 && !(flags & (XCX_F_WHITEN | XCX_F_STACK))) best = -1;
+  if (seg_force && nfft == 0 && !(flags & (XCX_F_WHITEN | XCX_F_STACK))) best = -1;
   if (best < 0) {
-    const bool seg_ok = wave && nfft == 0 && !(flags & (XCX_F_WHITEN | XCX_F_STACK));
+    const bool seg_ok = nfft == 0 && !(flags & (XCX_F_WHITEN | XCX_F_STACK));
     if (!seg_ok)
       return set_err(XCX_EUNSUPPORTED,
                      "no supported transform length for n=%d (nfft=%d); "
                      "supported N = 2*N1*N2h up to %d (longer windows: segmented plans, without "
                      "XCX_WHITEN / XCX_STACK / nfft)", n, nfft,
-                     wave ? 2 * kWCols[kNWCols - 1].L * kWRows[kNWRows - 1].L
-                          : 2 * kCols[kNCols - 1].L * kRows[kNRows - 1].L);
+                     2 * kWCols[kNWCols - 1].L * kWRows[kNWRows - 1].L);
     return seg_plan_create(ctx, n, idx_min, idx_max, flags, out);
   }
   HIP_TRY(hipSetDevice(ctx->device));
   xcx_plan* p = new (std::nothrow) xcx_plan();
   if (!p) return set_err(XCX_ENOMEM, "host allocation failed");
   p->ctx = ctx;
-  p->wave = wave;
-  if (wave) { p->wcol = &kWCols[bi]; p->wrow = &kWRows[bj]; }
-  else { p->col = &kCols[bi]; p->row = &kRows[bj]; }
+  p->wcol = &kWCols[bi]; p->wrow = &kWRows[bj];
   Geom& g = p->g;
   g.n = n;
   g.N = (int)best;
-  g.N1 = wave ? kWCols[bi].L : kCols[bi].L;
-  g.N2h = wave ? kWRows[bj].L : kRows[bj].L;
+  g.N1 = kWCols[bi].L;
+  g.N2h = kWRows[bj].L;
   g.N2 = 2 * g.N2h;
   if (const char* ge = getenv("XCX_GRAM")) p->gram = strcmp(ge, "0") != 0;
-  if (wave) {
+  {
     const char* de = getenv("XCX_DUAL");
     if (!(de && strcmp(de, "0") == 0))
       for (int i = 0; i < kNWFused; ++i)
@@ -608,8 +541,8 @@ extern "C" int xcx_plan_destroy(xcx_plan* p) {
     delete p->seg;
     p->seg = nullptr;
   }
-  DevBuf* bufs[] = {&p->tw_N1, &p->tw_N2h, &p->tw_unt, &p->tw_N, &p->stats,
-                    &p->Tm_f, &p->Tn_f, &p->spectra, &p->T, &p->descs,
+  DevBuf* bufs[] = {&p->tw_N1, &p->tw_N2h, &p->tw_unt, &p->tw_N,
+                    &p->Tm_f, &p->spectra, &p->T, &p->descs,
                     &p->dtraces, &p->dout, &p->dpairs, &p->psum, &p->psq, &p->gramC, &p->gramTiles, &p->gramPidx};
   for (DevBuf* b : bufs) b->release();
   delete p;
@@ -717,99 +650,54 @@ static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_
   // station-windows per forward launch: large launches fill the chip
   static const int chunk_cap = getenv("XCX_FWD_CHUNK") ? std::max(1, atoi(getenv("XCX_FWD_CHUNK"))) : 512;
   const int kChunk = std::max(std::min(64, chunk_cap), std::min(chunk_cap, sw_end - sw_begin));
-  const size_t tm_per = (size_t)g.N1 * g.N2h;
   int rc;
   if ((g.flags & XCX_F_WHITEN) && !p->whiten_set)
     return set_err(XCX_EINVAL, "XCX_WHITEN set but xcx_plan_set_whiten() not called");
-  if (p->wave) {
-    const size_t tf_per = (size_t)(g.N2h + 1) * g.N1;
-    if ((rc = p->psum.ensure(ctx, sizeof(double) * kStatParts * kChunk))) return rc;
-    if ((rc = p->psq.ensure(ctx, sizeof(double) * kStatParts * kChunk))) return rc;
-    if ((rc = p->Tm_f.ensure(ctx, sizeof(cf) * tf_per * kChunk))) return rc;
-    for (int b = sw_begin; b < sw_end; b += kChunk) {
-      const int cnt = std::min(kChunk, sw_end - b);
-      {
-        ProfScope ps(p, KID_STATS, cnt);
-        if (g.flags & XCX_F_DEMEAN)
-          hipLaunchKernelGGL(k_wstats<0>, dim3(kStatParts, cnt), dim3(kNT), 0, ctx->stream, traces, stride_s,
-                             stride_w, W, w0, b, g.n, g.flags, (const double*)nullptr, (double*)p->psum.ptr);
-        if ((g.flags & XCX_F_NORMALIZE) && !(g.flags & XCX_F_WHITEN))
-          hipLaunchKernelGGL(k_wstats<1>, dim3(kStatParts, cnt), dim3(kNT), 0, ctx->stream, traces, stride_s,
-                             stride_w, W, w0, b, g.n, g.flags, (const double*)p->psum.ptr, (double*)p->psq.ptr);
-      }
-      HIP_TRY(hipGetLastError());
-      WF1Args f1{};
-      f1.traces = traces; f1.stride_s = stride_s; f1.stride_w = stride_w;
-      f1.W = W; f1.w0 = w0; f1.sw0 = b;
-      f1.psum = (const double*)p->psum.ptr;
-      f1.Tf = (cf*)p->Tm_f.ptr;
-      f1.tw_sub = (const cf*)p->tw_N2h.ptr;
-      f1.tw_unt = (const cf*)p->tw_unt.ptr;
-      f1.tw_N = (const cf*)p->tw_N.ptr;
-      f1.g = g;
-      {
-        ProfScope ps(p, KID_FWD_ROWS, cnt);
-        HIP_TRY(p->wrow->fwd(f1, dim3(g.N1 / kWRB, cnt), ctx->stream));
-      }
-      WF2Args f2{};
-      f2.Tf = (const cf*)p->Tm_f.ptr;
-      f2.psq = (const double*)p->psq.ptr;
-      f2.X = (cf*)p->spectra.ptr;
-      f2.spec_pitch = p->spec_pitch;
-      f2.slot0 = p->fwd_slot_ld ? slot0 : slot0 + b;
-      f2.sw_first = b; f2.slot_w = p->fwd_slot_w; f2.slot_ld = p->fwd_slot_ld;
-      f2.tw_sub = (const cf*)p->tw_N1.ptr;
-      f2.wb0 = p->wb[0]; f2.wb1 = p->wb[1]; f2.wb2 = p->wb[2]; f2.wb3 = p->wb[3];
-      f2.fixed_norm = p->fixed_norm;
-      f2.g = g;
-      {
-        ProfScope ps(p, KID_FWD_COLS, cnt);
-        HIP_TRY(p->wcol->fwd(f2, dim3(g.N2h + 1, cnt), ctx->stream));
-      }
-      p->launches += 4;
-    }
-    return XCX_OK;
-  }
-  if ((rc = p->stats.ensure(ctx, sizeof(SwStat) * kChunk))) return rc;
-  if ((rc = p->Tm_f.ensure(ctx, sizeof(cf) * tm_per * kChunk))) return rc;
-  if ((rc = p->Tn_f.ensure(ctx, sizeof(cf) * g.N1 * kChunk))) return rc;
+  const size_t tf_per = (size_t)(g.N2h + 1) * g.N1;
+  if ((rc = p->psum.ensure(ctx, sizeof(double) * kStatParts * kChunk))) return rc;
+  if ((rc = p->psq.ensure(ctx, sizeof(double) * kStatParts * kChunk))) return rc;
+  if ((rc = p->Tm_f.ensure(ctx, sizeof(cf) * tf_per * kChunk))) return rc;
   for (int b = sw_begin; b < sw_end; b += kChunk) {
     const int cnt = std::min(kChunk, sw_end - b);
     {
       ProfScope ps(p, KID_STATS, cnt);
-      hipLaunchKernelGGL(k_stats, dim3(cnt), dim3(kNT), 0, ctx->stream, traces,
-                         stride_s, stride_w, W, w0, b, g.n, g.N, g.flags,
-                         p->fixed_norm, (SwStat*)p->stats.ptr);
+      if (g.flags & XCX_F_DEMEAN)
+        hipLaunchKernelGGL(k_wstats<0>, dim3(kStatParts, cnt), dim3(kNT), 0, ctx->stream, traces, stride_s,
+                           stride_w, W, w0, b, g.n, g.flags, (const double*)nullptr, (double*)p->psum.ptr);
+      if ((g.flags & XCX_F_NORMALIZE) && !(g.flags & XCX_F_WHITEN))
+        hipLaunchKernelGGL(k_wstats<1>, dim3(kStatParts, cnt), dim3(kNT), 0, ctx->stream, traces, stride_s,
+                           stride_w, W, w0, b, g.n, g.flags, (const double*)p->psum.ptr, (double*)p->psq.ptr);
     }
     HIP_TRY(hipGetLastError());
-    F1Args f1{};
+    WF1Args f1{};
     f1.traces = traces; f1.stride_s = stride_s; f1.stride_w = stride_w;
     f1.W = W; f1.w0 = w0; f1.sw0 = b;
-    f1.stats = (const SwStat*)p->stats.ptr;
-    f1.Tm = (cf*)p->Tm_f.ptr; f1.Tn = (cf*)p->Tn_f.ptr;
+    f1.psum = (const double*)p->psum.ptr;
+    f1.Tf = (cf*)p->Tm_f.ptr;
     f1.tw_sub = (const cf*)p->tw_N2h.ptr;
     f1.tw_unt = (const cf*)p->tw_unt.ptr;
     f1.tw_N = (const cf*)p->tw_N.ptr;
     f1.g = g;
     {
       ProfScope ps(p, KID_FWD_ROWS, cnt);
-      HIP_TRY(p->row->fwd(f1, dim3(g.N1 / kRB, cnt), ctx->stream));
+      HIP_TRY(p->wrow->fwd(f1, dim3(g.N1 / kWRB, cnt), ctx->stream));
     }
-    F2Args f2{};
-    f2.Tm = (const cf*)p->Tm_f.ptr; f2.Tn = (const cf*)p->Tn_f.ptr;
-    f2.stats = (const SwStat*)p->stats.ptr;
-    f2.Xm = (cf*)p->spectra.ptr;
-    f2.Xn = (cf*)p->spectra.ptr + tm_per;
+    WF2Args f2{};
+    f2.Tf = (const cf*)p->Tm_f.ptr;
+    f2.psq = (const double*)p->psq.ptr;
+    f2.X = (cf*)p->spectra.ptr;
     f2.spec_pitch = p->spec_pitch;
-    f2.slot0 = slot0 + b;
+    f2.slot0 = p->fwd_slot_ld ? slot0 : slot0 + b;
+    f2.sw_first = b; f2.slot_w = p->fwd_slot_w; f2.slot_ld = p->fwd_slot_ld;
     f2.tw_sub = (const cf*)p->tw_N1.ptr;
     f2.wb0 = p->wb[0]; f2.wb1 = p->wb[1]; f2.wb2 = p->wb[2]; f2.wb3 = p->wb[3];
+    f2.fixed_norm = p->fixed_norm;
     f2.g = g;
     {
       ProfScope ps(p, KID_FWD_COLS, cnt);
-      HIP_TRY(p->col->fwd(f2, dim3(g.N2h / kCB + 1, cnt), ctx->stream));
+      HIP_TRY(p->wcol->fwd(f2, dim3(g.N2h + 1, cnt), ctx->stream));
     }
-    p->launches += 3;
+    p->launches += 4;
   }
   return XCX_OK;
 }
@@ -818,57 +706,22 @@ static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_
 static int pair_batch(xcx_plan* p, size_t d0, int B, float* out, int nstack, const cf* Xsrc = nullptr) {
   xcx_ctx* ctx = p->ctx;
   const Geom& g = p->g;
-  const size_t tm_per = (size_t)g.N1 * g.N2h;
-  if (p->wave) {
-    WI1Args a{};
-    a.X = Xsrc ? Xsrc : (const cf*)p->spectra.ptr;
-    a.spec_pitch = p->spec_pitch;
-    a.pw = (const PwDesc*)p->descs.ptr + d0;
-    a.B = B;
-    a.nstack = nstack;
-    a.T = (cf*)p->T.ptr;
-    a.tw_sub = (const cf*)p->tw_N1.ptr;
-    a.tw_N = (const cf*)p->tw_N.ptr;
-    a.g = g;
-    const int per_xcd = (g.N2h + 1 + 7) / 8;
-    {
-      ProfScope ps(p, KID_PAIR_COLS, B);
-      HIP_TRY(p->wcol->pair(a, dim3(8u * per_xcd * B), ctx->stream));
-    }
-    WI2Args r{};
-    r.T = (const cf*)p->T.ptr;
-    r.pw = a.pw;
-    r.out = out;
-    r.tw_sub = (const cf*)p->tw_N2h.ptr;
-    r.tw_unt = (const cf*)p->tw_unt.ptr;
-    r.g = g;
-    {
-      ProfScope ps(p, KID_PAIR_ROWS, B);
-      HIP_TRY(p->wrow->pair(r, dim3(g.N1 / kWRB, B), ctx->stream));
-    }
-    p->launches += 2;
-    p->pair_windows += B;
-    return XCX_OK;
-  }
-  I1Args a{};
-  a.Xm = (const cf*)p->spectra.ptr;
-  a.Xn = (const cf*)p->spectra.ptr + tm_per;
+  WI1Args a{};
+  a.X = Xsrc ? Xsrc : (const cf*)p->spectra.ptr;
   a.spec_pitch = p->spec_pitch;
   a.pw = (const PwDesc*)p->descs.ptr + d0;
   a.B = B;
   a.nstack = nstack;
-  a.stack_stride = 1;
   a.T = (cf*)p->T.ptr;
   a.tw_sub = (const cf*)p->tw_N1.ptr;
   a.tw_N = (const cf*)p->tw_N.ptr;
   a.g = g;
-  const int ncbt = g.N2h / kCB + 1;
-  const int per_xcd = (ncbt + 7) / 8;
+  const int per_xcd = (g.N2h + 1 + 7) / 8;
   {
     ProfScope ps(p, KID_PAIR_COLS, B);
-    HIP_TRY(p->col->pair(a, dim3(8u * per_xcd * B), ctx->stream));
+    HIP_TRY(p->wcol->pair(a, dim3(8u * per_xcd * B), ctx->stream));
   }
-  I2Args r{};
+  WI2Args r{};
   r.T = (const cf*)p->T.ptr;
   r.pw = a.pw;
   r.out = out;
@@ -877,7 +730,7 @@ static int pair_batch(xcx_plan* p, size_t d0, int B, float* out, int nstack, con
   r.g = g;
   {
     ProfScope ps(p, KID_PAIR_ROWS, B);
-    HIP_TRY(p->row->pair(r, dim3(g.N1 / kRB, B), ctx->stream));
+    HIP_TRY(p->wrow->pair(r, dim3(g.N1 / kWRB, B), ctx->stream));
   }
   p->launches += 2;
   p->pair_windows += B;
@@ -1171,7 +1024,6 @@ extern "C" int xcx_cc1d_stack_add(xcx_plan* p, const float* traces, int S, int W
   const Geom& g = p->g;
   if (p->seg) return set_err(XCX_EUNSUPPORTED, "segmented (long-window) plans do not stack");
   if (!(g.flags & XCX_F_STACK)) return set_err(XCX_EINVAL, "xcx_cc1d_stack_add needs an XCX_STACK plan");
-  if (!p->wave) return set_err(XCX_EUNSUPPORTED, "xcx_cc1d_stack_add needs the wave engine");
   if ((long long)S * W > 0x7fffffffLL / 2) return set_err(XCX_EINVAL, "S*W too large");
   HIP_TRY(hipSetDevice(ctx->device));
   int rc;
@@ -1319,7 +1171,7 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
   // pair column pass itself (MODE 1: W x 2 column loads per pair): building, writing and re-reading a
   // P x N/2 cross-spectrum buffer only pays once many windows share it (k_gram_mfma was 60 % of xcx_rfft).
   static const int gram_min_w = getenv("XCX_GRAM_MIN_W") ? std::max(2, atoi(getenv("XCX_GRAM_MIN_W"))) : 4;
-  const bool via_gram = stack && p->wave && p->gram && W >= gram_min_w;     // descriptors come from stack_tables()
+  const bool via_gram = stack && p->gram && W >= gram_min_w;     // descriptors come from stack_tables()
   if (!via_gram && (key != p->desc_key || p->hdescs.size() != ndesc)) {
     std::vector<int> perm(P);
     // processing order.  Dual pipelines: launch batches = station groups (pair_order.h: few distinct
@@ -1441,7 +1293,6 @@ extern "C" int xcx_cc1d_prepare(xcx_plan* p, const float* traces, int S, int W, 
   const Geom& g = p->g;
   if (p->seg) return set_err(XCX_EUNSUPPORTED, "xcx_cc1d_prepare does not apply to segmented (long-window) plans");
   if (g.flags & XCX_F_STACK) return set_err(XCX_EUNSUPPORTED, "xcx_cc1d_prepare does not apply to stacking plans");
-  if (!p->wave) return set_err(XCX_EUNSUPPORTED, "xcx_cc1d_prepare needs the wave engine");
   if ((long long)S * W > 0x7fffffffLL / 2) return set_err(XCX_EINVAL, "S*W too large");
   const size_t bytes = sizeof(cf) * p->spec_pitch * (size_t)S * W;
   if (W < 2 || bytes > ((size_t)24 << 30))
@@ -1704,7 +1555,6 @@ static int seg_plan_create(xcx_ctx* ctx, int n, int idx_min, int idx_max, int fl
   xcx_plan* p = new (std::nothrow) xcx_plan();
   if (!p) return set_err(XCX_ENOMEM, "host allocation failed");
   p->ctx = ctx;
-  p->wave = true;
   p->g.n = n;
   p->g.idx_min = idx_min; p->g.idx_max = idx_max;
   p->g.flags = flags & 0xffff;
