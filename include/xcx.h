@@ -100,6 +100,12 @@ int xcx_plan_destroy(xcx_plan* plan);
  * ramps of width ftaper outside, 0 beyond. */
 int xcx_plan_set_whiten(xcx_plan* plan, double sampling_rate, double fmin,
                         double fmax, double ftaper);
+/* Host-only (no GPU): the processing order xcx_cc1d_pairs gives a pair list -- launch batches of at most
+ * `batch` pairs that touch few stations (csrc/pair_order.h: lines of the affine plane AG(2,8) for <= 64
+ * stations, greedy station sets otherwise).  perm[P] = order (indices into `pairs`), bounds[ngroups + 1] =
+ * group starts (bounds must hold P + 1 ints).  Exposed for tests and for callers that want to lay their
+ * output out in processing order. */
+int xcx_pair_groups(const int* pairs, int S, int P, int batch, int* perm, int* bounds, int* ngroups);
 /* tuning: pair-windows per launch batch (default 512) */
 int xcx_plan_set_batch(xcx_plan* plan, int pair_windows_per_batch);
 /* out[0..5] = N, N1, N2, L (= idx_max-idx_min), batch, spectrum floats */

@@ -463,3 +463,38 @@ def test_ccdataset_xarray_conversion_on_a_duck_typed_dataset():
     back.update_xarray(x)
     assert (x['cc'].values == 1.5).all() and (x['status'].values == 1).all() and (x['hash'].values == 'h').all()
     assert not cinit.is_xarray_dataset(x)            # the real type check needs the real xarray
+
+
+def _pair_groups(pairs, S, batch):
+    import ctypes as C
+    from xcorr_amd import _ffi
+    pairs = np.ascontiguousarray(pairs, np.int32).reshape(-1, 2)
+    P = len(pairs)
+    perm = np.empty(P, np.int32)
+    bounds = np.empty(P + 1, np.int32)
+    ng = C.c_int(0)
+    _ffi.check(_ffi.lib().xcx_pair_groups(_ffi.ptr(pairs), S, P, batch, _ffi.ptr(perm), _ffi.ptr(bounds), C.byref(ng)))
+    return perm, bounds[:ng.value + 1]
+
+
+def test_pair_groups_processing_order():
+    """csrc/pair_order.h (host logic, no GPU): every pair exactly once, groups within the batch size, and for the
+    all-pairs list of 64 stations the 72 lines of AG(2, 8): 28 pairs on 8 stations each."""
+    for S, batch in ((64, 28), (64, 25), (16, 28), (30, 25), (100, 28), (3, 28), (2, 4)):
+        pairs = np.array([(i, j) for i in range(S) for j in range(i + 1, S)], np.int32)
+        perm, bounds = _pair_groups(pairs, S, batch)
+        assert sorted(perm.tolist()) == list(range(len(pairs)))
+        sizes = np.diff(bounds)
+        assert bounds[0] == 0 and bounds[-1] == len(pairs) and sizes.min() >= 1 and sizes.max() <= batch
+        stations = [len(set(pairs[perm[a:b]].ravel().tolist())) for a, b in zip(bounds[:-1], bounds[1:])]
+        if (S, batch) == (64, 28):
+            assert len(sizes) == 72 and set(sizes.tolist()) == {28} and set(stations) == {8}
+        # never worse than one new station pair per pair
+        assert sum(stations) <= 2 * len(pairs)
+        if S >= 16:
+            assert sum(stations) / len(pairs) < 0.45          # 8 x 8 tiles in 25-pair cuts: 0.48
+    # arbitrary lists: reversed pairs, auto-pairs, duplicates, a pair listed more often than the batch size
+    rng = np.random.default_rng(3)
+    pairs = np.concatenate([rng.integers(0, 11, size=(60, 2)), [[3, 3], [10, 0], [10, 0]], [[5, 6]] * 9]).astype(np.int32)
+    perm, bounds = _pair_groups(pairs, 11, 4)
+    assert sorted(perm.tolist()) == list(range(len(pairs))) and np.diff(bounds).max() <= 4 and np.diff(bounds).min() >= 1

@@ -56,6 +56,7 @@ SIGNATURES = {
     'xcx_plan_set_whiten': [_vp, C.c_double, C.c_double, C.c_double,
                             C.c_double],
     'xcx_plan_set_batch': [_vp, _i],
+    'xcx_pair_groups': [_vp, _i, _i, _i, _vp, _vp, C.POINTER(_i)],
     'xcx_plan_info': [_vp, _pi],
     'xcx_cc1d_pairs': [_vp, _vp, _i, _i, _l, _l, _vp, _i, _vp, _l, _i],
     'xcx_cc1d': [_vp, _vp, _vp, _i, _vp, _i],

@@ -227,6 +227,13 @@ XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in
   }
 }
 
+// Band-limited spectra (whitened plans, Geom::band_hi): column k2 is exactly zero for k1 in [za, zb], where both
+// k = k1 N2 + k2 and N - k lie above the band.  zb < za: no such stretch (band_hi = N).
+XCX_DEV void band_zero_stretch(const Geom& g, int k2, int& za, int& zb) {
+  za = (g.band_hi >= k2) ? (g.band_hi - k2) / g.N2 + 1 : 0;
+  zb = (g.N - g.band_hi - k2 + g.N2 - 1) / g.N2 - 1;
+}
+
 // per station-window statistics as partial sums (deterministic order):
 // part[sw][p] (p < kStatParts): phase 0 sum(x), phase 1 sum(x'^2)
 constexpr int kStatParts = 16;
@@ -382,10 +389,16 @@ void k_wfwd_cols(WF2Args a) {
   const float wb0 = a.wb0, wb1 = a.wb1, wb2 = a.wb2, wb3 = a.wb3;
   auto in = [=](int m1, int) -> cf { return src[m1]; };
   using CG = ColGeom<RX>;
+  // the out-of-band stretch of a band-limited plan is never stored: the buffer holds zeros there
+  // (zeroed once per allocation by forward()), which is what the whitening gain would produce
+  int za, zb;
+  band_zero_stretch(g, k2, za, zb);
+  const unsigned zlen = (whiten && zb >= za) ? (unsigned)(zb - za + 1) : 0u;
   auto epi = [=](int, int j0, int, cf (&v)[CG::RL]) {
 #pragma unroll
     for (int t = 0; t < CG::RL; ++t) {
       const int k1 = j0 + t * CG::NSL;
+      if ((unsigned)(k1 - za) < zlen) continue;
       cf o = v[t];
       if (whiten) {
         int k = k1 * N2 + k2;
@@ -463,8 +476,8 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
   // before issuing the next (24 serial round trips per wave), and per-lane selects of the offset or of
   // the loaded value cost one VGPR per load and split the gather in two at 128 VGPRs.  Instructions
   // that straddle a band edge load what is stored (zeros included).
-  const int za = (g.band_hi >= k2) ? (g.band_hi - k2) / g.N2 + 1 : 0;
-  const int zb = (g.N - g.band_hi - k2 + g.N2 - 1) / g.N2 - 1;
+  int za, zb;
+  band_zero_stretch(g, k2, za, zb);
   const int zev = (za + 1) & ~1;                                  // first even index inside the range
   const bool zok = zb - zev + 1 >= 2 * kWNT;                      // room for the zero chunk of a 16-byte wave load
   auto zbase = [=](const cf* base, int kb, int span) -> const cf* {

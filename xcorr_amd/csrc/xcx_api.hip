@@ -285,6 +285,7 @@ int DevBuf::ensure(xcx_ctx* ctx, size_t need) {
   bytes = 0;
   HIP_TRY(hipMalloc(&ptr, need));
   bytes = need;
+  gen += 1;
   return XCX_OK;
 }
 void DevBuf::release() {
@@ -355,6 +356,10 @@ struct xcx_plan {
   DevBuf Tm_f, spectra, T, descs, dtraces, dout, dpairs;
   std::vector<PwDesc> hdescs;
   std::vector<int> bounds;   // launch-batch starts inside one window's P descriptors (pair_order.h); empty: fixed batches
+  // spectrum buffers whose out-of-band stretches hold zeros (band-limited plans: the forward column pass
+  // does not store there): {pointer, DevBuf generation, band_hi} of up to two buffers (spectra, spectra_next)
+  struct Zeroed { void* ptr = nullptr; unsigned long long gen = 0; int band_hi = 0; } zeroed[2];
+  int zeroed_next = 0;
   unsigned long long desc_key = 0;
   long long launches = 0, pair_windows = 0;
   // optional per-kernel HIP-event timing (xcx_plan_profile)
@@ -586,6 +591,20 @@ extern "C" int xcx_plan_set_whiten(xcx_plan* p, double fs, double fmin,
   return XCX_OK;
 }
 
+extern "C" int xcx_pair_groups(const int* pairs, int S, int P, int batch, int* perm, int* bounds, int* ngroups) {
+  if (!pairs || !perm || !bounds || !ngroups) return set_err(XCX_EINVAL, "null argument");
+  if (S < 1 || P < 1 || batch < 1) return set_err(XCX_EINVAL, "S, P, batch must be >= 1");
+  for (int i = 0; i < P; ++i)
+    if (pairs[2 * i] < 0 || pairs[2 * i] >= S || pairs[2 * i + 1] < 0 || pairs[2 * i + 1] >= S)
+      return set_err(XCX_EINVAL, "pair %d = (%d,%d) outside [0,%d)", i, pairs[2 * i], pairs[2 * i + 1], S);
+  std::vector<int> pm, bd;
+  pair_groups(pairs, S, P, batch, pm, bd);
+  std::copy(pm.begin(), pm.end(), perm);
+  std::copy(bd.begin(), bd.end(), bounds);
+  *ngroups = (int)bd.size() - 1;
+  return XCX_OK;
+}
+
 extern "C" int xcx_plan_set_batch(xcx_plan* p, int b) {
   if (!p || b < 1 || b > 65535) return set_err(XCX_EINVAL, "batch must be in [1,65535]");
   p->batch = b;
@@ -653,6 +672,18 @@ static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_
   int rc;
   if ((g.flags & XCX_F_WHITEN) && !p->whiten_set)
     return set_err(XCX_EINVAL, "XCX_WHITEN set but xcx_plan_set_whiten() not called");
+  if (g.band_hi < g.N) {
+    // band-limited plan: the forward column pass skips the stores of the out-of-band stretch of every
+    // column (60 % of the spectrum bytes for 0.1-10 Hz at 50 Hz), so the buffer is zeroed once per
+    // allocation and band; the pair pass reads its "stored zeros" from there (wave_kernels.h)
+    bool ok = false;
+    for (auto& z : p->zeroed) ok = ok || (z.ptr == p->spectra.ptr && z.gen == p->spectra.gen && z.band_hi == g.band_hi);
+    if (!ok) {
+      HIP_TRY(hipMemsetAsync(p->spectra.ptr, 0, p->spectra.bytes, ctx->stream));
+      p->zeroed[p->zeroed_next] = {p->spectra.ptr, p->spectra.gen, g.band_hi};
+      p->zeroed_next ^= 1;
+    }
+  }
   const size_t tf_per = (size_t)(g.N2h + 1) * g.N1;
   if ((rc = p->psum.ensure(ctx, sizeof(double) * kStatParts * kChunk))) return rc;
   if ((rc = p->psq.ensure(ctx, sizeof(double) * kStatParts * kChunk))) return rc;
@@ -1178,7 +1209,7 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
     // stations per launch, so few first-touch spectrum fetches); otherwise 8 x 8 station tiles.
     static const bool grouped = !(getenv("XCX_GROUPS") && atoi(getenv("XCX_GROUPS")) == 0);
     p->bounds.clear();
-    if (grouped && p->dual && !p->flow) {
+    if (grouped && p->dual) {          // the flow kernel takes the order (its batches are fixed-size cuts of it)
       pair_groups(pairs, S, P, p->batch, perm, p->bounds);
     } else {
       for (int i = 0; i < P; ++i) perm[i] = i;
