@@ -320,6 +320,10 @@ def test_rotate_and_sensitivity():
     x = np.array([2., 4.], np.float32)
     y = remove_sensitivity(x, 2.0)
     assert y.dtype == np.float32 and np.array_equal(y, [1, 2])
+    from xcorr_amd.stream import normalize
+    z = normalize(np.array([[1., -4., 2.], [0., 0., 0.]], np.float32))
+    assert z.dtype == np.float32 and np.array_equal(z, [[.25, -1., .5], [0., 0., 0.]])
+    assert np.array_equal(normalize(np.array([2., 4.]), norm=-2.), [1., 2.])
 
 
 def test_hasher_restates_reference_serialisation():

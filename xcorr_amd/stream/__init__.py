@@ -10,7 +10,7 @@ obspy itself** (SURVEY 8c).  ``running_rms`` is the reference's own code.
 """
 from .ops import (detrend, filter, taper, decimate, resample, interpolate, running_rms,   # noqa: F401
                   butter_sos, cheby2_lowpass_sos, cosine_taper_length, apply_operations)
-from .segments import merge, trim, remove_sensitivity, rotate_ne_rt                       # noqa: F401
+from .segments import merge, trim, remove_sensitivity, rotate_ne_rt, normalize                       # noqa: F401
 
-__all__ = ['merge', 'trim', 'remove_sensitivity', 'rotate_ne_rt', 'detrend', 'filter', 'taper', 'decimate', 'resample', 'interpolate', 'running_rms',
+__all__ = ['merge', 'trim', 'remove_sensitivity', 'rotate_ne_rt', 'normalize', 'detrend', 'filter', 'taper', 'decimate', 'resample', 'interpolate', 'running_rms',
            'butter_sos', 'cheby2_lowpass_sos', 'cosine_taper_length', 'apply_operations']

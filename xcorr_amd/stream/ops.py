@@ -155,7 +155,7 @@ def running_rms(x, sampling_rate, window=1., ctx=None):
 
 _OPS = {'detrend': detrend, 'filter': filter, 'taper': taper, 'decimate': decimate, 'resample': resample,
         'interpolate': interpolate, 'running_rms': running_rms, 'merge': _seg.merge, 'trim': _seg.trim,
-        'remove_sensitivity': _seg.remove_sensitivity}
+        'remove_sensitivity': _seg.remove_sensitivity, 'normalize': _seg.normalize}
 
 
 def apply_operations(x, sampling_rate, operations, ctx=None, t0=0.0, starttime=None, endtime=None,
@@ -192,6 +192,8 @@ def apply_operations(x, sampling_rate, operations, ctx=None, t0=0.0, starttime=N
             if sensitivity is None:
                 raise ValueError('remove_sensitivity needs the channel sensitivity (inventory)')
             x = _seg.remove_sensitivity(x, sensitivity)
+        elif name == 'normalize':
+            x = _seg.normalize(x, **p)
         elif name == 'detrend':
             x = detrend(x, ctx=ctx, **p)
         elif name == 'taper':

@@ -142,6 +142,21 @@ def remove_sensitivity(x, sensitivity):
     return (x / sensitivity).astype(x.dtype if x.dtype.kind == 'f' else np.float64)
 
 
+def normalize(x, norm=None):
+    """``Trace.normalize(norm=None)``: divide by the absolute maximum of the trace (or by `norm`; a negative
+    `norm` is used by its absolute value, as ObsPy does with a warning).  An all-zero trace is returned
+    unchanged.  Documented ObsPy behaviour restated, unverified vs obspy."""
+    x = np.asarray(x)
+    if norm is None:
+        norm = np.abs(x).max(axis=-1, keepdims=True) if x.size else 1.0
+        norm = np.where(norm == 0, 1.0, norm)
+    else:
+        norm = abs(float(norm))
+        if norm == 0:
+            return x
+    return (x / norm).astype(x.dtype if x.dtype.kind == 'f' else np.float64)
+
+
 def rotate_ne_rt(n, e, back_azimuth):
     """``rotate('NE->RT', back_azimuth)`` (obspy.signal.rotate.rotate_ne_rt): degrees from
     north of the direction from station to source.  Returns (radial, transverse)."""
