@@ -26,27 +26,54 @@ def run(budget=60.0, seed=0, ctx=None):
         imin = int(rng.integers(0, full)); imax = int(rng.integers(imin + 1, full + 1))
     flags = dict(normalize=bool(rng.random() < 0.7), demean=bool(rng.random() < 0.4), onebit=bool(rng.random() < 0.3))
     stack = bool(rng.random() < 0.4)
+    # random whitening band (band-limited spectrum loads / stores): from a sliver to nearly the whole band,
+    # zero or wide flanks; every planner size, stacked or not
+    wh = None
+    if rng.random() < 0.35 and n >= 16:
+        fs = 50.0
+        fmin = float(rng.uniform(0.0, 0.35)) * fs / 2
+        fmax = float(rng.uniform(fmin / (fs / 2) + 0.02, 0.98)) * fs / 2
+        ftaper = float(rng.choice([0.0, rng.uniform(0.0, 0.1) * fs / 2]))
+        if flags['demean'] and fmin - ftaper <= 0.02 * fs / 2:
+            # whitening maps the DC bin of a demeaned window (pure rounding noise, arbitrary phase) to +-g(0):
+            # ill-conditioned in any precision, so keep DC outside the band when the window is demeaned
+            fmin = ftaper + 0.02 * fs / 2
+            fmax = max(fmax, fmin + 0.02 * fs / 2)
+        wh = (fs, fmin, fmax, ftaper)
+        flags['normalize'] = True
     allp = [(i, j) for i in range(S) for j in range(S)]
     k = int(rng.integers(1, len(allp) + 1))
     pairs = np.array([allp[i] for i in rng.choice(len(allp), k, replace=False)], np.int32)
     tr = (rng.standard_normal((S, T)) + rng.uniform(-1, 1)).astype(np.float32)
-    plan = CCPlan(ctx, n, imin, imax, stack=stack, **flags)
+    if flags['demean']:
+        # float32 conditioning of x - mean(x): a window whose samples nearly coincide (tiny n) loses
+        # eps * max|x| / rms(x - mean) of relative accuracy in ANY float32 implementation -- skip those
+        cond = 0.0
+        for w in range(W):
+            seg = tr[:, w * hop:w * hop + n].astype(np.float64)
+            dev = np.sqrt(((seg - seg.mean(axis=1, keepdims=True)) ** 2).mean(axis=1))
+            cond = max(cond, float((np.abs(seg).max(axis=1) / np.maximum(dev, 1e-300)).max()))
+        if cond > 20.0:
+            continue
+    plan = CCPlan(ctx, n, imin, imax, stack=stack, whiten=wh, **flags)
     if os.environ.get('FUZZ_VERBOSE'):
         print(cases, dict(n=n, W=W, hop=hop, S=S, imin=imin, imax=imax, stack=stack, P=len(pairs), N1=plan.N1, N2=plan.N2, batch=plan.batch, **flags), flush=True)
     got = plan.pairs(tr, pairs, W, hop)
+    g = R.whiten_weights(plan.N, *wh) if wh else None
+    kw = dict(whiten=g, nfft=plan.N) if wh else {}
     ref = R.cc_pairs(tr, pairs, n, hop, normalize=flags['normalize'], index_min=imin, index_max=imax,
-                     onebit_=flags['onebit'], demean_=flags['demean'], dtype=np.float64)[:, :W]
+                     onebit_=flags['onebit'], demean_=flags['demean'], dtype=np.float64, **kw)[:, :W]
     if stack:
         ref = ref.sum(axis=1)
     scale = np.abs(R.cc_pairs(tr, pairs, n, hop, normalize=flags['normalize'], onebit_=flags['onebit'],
-                              demean_=flags['demean'], dtype=np.float64)[:, :W]).max()
+                              demean_=flags['demean'], dtype=np.float64, **kw)[:, :W]).max()
     if stack:
         scale *= W
     err = float(np.abs(got - ref).max() / max(scale, 1e-30))
     worst = max(worst, err); cases += 1
     tol = 1e-5          # one-bit after demean decides its signs in float64 on the GPU, like the oracle
     if not (err < tol):
-        raise AssertionError(f'{dict(n=n, W=W, hop=hop, S=S, imin=imin, imax=imax, stack=stack, P=len(pairs), **flags)}: {err}')
+        raise AssertionError(f'{dict(n=n, W=W, hop=hop, S=S, imin=imin, imax=imax, stack=stack, P=len(pairs), whiten=wh, **flags)}: {err}')
     plan.close()
   return cases, worst
 
