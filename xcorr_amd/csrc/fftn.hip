@@ -143,7 +143,7 @@ int bluestein_core(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom
   xcx_plan* plan = ctx->bs_plan[slot];
   const long ld = (g.nout + 31) / 32 * 32;
   // rows per pass: bounded workspace (traces + spectra scale with np)
-  const long chunk = std::max<long>(1, std::min<long>(std::min<long>(batch, 256), ((long)256 << 20) / (16 * g.np)));
+  const long chunk = std::max<long>(1, std::min<long>(std::min<long>(batch, 256), ((long)1024 << 20) / (16 * g.np)));
   DevBuf &tr = ctx->scratch[1], &lin = ctx->scratch[2], &din = ctx->scratch[4], &dout = ctx->scratch[5];
   if ((rc = tr.ensure(ctx, sizeof(float) * 2 * g.np * (chunk + 2)))) return rc;
   if ((rc = lin.ensure(ctx, sizeof(float) * ld * 2 * chunk))) return rc;
