@@ -82,6 +82,13 @@ __global__ __launch_bounds__(256, 3) void k_gram_mfma(GramArgs a) {
   const int quad = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if (quad >= nq || (blockIdx.x >> 3) >= per_xcd) return;
   const int f0 = quad * 4;
+  if (a.g.band_hi < a.g.N) {
+    // spectrum element e = k2 N1 + k1; N1 is a multiple of 4, so a quad lies in one column
+    const int k2 = f0 / a.g.N1, k1 = f0 - k2 * a.g.N1;
+    int za, zb;
+    band_zero_stretch(a.g, k2, za, zb);
+    if (zb >= za && k1 >= za && k1 + 3 <= zb) return;       // every spectrum is zero here, and so is G
+  }
   const int S = a.S, W = a.W;
   const bool two = S > 32;
   f32x16 gr00 = {0}, gr01 = {0}, gr11 = {0}, gi00 = {0}, gi01 = {0}, gi11 = {0};

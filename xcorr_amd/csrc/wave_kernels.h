@@ -1128,6 +1128,8 @@ struct GramArgs {
   cf* C; size_t c_pitch;            // C[p*c_pitch + k]
   int accumulate;                   // 0: C = G;  1: C += G (multi-day stack, xcx_cc1d_stack_add)
   int ldw;                          // slots per station (>= W; 0: W): X[(s*ldw + w)*spec_pitch + k]
+  Geom g;                           // band-limited plans (g.band_hi < g.N): frequency quads inside the zero stretch of
+                                    // their column are skipped -- C is zeroed once per allocation and never written there
 };
 
 hipError_t launch_gram(const GramArgs& a, hipStream_t s);

@@ -358,7 +358,7 @@ struct xcx_plan {
   std::vector<int> bounds;   // launch-batch starts inside one window's P descriptors (pair_order.h); empty: fixed batches
   // spectrum buffers whose out-of-band stretches hold zeros (band-limited plans: the forward column pass
   // does not store there): {pointer, DevBuf generation, band_hi} of up to two buffers (spectra, spectra_next)
-  struct Zeroed { void* ptr = nullptr; unsigned long long gen = 0; int band_hi = 0; } zeroed[2];
+  struct Zeroed { void* ptr = nullptr; unsigned long long gen = 0; int band_hi = 0; } zeroed[2], gram_zeroed;
   int zeroed_next = 0;
   unsigned long long desc_key = 0;
   long long launches = 0, pair_windows = 0;
@@ -994,7 +994,15 @@ static int stack_gram(xcx_plan* p, int S, int W, int P, int accumulate, int ldw 
   const Geom& g = p->g;
   int rc;
   if ((rc = p->gramC.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)P))) return rc;
+  if (g.band_hi < g.N && (p->gram_zeroed.ptr != p->gramC.ptr || p->gram_zeroed.gen != p->gramC.gen ||
+                          p->gram_zeroed.band_hi != g.band_hi)) {
+    // band-limited plan: the Gram kernel skips the out-of-band frequency quads, which therefore hold the
+    // zeros of this one fill for the lifetime of the buffer (the pair pass reads its stored zeros from them)
+    HIP_TRY(hipMemsetAsync(p->gramC.ptr, 0, p->gramC.bytes, ctx->stream));
+    p->gram_zeroed = {p->gramC.ptr, p->gramC.gen, g.band_hi};
+  }
   GramArgs ga{};
+  ga.g = g;
   ga.X = (const cf*)p->spectra.ptr;
   ga.spec_pitch = p->spec_pitch;
   ga.S = S; ga.W = W;
