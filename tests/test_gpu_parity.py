@@ -454,3 +454,24 @@ def test_output_buffers_are_validated(ctx):
     with pytest.raises(ValueError):
         plan.cc(tr[:1, :n], tr[1:2, :n], out=np.empty((1, plan.L))[:, ::2])
     plan.close()
+
+
+def test_tiny_windows_single_station(ctx):
+    """Edges of the pair / window API: windows of 1, 2, 3 and 5 samples, a single station (auto-pair only), a
+    single window, raw / normalised / stacked -- and the two-input form cc(x, y) at the same sizes."""
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 5):
+        for S, W in ((1, 1), (2, 1), (3, 2)):
+            hop = max(1, n // 2)
+            tr = rng.standard_normal((S, (W - 1) * hop + n)).astype(np.float32) + 0.5
+            pairs = np.array([(i, j) for i in range(S) for j in range(i, S)], np.int32)
+            for kw in (dict(normalize=True), dict(normalize=False), dict(normalize=True, stack=True)):
+                plan = X.CCPlan(ctx, n, **kw)
+                got = plan.pairs(tr, pairs, W, hop)
+                ref = R.cc_pairs(tr, pairs, n, hop, normalize=kw['normalize'], dtype=np.float64)
+                if kw.get('stack'):
+                    ref = ref.sum(axis=1)
+                assert got.shape == ref.shape and relerr(got, ref) < TOL, (n, S, W, kw)
+                plan.close()
+            x, y = tr[:1, :n], tr[-1:, :n]
+            assert np.abs(X.CCPlan(ctx, n).cc(x, y)[0] - R.cc(x[0], y[0], normalize=True, dtype=np.float64)).max() < TOL
