@@ -333,16 +333,40 @@ void k_wfwd_rows(WF1Args a) {
   fft_stage_c<N2h, RX::R1, RX::R0, kWRB, kWNT, false, true, false>(b1, lds_ld, to_lds);
   group_sync<kWNT>();
   cf* __restrict__ Tf = a.Tf + (size_t)sw * (size_t)(N2h + 1) * N1;
-  for (int i = tid_of<kWNT>(); i < kWRB * N2h; i += kWNT) {
-    const int r = i % kWRB, k = i / kWRB;
+  // Hermitian untangle + four-step factor, fully unrolled: lane (r, kq) = (tid % 16, tid / 16) takes the bins
+  // k = kq + 4 it of its row.  Both twiddles advance by a constant factor from one bin to the next
+  // (w_N2^4 and w_N^(4 m1)), so they are formed by multiplication and re-seeded from the tables every 8 bins;
+  // all table loads are issued up front.  (As a rolled loop with three table lookups per bin the epilogue
+  // was 30 serialised load round trips per wave.)
+  {
+    constexpr int EIT = kWRB * N2h / kWNT;                 // bins per lane
+    constexpr int NSEED = (EIT + 7) / 8;
+    static_assert((kWRB * N2h) % kWNT == 0, "row length must be a multiple of 4");
+    const int r = tid_of<kWNT>() % kWRB, kq = tid_of<kWNT>() / kWRB;
     const int m1 = row0 + r;
-    const cf u = lds[k * kWRB + r];
-    const cf v = cconj(lds[((k == 0) ? 0 : (N2h - k)) * kWRB + r]);
-    const cf sm = cadd(u, v), df = csub(u, v);
-    const cf e = cmul(a.tw_unt[k], df);
-    cf H = make_float2(0.5f * (sm.x + e.y), 0.5f * (sm.y - e.x));
-    H = cmul(H, twN_lookup(a.tw_N, (unsigned)m1 * (unsigned)k));
-    Tf[k * N1 + m1] = H;
+    cf su[NSEED], sn[NSEED];
+#pragma unroll
+    for (int j = 0; j < NSEED; ++j) {
+      const int ks = kq + 32 * j < N2h ? kq + 32 * j : N2h - 1;      // clamped: unused past the last bin
+      su[j] = *uoff(a.tw_unt, (unsigned)ks);
+      sn[j] = twN_lookup(a.tw_N, (unsigned)m1 * (unsigned)ks);
+    }
+    const cf du = *uoff(a.tw_unt, 4u);                     // w_N2^4
+    const cf dn = twN_lookup(a.tw_N, 4u * (unsigned)m1);   // w_N^(4 m1)
+    cf tu = su[0], tn = sn[0];
+    static_for<EIT>([&](auto ic) {
+      constexpr int it = decltype(ic)::value;
+      const int k = kq + 4 * it;
+      if constexpr (it % 8 == 0) { tu = su[it / 8]; tn = sn[it / 8]; }
+      else { tu = cmul(tu, du); tn = cmul(tn, dn); }
+      const cf u = lds[k * kWRB + r];
+      const cf v = cconj(lds[((k == 0) ? 0 : (N2h - k)) * kWRB + r]);
+      const cf sm = cadd(u, v), df = csub(u, v);
+      const cf e = cmul(tu, df);
+      cf H = make_float2(0.5f * (sm.x + e.y), 0.5f * (sm.y - e.x));
+      H = cmul(H, tn);
+      Tf[k * N1 + m1] = H;
+    });
   }
   if (tid_of<kWNT>() < kWRB) {
     const int r = tid_of<kWNT>(), m1 = row0 + r;
