@@ -159,6 +159,26 @@ def test_pairs_engine(ctx, kw):
     plan.close()
 
 
+def test_whitening_band_edge_next_to_a_bin(ctx):
+    # band edges a hair inside/outside a frequency bin (1-2e-5 bins: below float32 resolution):
+    # the float edges the kernels compare against must keep the double-precision decision for every bin
+    S, n, hop, W = 3, 3000, 1500, 2
+    tr = R.synthetic_traces(S, hop * (W - 1) + n)
+    pairs = R.all_pairs(S)
+    N = X.CCPlan(ctx, n).N
+    fs = 50.
+    for lo_bin, hi_bin in ((300 + 1e-5, 1500 - 2e-5), (300 - 1e-5, 1500 + 2e-5)):
+        wh = (fs, lo_bin * fs / N, hi_bin * fs / N, 0.)
+        plan = X.CCPlan(ctx, n, whiten=wh)
+        assert plan.N == N
+        g = R.whiten_weights(N, *wh)
+        assert np.count_nonzero(g) == (1199 if lo_bin > 300 else 1201)
+        assert np.float32(lo_bin) == 300 and np.float32(hi_bin) == 1500
+        ref = R.cc_pairs(tr, pairs, n, hop, dtype=np.float64, whiten=g, nfft=N)
+        assert relerr(plan.pairs(tr, pairs, W, hop), ref) < TOL
+        plan.close()
+
+
 def test_pairs_unbiased_and_order(ctx):
     S, n, hop, W = 4, 2000, 1000, 3
     tr = R.synthetic_traces(S, hop * (W - 1) + n)
@@ -318,7 +338,7 @@ def test_rccl_stack_reduce_single_rank(ctx):
 def test_stack_gram_many_stations_and_odd_pairs(ctx, monkeypatch):
     """Time-stack through the Gram (batched rank-W update) kernel: 11 stations
     (two 8-station tiles, ragged), pairs in arbitrary order with i > j, an
-    auto-pair and a duplicate; also the per-element stack loop (XCX_GRAM=0)."""
+    auto-pair and a duplicate; also the two-window stack that is summed in the pair column pass."""
     S, n, hop, W = 11, 1200, 600, 5
     tr = R.synthetic_traces(S, hop * (W - 1) + n)
     rng = np.random.default_rng(5)
@@ -328,11 +348,10 @@ def test_stack_gram_many_stations_and_odd_pairs(ctx, monkeypatch):
     got = X.CCPlan(ctx, n, stack=True).pairs(tr, pairs, W, hop)
     assert got.shape == (len(pairs), 2 * n - 1)
     assert relerr(got, ref) < TOL
-    monkeypatch.setenv('XCX_GRAM', '0')
-    got0 = X.CCPlan(ctx, n, stack=True).pairs(tr, pairs, W, hop)
-    assert relerr(got0, ref) < TOL
+    ref2 = R.cc_pairs(tr[:, :hop + n], pairs, n, hop, dtype=np.float64).sum(axis=1)          # W = 2: no Gram pass
+    got2 = X.CCPlan(ctx, n, stack=True).pairs(tr[:, :hop + n], pairs, 2, hop)
+    assert relerr(got2, ref2) < TOL
     # with one-bit + whitening the stack is still the sum of the per-window CCFs
-    monkeypatch.delenv('XCX_GRAM')
     kw = dict(onebit=True, demean=True, whiten=(50., 1., 10., .5))
     per = X.CCPlan(ctx, n, **kw).pairs(tr, pairs, W, hop).astype(np.float64).sum(axis=1)
     st = X.CCPlan(ctx, n, stack=True, **kw).pairs(tr, pairs, W, hop)

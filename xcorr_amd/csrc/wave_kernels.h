@@ -456,8 +456,8 @@ struct WI1Args {
 
 // column body shared by the pair kernels (separate, dual, flow): pair-window
 // descriptor d, column k2, T slot base `T`
-// MODE 0: C = X_a conj X_b;  1: sum of that over nstack consecutive slots;
-// 2: C is read from a precomputed cross-spectrum (slot_a of the Gram buffer)
+// MODE 0: C = X_a conj X_b;  1: sum of that over TWO consecutive slots (nstack == 2);
+// 2: C is read from a precomputed cross-spectrum (slot_a of the Gram buffer; nstack < 0)
 template <class RX, int MODE>
 XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_t spec_pitch,
                            const PwDesc d, int nstack, int k2, cf* __restrict__ T,
@@ -510,10 +510,10 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
   };
   auto in = [=](int k1, int kb) -> cf {
     if constexpr (MODE == 1) {
-      cf acc = cmulc(*uoff(A, (unsigned)k1), *uoff(Bp, (unsigned)k1));
-      for (int w = 1; w < nstack; ++w)
-        acc = cadd(acc, cmulc(A[k1 + w * sstride], Bp[k1 + w * sstride]));
-      return acc;
+      // exactly two windows per station (the chirp convolutions of fftn.hip), four loads and no loop: as a
+      // loop over nstack windows every call waited for its own loads -- 24 serial round trips per wave
+      return cadd(cmulc(*uoff(A, (unsigned)k1), *uoff(Bp, (unsigned)k1)),
+                  cmulc(*uoff(A, (unsigned)k1 + sstride), *uoff(Bp, (unsigned)k1 + sstride)));
     } else if constexpr (MODE == 2) {
       return *uoff(zbase(A, kb, kWNT), (unsigned)k1);
     } else {

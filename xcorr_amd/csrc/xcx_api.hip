@@ -304,7 +304,6 @@ struct xcx_plan {
   const WColEntry* wcol = nullptr;
   const WRowEntry* wrow = nullptr;
   DevBuf gramC, gramTiles, gramPidx;   // time-stack cross-spectra [P][spec_pitch], tile list, pair lookup
-  bool gram = true;          // stack via the Gram kernel (XCX_GRAM=0: per-element loop)
   const WFusedEntry* dual = nullptr;    // one-launch I2(b-1) + I1(b) kernel, if built for (N1, N2h)
   // windows too long for one transform (n + max|lag| beyond the planner's table, e.g. the reference's
   // production setting window_length = 86400 s, clip_lag = (0, 9 h): scripts/cc.py:25-29): the
@@ -471,7 +470,6 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
   g.N1 = kWCols[bi].L;
   g.N2h = kWRows[bj].L;
   g.N2 = 2 * g.N2h;
-  if (const char* ge = getenv("XCX_GRAM")) p->gram = strcmp(ge, "0") != 0;
   {
     const char* de = getenv("XCX_DUAL");
     if (!(de && strcmp(de, "0") == 0))
@@ -561,10 +559,15 @@ extern "C" int xcx_plan_set_whiten(xcx_plan* p, double fs, double fmin,
   if (!(fs > 0) || !(fmin >= 0) || !(fmax > fmin) || ftaper < 0)
     return set_err(XCX_EINVAL, "bad whitening band");
   const double bin = (double)p->g.N / fs;   // bins per Hz
-  p->wb[0] = (float)((fmin - ftaper) * bin);
-  p->wb[1] = (float)(fmin * bin);
-  p->wb[2] = (float)(fmax * bin);
-  p->wb[3] = (float)((fmax + ftaper) * bin);
+  // band edges in bins, float for the kernels; rounding to float must not carry an edge across an integer bin
+  // (fmax * bin = 21377.9994 rounds to 21378.0f and would admit bin 21378): lower edges compare k >= edge,
+  // upper edges k <= edge, so step the float back to the double's side of the integer it crossed
+  auto lower = [](double e) { float f = (float)e; return ((double)f < e && ceil((double)f) < ceil(e)) ? nextafterf(f, INFINITY) : f; };
+  auto upper = [](double e) { float f = (float)e; return ((double)f > e && floor((double)f) > floor(e)) ? nextafterf(f, -INFINITY) : f; };
+  p->wb[0] = lower((fmin - ftaper) * bin);
+  p->wb[1] = lower(fmin * bin);
+  p->wb[2] = upper(fmax * bin);
+  p->wb[3] = upper((fmax + ftaper) * bin);
   // Parseval norm of the ideal whitened spectrum |X[k]| = g[k]
   const int N = p->g.N;
   double acc = 0.0;
@@ -1206,11 +1209,10 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
   key = fnv(hdr, sizeof hdr, key);
   key = fnv(&ld_out, sizeof ld_out, key) & ~1ULL;      // even: never equal to a stack_tables() key (odd)
   const size_t ndesc = stack ? (size_t)P : (size_t)P * W;
-  // Stacks of very few windows (the chirp convolutions of fftn.hip stack W = 2) sum the products in the
-  // pair column pass itself (MODE 1: W x 2 column loads per pair): building, writing and re-reading a
-  // P x N/2 cross-spectrum buffer only pays once many windows share it (k_gram_mfma was 60 % of xcx_rfft).
-  static const int gram_min_w = getenv("XCX_GRAM_MIN_W") ? std::max(2, atoi(getenv("XCX_GRAM_MIN_W"))) : 4;
-  const bool via_gram = stack && p->gram && W >= gram_min_w;     // descriptors come from stack_tables()
+  // Stacks of TWO windows (the chirp convolutions of fftn.hip) sum the two products in the pair column pass
+  // itself (MODE 1: four column loads per pair, no loop): building, writing and re-reading a P x N/2
+  // cross-spectrum buffer only pays once several windows share it (k_gram_mfma was 60 % of xcx_rfft).
+  const bool via_gram = stack && W >= 3;             // descriptors come from stack_tables()
   if (!via_gram && (key != p->desc_key || p->hdescs.size() != ndesc)) {
     std::vector<int> perm(P);
     // processing order.  Dual pipelines: launch batches = station groups (pair_order.h: few distinct
