@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256) void k_mix(Args p) {
     char* C = p.C + ((size_t)u * p.c) % (p.nC - p.c + 1) / 256 * 256;
     // each wave moves its quarter of the unit; 8 wave-instructions of each kind in flight
     const size_t ra = p.a / 4, rb = p.b / 4, rc = p.c / 4;
-    const size_t nra = ra / (64 * RW), nrb = rb / (64 * TW), nrc = rc / (64 * (CW == 32 ? 16 : CW));
+    const size_t nra = ra / (64 * RW), nrb = rb / (64 * (TW == 12 ? 8 : TW)), nrc = rc / (64 * (CW >= 32 ? 16 : CW));
     const size_t steps = nra > nrb ? (nra > nrc ? nra : nrc) : (nrb > nrc ? nrb : nrc);
     for (size_t i = 0; i < steps; i += 8) {
       float v[8];
@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256) void k_mix(Args p) {
         const size_t j = i + k;
         if (j < nrb) {
           if (TW == 16) *reinterpret_cast<f4*>(B + wave * rb + j * 1024 + lane * 16) = f4{v[k], v[k], v[k], v[k]};
+          else if (TW == 12) *reinterpret_cast<f2*>(B + wave * rb + j * 512 + lane * 8) = f2{v[k], v[k]};   // round 3: 512 contiguous bytes
           else {   // 4 segments of 128 B (16 lanes x 8 B), 15488 B apart: the T tile store of a column wave
             const size_t seg = (size_t)(lane >> 4) * 15488 + (lane & 15) * 8;
             const size_t base = (wave * rb + (j / 121) * 4 * 15488 + (j % 121) * 128) % (rb * 4 - 4 * 15488);
@@ -56,6 +57,10 @@ __global__ __launch_bounds__(256) void k_mix(Args p) {
           if (CW == 32) {   // 16 B per lane, four 256-byte segments (16 lanes x 16 B) 6144 B apart: WG-cooperative CCF store
             const size_t seg = (size_t)(lane >> 4) * 6144 + (lane & 15) * 16;
             const size_t base = (wave * rc + (j / 24) * 4 * 6144 + (j % 24) * 256) % (rc * 4 - 4 * 6144);
+            __builtin_nontemporal_store(f4{v[k], v[k], v[k], v[k]}, reinterpret_cast<f4*>(C + base + seg));
+          } else if (CW == 64) {   // 16 B per lane, two 512-byte segments (32 lanes x 16 B) 6144 B apart: 128-row tiles
+            const size_t seg = (size_t)(lane >> 5) * 6144 + (lane & 31) * 16;
+            const size_t base = (wave * rc + (j / 12) * 2 * 6144 + (j % 12) * 512) % (rc * 4 - 2 * 6144);
             __builtin_nontemporal_store(f4{v[k], v[k], v[k], v[k]}, reinterpret_cast<f4*>(C + base + seg));
           } else if (CW == 16) __builtin_nontemporal_store(f4{v[k], v[k], v[k], v[k]}, reinterpret_cast<f4*>(C + wave * rc + j * 1024 + lane * 16));
           else if (CW == 8) __builtin_nontemporal_store(f2{v[k], v[k]}, reinterpret_cast<f2*>(C + wave * rc + j * 512 + lane * 8));
@@ -109,5 +114,15 @@ int main() {
   Args r = p; r.b = 0; r.c = 0;
   run<16, 16, 16>("reads only, 16 B/lane", r, e0, e1);
   run<8, 16, 16>("reads only, 8 B/lane", r, e0, e1);
+  // round 3: 1.74 MB of reads per unit (T + the band-limited, station-grouped spectra), T tile stores as 512 contiguous bytes
+  Args t = p; t.a = (size_t)(1.74 * MB) / 4096 * 4096;
+  printf("round-3 mix per unit: %.2f MB read + %.2f MB ring write + %.2f MB nt stream write\n", t.a / 1e6, t.b / 1e6, t.c / 1e6);
+  run<16, 16, 16>("ideal: 16 B/lane everywhere", t, e0, e1);
+  run<8, 12, 32>("round-3 shapes: 8 B reads, 8 B x 512 B ring, 16 B 4 x 256 B stream", t, e0, e1);
+  run<8, 12, 64>("  ... with a 2 x 512 B stream (128-row tiles)", t, e0, e1);
+  run<8, 12, 32>("round-3 shapes again", t, e0, e1);
+  run<8, 12, 64>("  ... with a 2 x 512 B stream again", t, e0, e1);
+  run<8, 12, 16>("  ... with a contiguous 16 B/lane stream", t, e0, e1);
+  run<16, 12, 32>("  ... with 16 B/lane reads", t, e0, e1);
   return 0;
 }
