@@ -39,7 +39,7 @@ using namespace xcx;
 namespace {
 
 constexpr int NT = 256;
-constexpr int CB = 16;
+constexpr int CB = 16;   // columns per workgroup: 8 (64-byte segments, 4 workgroups per CU) measured +3 %, 32 (1 per CU) -28 %
 
 // LDS index padding of the row kernels: one extra slot per 16 keeps the stride-16 /
 // stride-256 stage writes off a single bank group
@@ -314,7 +314,9 @@ int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const int2* dpa
   if ((rc = S1.ensure(ctx, rowb * g.F * T))) return rc;
   if ((rc = S2.ensure(ctx, rowb * P1 * T))) return rc;
   // pairs per pass: 512 MiB of intermediate T2 (larger passes amortise the launch tails; keeping
-  // T2 inside the 256 MiB Infinity Cache measured 5-10% slower, not faster)
+  // T2 inside the 256 MiB Infinity Cache measured 5-10% slower, not faster -- and two overlapped
+  // chains of 4-6 pair passes on their own streams, T2 cache-resident, measured the same 51 k
+  // pairs/s as this single stream (round 3): the two kernels are not HBM-bound)
   const int PB = (int)std::max<size_t>(1, std::min<size_t>((size_t)P, ((size_t)512 << 20) / (rowb * P1)));
   if ((rc = T2.ensure(ctx, rowb * P1 * PB))) return rc;
   if ((rc = misc.ensure(ctx, sizeof(double) * (size_t)T * g.F + (sizeof(float) + sizeof(long long)) * (size_t)P1 * PB + 64)))
