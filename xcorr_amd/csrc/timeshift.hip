@@ -7,9 +7,12 @@
 //     h[m] = (1/n) [ sin((n-1) pi u)/sin(pi u) + cos(pi n alpha) (-1)^m ],  u = m/n - alpha,
 //     alpha = delay * fN / (n/2)   (cycles per frequency bin),
 // which needs no length-n FFT (n = 359 998 = 2 * 179 999 has a prime factor): the
-// kernel is generated analytically in float64 on the device, the circular
-// convolution is the linear cross-correlation engine at a fast length
-// N >= 2n-1 followed by the wrap-around fold  y[m] = R[m] + R[m-n].
+// kernel is generated analytically in float64 on the device and the circular
+// convolution runs on the linear cross-correlation engine at a fast length N >= 2n-1:
+// the row is correlated against TWO periods of the kernel (2n-1 samples), so the n retained
+// lags ARE the circular convolution and the pair pass writes y directly (round 3; before: one
+// period, all 2n-1 lags written, then a fold pass y[m] = R[m] + R[m-n] -- kept for rows longer
+// than one transform, which go through the block decomposition).
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cmath>
@@ -31,7 +34,7 @@ using namespace xcx;
   } while (0)
 
 int xcx_internal_forward(xcx_plan* p, const float* traces, long stride_s, long stride_w,
-                         int W, int w0, int sw_begin, int sw_end, int slot0);
+                         int W, int w0, int sw_begin, int sw_end, int slot0, int n_valid);
 int xcx_internal_pairs(xcx_plan* p, const PwDesc* hdesc, int count, float* out);
 int xcx_internal_spectra(xcx_plan* p, size_t slots);
 bool xcx_internal_segmented(xcx_plan* p);
@@ -49,7 +52,7 @@ namespace {
 // Odd n (only reachable through the fft/ifft path, which keeps every sample): all n frequencies
 // |k| <= (n-1)/2 exist and  h[m] = sin(n pi u) / (n sin(pi u)) = -(-1)^m sin(pi n alpha) / (n sin(pi u)),
 // limit 1 at u -> 0.
-__global__ void k_dirichlet(float* __restrict__ hr, long n, long rows, const double* __restrict__ alpha) {
+__global__ void k_dirichlet(float* __restrict__ hr, long n, long rows, const double* __restrict__ alpha, int ext) {
   // grid (ceil(n / 256), rows): no 64-bit division per sample
   const long r = blockIdx.y;
   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -74,7 +77,15 @@ __global__ void k_dirichlet(float* __restrict__ hr, long n, long rows, const dou
     if (fabs(su) < 1e-12) h = ((double)(n - 1) + ca * sgn) * inv_n;
     else h = -sgn * sa * (cu / su) * inv_n;
   }
-  hr[r * n + t] = (float)h;
+  if (!ext) {
+    hr[r * n + t] = (float)h;
+  } else {
+    // two periods, g[j] = h[(n-1-j) mod n], j < 2n-1: with R[lag] = sum_j x[j+lag] g[j] (x zero beyond n samples)
+    // the lags -(n-1) .. 0 are y[m], m = n-1+lag.  h[m] = this thread's value (m = (-t) mod n).
+    float* g = hr + r * (2 * n - 1);
+    g[n - 1 - m] = (float)h;
+    if (m >= 1) g[2 * n - 1 - m] = (float)h;
+  }
 }
 
 // y[r][m] = R[r][m + n - 1] + (m >= 1 ? R[r][m - 1] : 0), times cos(2 pi m / n) when `modulate`
@@ -89,6 +100,14 @@ __global__ void k_fold(const float* __restrict__ lin, long ld, float* __restrict
   y[r * n + m] = v;
 }
 
+// y[r][m] *= cos(2 pi m / n)   (odd-length fft / ifft path of the reference, see xcx_timeshift_fft)
+__global__ void k_modulate(float* __restrict__ y, long n, long rows) {
+  const long r = blockIdx.y;
+  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= n || r >= rows) return;
+  y[r * n + m] = (float)((double)y[r * n + m] * cospi(2.0 * (double)m / (double)n));
+}
+
 }  // namespace
 
 // rows [batch][size] -> [batch][n] (n <= size), alpha[r] = shift of row r in cycles per frequency bin
@@ -99,18 +118,29 @@ static int timeshift_rows(xcx_ctx* ctx, const float* x, float* y, long batch, lo
   if (!ctx->ts_plan || ctx->ts_n != n) {
     if (ctx->ts_plan) { xcx_plan_destroy(ctx->ts_plan); ctx->ts_plan = nullptr; }
     if (n > 0x7fffffffL / 2) return set_err(XCX_EUNSUPPORTED, "row too long");
-    if ((rc = xcx_plan_cc1d(ctx, (int)n, 0, 0, 0, 0, &ctx->ts_plan))) return rc;
+    // direct form: operands of 2n-1 samples (the row is zero beyond its first n), lags -(n-1) .. 0 retained;
+    // such a plan is alias-free at N >= 2n-1 (kPlanShortOperand, xcx_api.hip)
+    const int np = (int)(2 * n - 1);
+    ctx->ts_direct = false;
+    if (np <= kMaxTransformN) {
+      if ((rc = xcx_plan_cc1d(ctx, np, 0, (int)(n - 1), np, kPlanShortOperand, &ctx->ts_plan))) return rc;
+      ctx->ts_direct = !xcx_internal_segmented(ctx->ts_plan);
+      if (!ctx->ts_direct) { xcx_plan_destroy(ctx->ts_plan); ctx->ts_plan = nullptr; }
+    }
+    // longer than one transform: one period + fold, through the block decomposition
+    if (!ctx->ts_direct && (rc = xcx_plan_cc1d(ctx, (int)n, 0, 0, 0, 0, &ctx->ts_plan))) return rc;
     ctx->ts_n = n;
   }
   xcx_plan* plan = ctx->ts_plan;
+  const bool direct = ctx->ts_direct;
   const long L = 2 * n - 1;
   const long ld = (L + 31) / 32 * 32;
   const int kRows = n > 400000 ? 16 : 256;            // rows per launch group: bounded workspace for long rows; 128 -> 256 measured -5 % (launch tails)
   DevBuf &hr = ctx->scratch[1], &lin = ctx->scratch[2], &dal = ctx->scratch[3], &dx = ctx->scratch[4],
          &dy = ctx->scratch[5];
   const int chunk = (int)std::min<long>(kRows, batch);
-  if ((rc = hr.ensure(ctx, sizeof(float) * n * chunk))) return rc;
-  if ((rc = lin.ensure(ctx, sizeof(float) * ld * chunk))) return rc;
+  if ((rc = hr.ensure(ctx, sizeof(float) * (direct ? L : n) * chunk))) return rc;
+  if (!direct && (rc = lin.ensure(ctx, sizeof(float) * ld * chunk))) return rc;
   if ((rc = dal.ensure(ctx, sizeof(double) * batch))) return rc;
   HIP_TRY(hipMemcpyAsync(dal.ptr, alpha.data(), sizeof(double) * batch, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -131,14 +161,25 @@ static int timeshift_rows(xcx_ctx* ctx, const float* x, float* y, long batch, lo
     const int cnt = (int)std::min<long>(chunk, batch - r0);
     const dim3 grid((unsigned)((n + 255) / 256), (unsigned)cnt);
     hipLaunchKernelGGL(k_dirichlet, grid, dim3(256), 0, ctx->stream, (float*)hr.ptr, n, (long)cnt,
-                       (const double*)dal.ptr + r0);
+                       (const double*)dal.ptr + r0, direct ? 1 : 0);
     HIP_TRY(hipGetLastError());
+    if (direct) {
+      if ((rc = xcx_internal_forward(plan, xd + r0 * size, size, 0, 1, 0, 0, cnt, 0, (int)n))) return rc;
+      if ((rc = xcx_internal_forward(plan, (const float*)hr.ptr, L, 0, 1, 0, 0, cnt, cnt, 0))) return rc;
+      for (int i = 0; i < cnt; ++i) d[i] = PwDesc{i, cnt + i, (long long)i * n};
+      if ((rc = xcx_internal_pairs(plan, d.data(), cnt, yd + r0 * n))) return rc;
+      if (modulate) {
+        hipLaunchKernelGGL(k_modulate, grid, dim3(256), 0, ctx->stream, yd + r0 * n, n, (long)cnt);
+        HIP_TRY(hipGetLastError());
+      }
+      continue;
+    }
     if (seg) {
       for (int i = 0; i < cnt; ++i) { xs[i] = xd + (r0 + i) * size; ys[i] = (const float*)hr.ptr + (long)i * n; }
       if ((rc = xcx_internal_seg_rows(plan, xs.data(), ys.data(), cnt, (float*)lin.ptr, ld))) return rc;
     } else {
-      if ((rc = xcx_internal_forward(plan, xd + r0 * size, size, 0, 1, 0, 0, cnt, 0))) return rc;
-      if ((rc = xcx_internal_forward(plan, (const float*)hr.ptr, n, 0, 1, 0, 0, cnt, cnt))) return rc;
+      if ((rc = xcx_internal_forward(plan, xd + r0 * size, size, 0, 1, 0, 0, cnt, 0, 0))) return rc;
+      if ((rc = xcx_internal_forward(plan, (const float*)hr.ptr, n, 0, 1, 0, 0, cnt, cnt, 0))) return rc;
       for (int i = 0; i < cnt; ++i) d[i] = PwDesc{i, cnt + i, (long long)i * ld};
       if ((rc = xcx_internal_pairs(plan, d.data(), cnt, (float*)lin.ptr))) return rc;
     }

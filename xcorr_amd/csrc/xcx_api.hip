@@ -664,9 +664,10 @@ extern "C" int xcx_plan_profile_read(xcx_plan* p, int kernel_id, char* name, siz
 // (sw = s*W + wl, window index w0 + wl) -> spectrum slots slot0 + sw
 // ---------------------------------------------------------------------------
 int xcx_internal_forward(xcx_plan* p, const float* traces, long stride_s, long stride_w,
-                         int W, int w0, int sw_begin, int sw_end, int slot0);
+                         int W, int w0, int sw_begin, int sw_end, int slot0, int n_valid);
+// n_valid > 0: the windows hold n_valid < n samples (zero beyond; plans without demean / normalise only)
 static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_w,
-                   int W, int w0, int sw_begin, int sw_end, int slot0) {
+                   int W, int w0, int sw_begin, int sw_end, int slot0, int n_valid = 0) {
   xcx_ctx* ctx = p->ctx;
   const Geom& g = p->g;
   // station-windows per forward launch: large launches fill the chip
@@ -712,6 +713,7 @@ static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_
     f1.tw_unt = (const cf*)p->tw_unt.ptr;
     f1.tw_N = (const cf*)p->tw_N.ptr;
     f1.g = g;
+    if (n_valid > 0) f1.g.n = n_valid;
     {
       ProfScope ps(p, KID_FWD_ROWS, cnt);
       HIP_TRY(p->wrow->fwd(f1, dim3(g.N1 / kWRB, cnt), ctx->stream));
@@ -1449,8 +1451,10 @@ extern "C" int xcx_cc1d(xcx_plan* p, const float* x, const float* y, int batch,
 // internals shared with timeshift.hip
 // ---------------------------------------------------------------------------
 int xcx_internal_forward(xcx_plan* p, const float* traces, long stride_s, long stride_w,
-                         int W, int w0, int sw_begin, int sw_end, int slot0) {
-  return forward(p, traces, stride_s, stride_w, W, w0, sw_begin, sw_end, slot0);
+                         int W, int w0, int sw_begin, int sw_end, int slot0, int n_valid) {
+  if (n_valid > 0 && (n_valid > p->g.n || (p->g.flags & (XCX_F_DEMEAN | XCX_F_NORMALIZE | XCX_F_ONEBIT))))
+    return set_err(XCX_EINVAL, "short windows need a plan without demean / normalise / one-bit");
+  return forward(p, traces, stride_s, stride_w, W, w0, sw_begin, sw_end, slot0, n_valid);
 }
 int xcx_internal_pairs(xcx_plan* p, const PwDesc* hdesc, int count, float* out) {
   xcx_ctx* ctx = p->ctx;

@@ -7,6 +7,8 @@ struct xcx_ctx;
 
 // library-internal plan flag (above the 16 public flag bits of include/xcx.h), see xcx_plan_cc1d
 constexpr int kPlanShortOperand = 0x10000;
+// longest single transform of the instantiated kernels: N = 2 * N1 * N2h = 2 * 3072 * 128
+constexpr int kMaxTransformN = 786432;
 
 namespace xcx {
 int set_err(int code, const char* fmt, ...);
@@ -29,6 +31,7 @@ struct xcx_ctx {
   xcx::DevBuf scratch[10];   // grow-only workspaces of the row ops / filters / transforms
   struct xcx_plan* ts_plan = nullptr;   // cached plan of xcx_timeshift
   long ts_n = 0;
+  bool ts_direct = false;               // ts_plan correlates against the period-extended kernel (timeshift.hip)
   struct xcx_plan* bs_plan[2] = {nullptr, nullptr};   // cached plans of the Bluestein FFTs (fftn.hip)
   long bs_key[2][3] = {{0, 0, 0}, {0, 0, 0}};
   int bs_next = 0;
