@@ -58,62 +58,79 @@ __device__ __forceinline__ double2 chirp(long m, long n, int sign) {
   return make_double2(c, sign < 0 ? -s : s);
 }
 
-// traces [B + 2][2][np]
-__global__ void k_bs_pre(const float* __restrict__ in, BsGeom g, long B, float* __restrict__ tr) {
+// tab[j] = exp(+ i pi j^2 / n), j = 0 .. n: the chirp of a transform length, evaluated once per context and n
+// (per element and row it cost a 64-bit modulo and a float64 sincospi: 40 % of a lag-axis rfft)
+__global__ void k_chirp_table(double2* __restrict__ tab, long n) {
+  const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j <= n) tab[j] = chirp(j, n, +1);
+}
+
+// c[m] from the table: c[-m] = c[m], c[m + n] = (-1)^n c[m]
+__device__ __forceinline__ double2 chirp_tab(const double2* __restrict__ tab, long m, long n, int sign) {
+  long mm = m < 0 ? -m : m;
+  bool flip = false;
+  while (mm > n) { mm -= n; flip ^= (bool)(n & 1); }
+  double2 c = tab[mm];
+  if (flip) { c.x = -c.x; c.y = -c.y; }
+  if (sign < 0) c.y = -c.y;
+  return c;
+}
+
+// traces [B + 2][2][np]; grid (ceil(np / 256), B + 1): row B writes the two chirp stations
+__global__ void k_bs_pre(const float* __restrict__ in, BsGeom g, long B, float* __restrict__ tr,
+                         const double2* __restrict__ tab) {
   const long np = g.np;
-  const long total = (B + 1) * np;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long b = i / np, t = i % np;
-    if (b < B) {
-      float ar = 0.f, ai = 0.f;
-      if (t < g.nin) {
-        const long m = g.m0 + t;
-        double vr, vi = 0.0;
-        if (g.in_complex == 2) {                 // real rows read as (even, odd) sample pairs; pitch in floats
-          vr = in[b * g.in_pitch + 2 * m];
-          vi = in[b * g.in_pitch + 2 * m + 1];
-        } else if (g.in_complex) {
-          const float2 v = reinterpret_cast<const float2*>(in)[b * g.in_pitch + m];
-          vr = v.x; vi = v.y;
-        } else {
-          vr = in[b * g.in_pitch + m];
-        }
-        if (g.half_weights && m != 0 && 2 * m != g.n) { vr *= 2.0; vi *= 2.0; }
-        const double2 c = chirp(m, g.n, g.sign);
-        ar = (float)(vr * c.x - vi * c.y);
-        ai = (float)(vr * c.y + vi * c.x);
+  const long b = blockIdx.y;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= np) return;
+  if (b < B) {
+    float ar = 0.f, ai = 0.f;
+    if (t < g.nin) {
+      const long m = g.m0 + t;
+      double vr, vi = 0.0;
+      if (g.in_complex == 2) {                 // real rows read as (even, odd) sample pairs; pitch in floats
+        vr = in[b * g.in_pitch + 2 * m];
+        vi = in[b * g.in_pitch + 2 * m + 1];
+      } else if (g.in_complex) {
+        const float2 v = reinterpret_cast<const float2*>(in)[b * g.in_pitch + m];
+        vr = v.x; vi = v.y;
+      } else {
+        vr = in[b * g.in_pitch + m];
       }
-      tr[(b * 2 + 0) * np + t] = ar;
-      tr[(b * 2 + 1) * np + t] = ai;
-    } else {                                    // the two chirp stations
-      // conj(c)[m - k] at m - k = (m0 + s) - (k0 + u), s - u = t - (nout-1)
-      const double2 c = chirp(t - (g.nout - 1) - (g.k0 - g.m0), g.n, -g.sign);
-      tr[((B + 0) * 2 + 0) * np + t] = (float)c.x;
-      tr[((B + 0) * 2 + 1) * np + t] = (float)-c.y;
-      tr[((B + 1) * 2 + 0) * np + t] = (float)c.y;
-      tr[((B + 1) * 2 + 1) * np + t] = (float)c.x;
+      if (g.half_weights && m != 0 && 2 * m != g.n) { vr *= 2.0; vi *= 2.0; }
+      const double2 c = chirp_tab(tab, m, g.n, g.sign);
+      ar = (float)(vr * c.x - vi * c.y);
+      ai = (float)(vr * c.y + vi * c.x);
     }
+    tr[(b * 2 + 0) * np + t] = ar;
+    tr[(b * 2 + 1) * np + t] = ai;
+  } else {                                    // the two chirp stations
+    // conj(c)[m - k] at m - k = (m0 + s) - (k0 + u), s - u = t - (nout-1)
+    const double2 c = chirp_tab(tab, t - (g.nout - 1) - (g.k0 - g.m0), g.n, -g.sign);
+    tr[((B + 0) * 2 + 0) * np + t] = (float)c.x;
+    tr[((B + 0) * 2 + 1) * np + t] = (float)-c.y;
+    tr[((B + 1) * 2 + 0) * np + t] = (float)c.y;
+    tr[((B + 1) * 2 + 1) * np + t] = (float)c.x;
   }
 }
 
 // out[b][k] = c[k] (R[2b][k] + i R[2b+1][k]) scale ; real_only keeps the real part
-// out_mode 0: complex, 1: real part, 2: modulus
+// out_mode 0: complex, 1: real part, 2: modulus.   grid (ceil(nout / 256), B)
 __global__ void k_bs_post(const float* __restrict__ R, long ld, BsGeom g, long B, double scale, int real_only,
-                          float* __restrict__ out) {
-  const long total = B * g.nout;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const long b = i / g.nout, k = i % g.nout;
-    const double re = R[(2 * b) * ld + k], im = R[(2 * b + 1) * ld + k];
-    const double2 c = chirp(g.k0 + k, g.n, g.sign);
-    double orr = (re * c.x - im * c.y) * scale, oi = (re * c.y + im * c.x) * scale;
-    const long o = b * (g.out_pitch ? g.out_pitch : g.nout) + g.k0 + k;
-    if (real_only == 1) out[o] = (float)(g.accumulate ? (double)out[o] + orr : orr);
-    else if (real_only == 2) out[o] = (float)sqrt(orr * orr + oi * oi);
-    else {
-      float2* oc = reinterpret_cast<float2*>(out) + o;
-      if (g.accumulate) { orr += (double)oc->x; oi += (double)oc->y; }
-      *oc = make_float2((float)orr, (float)oi);
-    }
+                          float* __restrict__ out, const double2* __restrict__ tab) {
+  const long b = blockIdx.y;
+  const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= g.nout || b >= B) return;
+  const double re = R[(2 * b) * ld + k], im = R[(2 * b + 1) * ld + k];
+  const double2 c = chirp_tab(tab, g.k0 + k, g.n, g.sign);
+  double orr = (re * c.x - im * c.y) * scale, oi = (re * c.y + im * c.x) * scale;
+  const long o = b * (g.out_pitch ? g.out_pitch : g.nout) + g.k0 + k;
+  if (real_only == 1) out[o] = (float)(g.accumulate ? (double)out[o] + orr : orr);
+  else if (real_only == 2) out[o] = (float)sqrt(orr * orr + oi * oi);
+  else {
+    float2* oc = reinterpret_cast<float2*>(out) + o;
+    if (g.accumulate) { orr += (double)oc->x; oi += (double)oc->y; }
+    *oc = make_float2((float)orr, (float)oi);
   }
 }
 
@@ -141,6 +158,14 @@ int bluestein_core(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom
     ctx->bs_key[slot][0] = g.np; ctx->bs_key[slot][1] = imin; ctx->bs_key[slot][2] = imax;
   }
   xcx_plan* plan = ctx->bs_plan[slot];
+  if (ctx->bs_tab_n != g.n || !ctx->bs_tab.ptr) {
+    ctx->bs_tab_n = 0;
+    if ((rc = ctx->bs_tab.ensure(ctx, sizeof(double2) * (size_t)(g.n + 1)))) return rc;
+    hipLaunchKernelGGL(k_chirp_table, dim3((unsigned)((g.n + 256) / 256)), dim3(256), 0, ctx->stream, (double2*)ctx->bs_tab.ptr, g.n);
+    HIP_TRY(hipGetLastError());
+    ctx->bs_tab_n = g.n;
+  }
+  const double2* tab = (const double2*)ctx->bs_tab.ptr;
   const long ld = (g.nout + 31) / 32 * 32;
   // rows per pass: bounded workspace (traces + spectra scale with np)
   const long chunk = std::max<long>(1, std::min<long>(std::min<long>(batch, 256), ((long)1024 << 20) / (16 * g.np)));
@@ -164,10 +189,8 @@ int bluestein_core(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom
   std::vector<int> pairs;
   for (long r0 = 0; r0 < batch; r0 += chunk) {
     const long cnt = std::min(chunk, batch - r0);
-    const long tot = (cnt + 1) * g.np;
-    const int grid = (int)std::min<long>((tot + 255) / 256, 256L * 16);
-    hipLaunchKernelGGL(k_bs_pre, dim3(grid), dim3(256), 0, ctx->stream,
-                       (const float*)((const char*)ind + in_row * r0), g, cnt, (float*)tr.ptr);
+    hipLaunchKernelGGL(k_bs_pre, dim3((unsigned)((g.np + 255) / 256), (unsigned)(cnt + 1)), dim3(256), 0, ctx->stream,
+                       (const float*)((const char*)ind + in_row * r0), g, cnt, (float*)tr.ptr, tab);
     HIP_TRY(hipGetLastError());
     pairs.resize(4 * cnt);
     for (long b = 0; b < cnt; ++b) {
@@ -177,10 +200,8 @@ int bluestein_core(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom
     if ((rc = xcx_cc1d_pairs(plan, (const float*)tr.ptr, (int)cnt + 2, 2, 2 * g.np, g.np, pairs.data(), (int)(2 * cnt),
                              (float*)lin.ptr, ld, 1)))
       return rc;
-    const long tot2 = cnt * g.nout;
-    const int grid2 = (int)std::min<long>((tot2 + 255) / 256, 256L * 16);
-    hipLaunchKernelGGL(k_bs_post, dim3(grid2), dim3(256), 0, ctx->stream, (const float*)lin.ptr, ld, g, cnt, scale,
-                       real_only, (float*)((char*)outd + out_row * r0));
+    hipLaunchKernelGGL(k_bs_post, dim3((unsigned)((g.nout + 255) / 256), (unsigned)cnt), dim3(256), 0, ctx->stream,
+                       (const float*)lin.ptr, ld, g, cnt, scale, real_only, (float*)((char*)outd + out_row * r0), tab);
     HIP_TRY(hipGetLastError());
   }
   if (stage_out) {

@@ -158,6 +158,7 @@ extern "C" int xcx_destroy(xcx_ctx* ctx) {
   for (auto* bp : ctx->bs_plan) if (bp) xcx_plan_destroy(bp);
   ctx->sg_tab.release();
   ctx->sos_tab.release();
+  ctx->bs_tab.release();
   for (auto& b : ctx->scratch) b.release();
   if (ctx->flow_T) (void)hipFree(ctx->flow_T);
   if (ctx->flow_err_dev) (void)hipFree(ctx->flow_err_dev);

@@ -35,6 +35,8 @@ struct xcx_ctx {
   struct xcx_plan* bs_plan[2] = {nullptr, nullptr};   // cached plans of the Bluestein FFTs (fftn.hip)
   long bs_key[2][3] = {{0, 0, 0}, {0, 0, 0}};
   int bs_next = 0;
+  xcx::DevBuf bs_tab;                    // chirp exp(i pi j^2 / n), j <= n, of the last transform length (fftn.hip)
+  long bs_tab_n = 0;
   xcx::DevBuf sg_tab;                    // cached DFT-matrix tables of xcx_spectrogram
   unsigned long long sg_key = 0;
   xcx::DevBuf sos_tab;                   // cached transition-matrix powers of the chunked SOS scan
