@@ -103,6 +103,22 @@ def test_timeshift_of_long_rows(ctx):
         assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
 
 
+def test_timeshift_at_the_single_transform_boundary(ctx):
+    """Rows up to 393 216 samples are shifted by ONE correlation against two periods of the Dirichlet kernel
+    (2n - 1 <= 786 432, the longest transform; the pair pass writes the shifted row), longer ones by the
+    one-period correlation + fold through the block decomposition: both sides of the switch, odd sizes too."""
+    from xcorr_amd import ops
+    rng = np.random.default_rng(23)
+    fs = 50.
+    for size in (393216, 393217, 393218, 393219):
+        x = (rng.standard_normal((2, size)) * np.hanning(size)).astype(np.float32)
+        delay = np.array([0.0113, -0.75])
+        got = ops.timeshift(ctx, x, delay, fs)
+        ref = R.timeshift(x, delay, fs)
+        assert got.shape == ref.shape == (2, size - (size & 1))
+        assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max(), size
+
+
 def test_production_postprocess_chain(ctx):
     """core/postprocess.py:133-141 on the production container layout: day-long windows
     (npts = 4 320 000), clip_lag = (0, 9 h) -> rows of 1 620 000 lags, device-resident."""
