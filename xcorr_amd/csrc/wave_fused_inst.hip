@@ -18,22 +18,12 @@ hipError_t XCX_CAT3(launch_wdual_, XCX_FC_L, _, XCX_FR_L)(const WDualArgs& a, hi
   constexpr size_t lds = sizeof(float) * PG::kLdsFloats;
   const int Bm = a.Bc > a.Br ? a.Bc : a.Br;
   const dim3 grid(8u * (unsigned)((PG::CWX + PG::RWX) * Bm));
-  // occupancy knob: pad the LDS request so that at most `wgs` workgroups share a CU
-  static const int wgs = getenv("XCX_DUAL_WGS") ? atoi(getenv("XCX_DUAL_WGS")) : 0;
-  size_t lds_req = lds;
-  if (wgs > 0) {
-    lds_req = std::max(lds, (size_t)(160 * 1024 / wgs) & ~(size_t)255);
-    static hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wpair_dual<RXC, RXR, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    static hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_wpair_dual<RXC, RXR, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e1 != hipSuccess) return e1;
-    if (e2 != hipSuccess) return e2;
-  }
   if (a.nstack < 0)
-    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, 2>), grid, dim3(kWNT * kWPB), lds_req, s, a);
+    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, 2>), grid, dim3(kWNT * kWPB), lds, s, a);
   else if (a.nstack > 1)
-    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, 1>), grid, dim3(kWNT * kWPB), lds_req, s, a);
+    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, 1>), grid, dim3(kWNT * kWPB), lds, s, a);
   else
-    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, 0>), grid, dim3(kWNT * kWPB), lds_req, s, a);
+    hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, 0>), grid, dim3(kWNT * kWPB), lds, s, a);
   return hipGetLastError();
 }
 

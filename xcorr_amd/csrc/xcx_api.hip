@@ -891,9 +891,7 @@ static int flow_run(xcx_plan* p, size_t first, size_t count, int nstack, float* 
   if (ctx->flow_T_bytes < tbytes) {
     if (ctx->flow_T) { HIP_TRY(hipStreamSynchronize(ctx->stream)); (void)hipFree(ctx->flow_T); ctx->flow_T = nullptr; ctx->flow_T_bytes = 0; }
     // uncached: producers and consumers of T sit on different XCDs inside one launch
-    static const char* tm = getenv("XCX_FLOW_T");            // A/B only: "plain" is NOT coherent across XCDs
-    hipError_t e = (tm && strcmp(tm, "plain") == 0) ? hipMalloc(&ctx->flow_T, tbytes)
-                 : hipExtMallocWithFlags(&ctx->flow_T, tbytes, (tm && strcmp(tm, "fg") == 0) ? hipDeviceMallocFinegrained : hipDeviceMallocUncached);
+    hipError_t e = hipExtMallocWithFlags(&ctx->flow_T, tbytes, hipDeviceMallocUncached);
     if (e != hipSuccess) { (void)hipGetLastError(); return set_err(XCX_ENOMEM, "uncached T ring of %zu bytes: %s", tbytes, hipGetErrorString(e)); }
     ctx->flow_T_bytes = tbytes;
   }
