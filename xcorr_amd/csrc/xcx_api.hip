@@ -143,6 +143,7 @@ extern "C" int xcx_init(int device, xcx_ctx** out) {
   if (!ctx) return set_err(XCX_ENOMEM, "host allocation failed");
   ctx->device = device;
   HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamCreateWithFlags(&ctx->pipe[i], hipStreamNonBlocking));   // see xcx_internal.h
   HIP_TRY(hipEventCreate(&ctx->ev0));
   HIP_TRY(hipEventCreate(&ctx->ev1));
   *out = ctx;
@@ -163,6 +164,8 @@ extern "C" int xcx_destroy(xcx_ctx* ctx) {
   if (ctx->flow_T) (void)hipFree(ctx->flow_T);
   if (ctx->flow_err_dev) (void)hipFree(ctx->flow_err_dev);
   if (ctx->flow_err_host) (void)hipHostFree(ctx->flow_err_host);
+  for (auto& ps : ctx->pipe)
+    if (ps) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
   (void)hipEventDestroy(ctx->ev0);
   (void)hipEventDestroy(ctx->ev1);
   (void)hipStreamDestroy(ctx->stream);
@@ -529,7 +532,7 @@ extern "C" int xcx_plan_destroy(xcx_plan* p) {
   (void)hipStreamSynchronize(p->ctx->stream);
   for (auto& e : p->evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   for (auto& ch : p->chains) {
-    if (ch.stream && ch.stream != p->ctx->stream) { (void)hipStreamSynchronize(ch.stream); (void)hipStreamDestroy(ch.stream); }
+    if (ch.stream && ch.stream != p->ctx->stream) (void)hipStreamSynchronize(ch.stream);   // the context owns it
     if (ch.done) (void)hipEventDestroy(ch.done);
   }
   if (p->ev_fwd) (void)hipEventDestroy(p->ev_fwd);
@@ -841,7 +844,10 @@ static int dual_run(xcx_plan* p, size_t first, size_t count, int nstack, float* 
     xcx_plan::Chain& ch = p->chains[c];
     if (!ch.stream) {
       if (nch == 1) ch.stream = ctx->stream;
-      else HIP_TRY(hipStreamCreateWithFlags(&ch.stream, hipStreamNonBlocking));
+      else {
+        if (!ctx->pipe[c]) HIP_TRY(hipStreamCreateWithFlags(&ctx->pipe[c], hipStreamNonBlocking));   // XCX_CHAINS > 2
+        ch.stream = ctx->pipe[c];
+      }
       HIP_TRY(hipEventCreateWithFlags(&ch.done, hipEventDisableTiming));
     }
     ch.B = 0;

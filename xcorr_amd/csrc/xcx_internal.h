@@ -25,6 +25,11 @@ struct DevBuf {
 struct xcx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  // Streams of the pair-phase pipelines, shared by every plan of the context and created WITH the context: a
+  // process has few hardware queues (4 by default) and HIP deals streams onto them in creation order, so two
+  // pipelines created late (after the streams of other plans) can land on ONE queue and lose their overlap --
+  // measured 75.7 -> 101 ms per step when a time-shift and two transform plans existed first.
+  hipStream_t pipe[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   void* comm = nullptr;      // ncclComm_t
   int nranks = 1, rank = 0;
