@@ -9,9 +9,11 @@
  *   - every function returns 0 on success or a negative XCX_E* code;
  *     xcx_last_error() returns the message of the calling thread's last error.
  *   - the caller owns every data buffer; the library owns plans, twiddle
- *     tables, workspaces and its HIP stream.  One xcx_ctx <-> one HIP device
- *     <-> one stream; contexts share no mutable state (the reference runs one
- *     Python thread per Dask worker, xcorr/scripts/utils.py:62-66).
+ *     tables, workspaces and its HIP streams.  One xcx_ctx <-> one HIP device
+ *     <-> one main stream (+ two pipeline streams that the pair phases of all
+ *     its plans share); a context and its plans are used from one thread at a
+ *     time; contexts share no mutable state (the reference runs one Python
+ *     thread per Dask worker, xcorr/scripts/utils.py:62-66).
  *   - `on_device` != 0: data pointers are device pointers obtained from
  *     xcx_malloc(); == 0: host pointers (the library stages through HBM).
  *   - all arrays are C-contiguous float32 with the core dimension last, which
