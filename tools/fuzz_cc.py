@@ -39,6 +39,23 @@ def run(budget=60.0, seed=0, ctx=None):
             # ill-conditioned in any precision, so keep DC outside the band when the window is demeaned
             fmin = ftaper + 0.02 * fs / 2
             fmax = max(fmax, fmin + 0.02 * fs / 2)
+        if rng.random() < 0.3:
+            # band edges a hair beside a frequency bin of the planned transform (the float edges the kernels compare
+            # against once admitted one bin too many: fmax N / fs = 21377.9994 -> 21378.0f)
+            probe = CCPlan(ctx, n, imin, imax)
+            Np = probe.N
+            probe.close()
+            snap = lambda f: (round(f * Np / fs) + float(rng.choice([-1.0, 1.0])) * float(rng.uniform(1e-7, 1e-4))) * fs / Np
+            fmin2, fmax2 = max(snap(fmin), 0.0), snap(fmax)
+            if ftaper > 0:
+                ftaper = max(snap(fmin2 + ftaper) - fmin2, 0.0)      # flank ends beside a bin as well
+                # a flank narrower than the float32 resolution of a bin coordinate (1e-5 bins at bin 200) is not
+                # resolved by the kernels' float edges (the ramp value of a bin INSIDE such a flank is decided as
+                # 0 or 1); physically meaningless, so not generated: flanks are sharp or at least 0.01 bin wide
+                if ftaper * Np / fs < 0.01:
+                    ftaper = 0.0
+            if fmax2 > fmin2 and fmin2 - ftaper >= 0:
+                fmin, fmax = fmin2, fmax2
         wh = (fs, fmin, fmax, ftaper)
         flags['normalize'] = True
     allp = [(i, j) for i in range(S) for j in range(S)]
