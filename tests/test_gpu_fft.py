@@ -163,3 +163,36 @@ def test_split_transform_boundaries(ctx):
         assert relerr(X, np.fft.rfft(x[:, :m].astype(np.float64), axis=-1)) < TOL
     c = (rng.standard_normal((1, 184321)) + 1j * rng.standard_normal((1, 184321))).astype(np.complex64)
     assert relerr(ops.fft(ctx, c), np.fft.fft(c.astype(np.complex128), axis=-1)) < TOL
+
+
+def test_device_resident_transforms(ctx):
+    """DeviceArray in -> DeviceArray out (complex rows as interleaved float32 pairs): the same values as the host
+    path, nothing staged through the host."""
+    rng = np.random.default_rng(12)
+    for n in (4096, 4999, 10006):
+        x = rng.standard_normal((3, n)).astype(np.float32)
+        m = (n - (n & 1)) // 2 + 1
+        d = ctx.array(x)
+        X = ops.rfft(ctx, d)
+        assert X.shape == (3, 2 * m)
+        Xh = X.to_host().view(np.complex64)
+        assert np.array_equal(Xh, ops.rfft(ctx, x))
+        xr = ops.irfft(ctx, X)
+        assert xr.shape == (3, 2 * m - 2)
+        assert np.array_equal(xr.to_host(), ops.irfft(ctx, Xh))
+        z = (x + 1j * rng.standard_normal((3, n))).astype(np.complex64)
+        dz = ctx.array(z.view(np.float32))
+        Z = ops.fft(ctx, dz)
+        assert Z.shape == (3, 2 * n)
+        assert np.array_equal(Z.to_host().view(np.complex64), ops.fft(ctx, z))
+        assert np.array_equal(ops.ifft(ctx, Z).to_host().view(np.complex64), ops.ifft(ctx, Z.to_host().view(np.complex64)))
+        h = ops.hilbert(ctx, d)
+        assert h.shape == (3, 2 * n)
+        assert np.array_equal(h.to_host().view(np.complex64), ops.hilbert(ctx, x))
+        e = ops.hilbert(ctx, d, envelope=True)
+        assert e.shape == (3, n)
+        assert np.array_equal(e.to_host(), ops.hilbert(ctx, x, envelope=True))
+        for b in (d, X, xr, dz, Z, h, e):
+            b.free()
+    with pytest.raises(ValueError):
+        ops.fft(ctx, ctx.array(np.zeros((2, 5), np.float32)))

@@ -299,6 +299,21 @@ def correlate2d(ctx, tiles, pairs, normalize=True, full=False):
 
 
 def _fft_call(name, ctx, x, in_dtype, out_dtype, out_len):
+    if isinstance(x, DeviceArray):
+        # device-resident rows: float32 DeviceArrays, complex rows as interleaved (re, im) pairs -- a complex row of
+        # m values is 2 m floats; the result is a new DeviceArray of the same convention and nothing crosses PCIe
+        ctx = _ctx(ctx, x)
+        cin, cout = in_dtype == np.complex64, out_dtype == np.complex64
+        width = x.shape[-1]
+        if cin and width % 2:
+            raise ValueError('complex device rows are interleaved (re, im) pairs: an even number of floats per row')
+        size = width // 2 if cin else width
+        batch = int(np.prod(x.shape[:-1])) if len(x.shape) > 1 else 1
+        m = out_len(size)
+        out = DeviceArray(ctx, (batch, 2 * m if cout else m))
+        if batch and m:
+            check(getattr(_ffi.lib(), name)(ctx.handle, ptr(x), ptr(out), batch, size, 1))
+        return out
     ctx = ctx if ctx is not None else default_context()
     a = np.ascontiguousarray(x, dtype=in_dtype)
     if a.ndim == 0:
@@ -336,6 +351,14 @@ def irfft(ctx, x):
 def hilbert(ctx, x, envelope=False):
     """Analytic signal (complex64) of every row, scipy.signal.hilbert semantics
     (xcorr/signal/hilbert.py:69); ``envelope=True`` returns its modulus (float32, :120)."""
+    if isinstance(x, DeviceArray):                # device rows in, device rows out (complex: interleaved pairs)
+        ctx = _ctx(ctx, x)
+        n = x.shape[-1]
+        batch = int(np.prod(x.shape[:-1])) if len(x.shape) > 1 else 1
+        out = DeviceArray(ctx, (batch, n if envelope else 2 * n))
+        if batch:
+            check(_ffi.lib().xcx_hilbert(ctx.handle, ptr(x), ptr(out), batch, n, int(bool(envelope)), 1))
+        return out
     ctx = ctx if ctx is not None else default_context()
     a = np.ascontiguousarray(x, dtype=np.float32)
     if a.ndim == 0:
