@@ -179,6 +179,29 @@ def test_whitening_band_edge_next_to_a_bin(ctx):
         plan.close()
 
 
+def test_rewhitening_a_plan_with_another_band(ctx):
+    # xcx_plan_set_whiten again on the same plan: narrow band, wide band, narrow again.  The forward pass does not
+    # store above the band and the pair pass reads "stored zeros" there -- what a wider band wrote in between must
+    # not survive (it did: error 0.93 before the zeroed-buffer records were dropped on a band change)
+    from xcorr_amd import _ffi
+    from xcorr_amd._ffi import check
+    S, n, hop, W = 4, 3000, 1500, 3
+    tr = R.synthetic_traces(S, hop * (W - 1) + n)
+    pairs = R.all_pairs(S)
+    narrow, wide = (50., 1., 5., 0.), (50., 1., 12., .5)
+    for stack in (False, True):
+        plan = X.CCPlan(ctx, n, whiten=narrow, stack=stack)
+        for wh in (narrow, wide, narrow, wide, narrow):
+            check(_ffi.lib().xcx_plan_set_whiten(plan.handle, *wh))
+            got = plan.pairs(tr, pairs, W, hop)
+            g = R.whiten_weights(plan.N, *wh)
+            ref = R.cc_pairs(tr, pairs, n, hop, dtype=np.float64, whiten=g, nfft=plan.N)
+            if stack:
+                ref = ref.sum(axis=1)
+            assert relerr(got, ref) < TOL, (stack, wh)
+        plan.close()
+
+
 def test_pairs_unbiased_and_order(ctx):
     S, n, hop, W = 4, 2000, 1000, 3
     tr = R.synthetic_traces(S, hop * (W - 1) + n)

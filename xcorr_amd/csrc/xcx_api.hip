@@ -593,7 +593,14 @@ extern "C" int xcx_plan_set_whiten(xcx_plan* p, double fs, double fmin,
   {
     static const bool prune = !(getenv("XCX_BAND_PRUNE") && atoi(getenv("XCX_BAND_PRUNE")) == 0);
     const double hi = floor((double)p->wb[3]);
-    p->g.band_hi = (prune && (p->g.flags & XCX_F_WHITEN) && hi >= 0 && hi < (double)N) ? (int)hi : N;
+    const int band_hi = (prune && (p->g.flags & XCX_F_WHITEN) && hi >= 0 && hi < (double)N) ? (int)hi : N;
+    if (band_hi != p->g.band_hi) {
+      // another band: whatever the buffers hold above the new edge is no longer "stored zeros" (a wider band of an
+      // earlier call wrote there) -- forget every buffer that was zeroed for the old one
+      for (auto& z : p->zeroed) z = {};
+      p->gram_zeroed = {};
+    }
+    p->g.band_hi = band_hi;
   }
   return XCX_OK;
 }
