@@ -2,6 +2,7 @@
 // pair x window cross-correlation driver.  No exceptions cross the boundary.
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -289,7 +290,10 @@ int DevBuf::ensure(xcx_ctx* ctx, size_t need) {
   bytes = 0;
   HIP_TRY(hipMalloc(&ptr, need));
   bytes = need;
-  gen += 1;
+  // process-wide allocation number: (ptr, gen) identifies THIS memory even when the allocator hands the same
+  // address to another buffer later (a per-buffer count could repeat there and revive a stale "zeroed" record)
+  static std::atomic<unsigned long long> next_gen{0};
+  gen = ++next_gen;
   return XCX_OK;
 }
 void DevBuf::release() {

@@ -16,7 +16,7 @@ int set_err(int code, const char* fmt, ...);
 struct DevBuf {
   void* ptr = nullptr;
   size_t bytes = 0;
-  unsigned long long gen = 0;              // bumped by every (re)allocation: identifies the memory's lifetime
+  unsigned long long gen = 0;              // process-wide allocation number of `ptr` (0: none): identifies the memory's lifetime
   int ensure(xcx_ctx* ctx, size_t need);   // grow-only
   void release();
 };
