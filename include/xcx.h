@@ -56,6 +56,7 @@ enum {
 /* ---- context / memory / timing ---------------------------------------- */
 int xcx_device_count(int* count);
 int xcx_init(int device, xcx_ctx** ctx);
+/* destroy a context's plans (xcx_plan_destroy) before the context: they run on its streams */
 int xcx_destroy(xcx_ctx* ctx);
 int xcx_last_error(char* buf, size_t len);
 int xcx_device_name(xcx_ctx* ctx, char* buf, size_t len);

@@ -379,6 +379,16 @@ def test_stack_gram_many_stations_and_odd_pairs(ctx, monkeypatch):
     per = X.CCPlan(ctx, n, **kw).pairs(tr, pairs, W, hop).astype(np.float64).sum(axis=1)
     st = X.CCPlan(ctx, n, stack=True, **kw).pairs(tr, pairs, W, hop)
     assert relerr(st, per) < TOL
+    # the band cannot change between the adds of one accumulation (transformed days wait for their Gram update)
+    from xcorr_amd import _ffi
+    acc = X.CCPlan(ctx, n, stack=True, **kw)
+    acc.stack_add(tr, pairs, W, hop)
+    with pytest.raises(XcxError, match='stack accumulation'):
+        _ffi.check(_ffi.lib().xcx_plan_set_whiten(acc.handle, 50., 1., 5., 0.))
+    got3, nw = acc.stack_finish(pairs)
+    assert nw == W and relerr(got3, per) < TOL
+    _ffi.check(_ffi.lib().xcx_plan_set_whiten(acc.handle, 50., 1., 5., 0.))       # fine between accumulations
+    acc.close()
 
 
 def test_randomised_sweep(ctx):

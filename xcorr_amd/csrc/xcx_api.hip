@@ -564,6 +564,12 @@ extern "C" int xcx_plan_set_whiten(xcx_plan* p, double fs, double fmin,
                                    double fmax, double ftaper) {
   if (!p) return set_err(XCX_EINVAL, "null plan");
   if (p->seg) return set_err(XCX_EUNSUPPORTED, "segmented (long-window) plans do not whiten");
+  if (p->acc_count > 0)           // days already transformed with the old band wait for their Gram update
+    return set_err(XCX_EINVAL, "xcx_plan_set_whiten during a stack accumulation (%d adds): finish or reset it first", p->acc_count);
+  if (p->prep_valid) {            // spectra prepared ahead (xcx_cc1d_prepare) carry the old band: let them finish, drop them
+    HIP_TRY(hipStreamWaitEvent(p->ctx->stream, p->prep_done, 0));
+    p->prep_valid = false;
+  }
   if (!(fs > 0) || !(fmin >= 0) || !(fmax > fmin) || ftaper < 0)
     return set_err(XCX_EINVAL, "bad whitening band");
   const double bin = (double)p->g.N / fs;   // bins per Hz
