@@ -502,3 +502,37 @@ def test_pair_groups_processing_order():
     pairs = np.concatenate([rng.integers(0, 11, size=(60, 2)), [[3, 3], [10, 0], [10, 0]], [[5, 6]] * 9]).astype(np.int32)
     perm, bounds = _pair_groups(pairs, 11, 4)
     assert sorted(perm.tolist()) == list(range(len(pairs))) and np.diff(bounds).max() <= 4 and np.diff(bounds).min() >= 1
+
+
+def test_fftlib_host_rules(monkeypatch):
+    """xcorr_amd.fftlib (B3 seam): numpy's n= / s= / axis= / norm= rules are host logic around the device
+    transforms.  With the device calls replaced by numpy's own (float32 in, same signatures), every wrapper
+    must reproduce numpy.fft for cropped, padded, odd and multi-axis calls."""
+    from xcorr_amd import fftlib, ops
+    monkeypatch.setattr(ops, 'fft', lambda ctx, x: np.fft.fft(x, axis=-1).astype(np.complex64))
+    monkeypatch.setattr(ops, 'ifft', lambda ctx, x: np.fft.ifft(x, axis=-1).astype(np.complex64))
+    monkeypatch.setattr(ops, 'rfft', lambda ctx, x: np.fft.rfft(x, axis=-1).astype(np.complex64))
+    monkeypatch.setattr(ops, 'irfft', lambda ctx, x: np.fft.irfft(x, axis=-1).astype(np.float32))
+    rng = np.random.default_rng(8)
+    x = rng.standard_normal((5, 12, 9)).astype(np.float32)
+    z = (x + 1j * rng.standard_normal(x.shape)).astype(np.complex64)
+    close = lambda a, b: np.allclose(a, b, rtol=2e-5, atol=2e-5 * np.abs(b).max())
+    for axis in (-1, 0, 1):
+        for n in (None, 4, 9, 12, 20):
+            for norm in (None, 'ortho', 'forward'):
+                assert close(fftlib.fft(z, n=n, axis=axis, norm=norm), np.fft.fft(z, n=n, axis=axis, norm=norm))
+                assert close(fftlib.ifft(z, n=n, axis=axis, norm=norm), np.fft.ifft(z, n=n, axis=axis, norm=norm))
+                assert close(fftlib.rfft(x, n=n, axis=axis, norm=norm), np.fft.rfft(x, n=n, axis=axis, norm=norm))
+                h = np.fft.rfft(x, axis=axis)
+                assert close(fftlib.irfft(h, n=n, axis=axis, norm=norm), np.fft.irfft(h, n=n, axis=axis, norm=norm))
+    for s in (None, (8, 16), (12, 9), (5, 5)):
+        for axes in ((-2, -1), (0, 2), (2, 0)):
+            assert close(fftlib.fft2(z, s=s, axes=axes), np.fft.fft2(z, s=s, axes=axes))
+            assert close(fftlib.ifft2(z, s=s, axes=axes), np.fft.ifft2(z, s=s, axes=axes))
+    with pytest.raises(ValueError):
+        fftlib.fft(z, n=0)
+    with pytest.raises(ValueError):
+        fftlib.fft2(z, axes=(0, 1, 2))
+    with pytest.raises(ValueError):
+        fftlib.fft(z, norm='bogus')
+    assert fftlib.fftshift is np.fft.fftshift and fftlib.rfftfreq is np.fft.rfftfreq
