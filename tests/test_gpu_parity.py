@@ -404,6 +404,20 @@ def test_randomised_sweep(ctx):
     assert cases > 50 and worst < 1e-5
 
 
+def test_randomised_call_sequences(ctx):
+    """tools/fuzz_state.py: random SEQUENCES of calls on long-lived plans (another whitening band, pair list,
+    window count, batch size, prepared spectra, open / abandoned accumulations) -- nothing a call leaves behind may
+    leak into the next (80 s runs: 21 000 operations, worst error 5.5e-6)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location(
+        'fuzz_state', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fuzz_state.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    ops_done, worst = mod.run(budget=6.0, seed=321, ctx=ctx)
+    assert ops_done > 100 and worst < 1e-5
+
+
 def test_clipped_plans_use_shorter_transforms(ctx):
     """N >= n + max|lag| is enough for exact retained lags (clip_lag of core/init.py:176-209):
     a +-600 s slice of a 3600 s window runs at N = 245760 instead of 368640."""
