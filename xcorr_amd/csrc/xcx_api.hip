@@ -331,6 +331,7 @@ struct xcx_plan {
   Chain chains[kMaxChains];
   int nchains = 2;
   hipEvent_t ev_fwd = nullptr;
+  hipEvent_t fwd_last = nullptr; hipStream_t fwd_last_stream = nullptr;   // end of the plan's most recent forward()
   // xcx_cc1d_prepare: spectra of the NEXT batch computed on a side stream while
   // the pair phase of the current one runs; consumed by a matching xcx_cc1d_pairs
   DevBuf spectra_next;
@@ -540,6 +541,7 @@ extern "C" int xcx_plan_destroy(xcx_plan* p) {
     if (ch.done) (void)hipEventDestroy(ch.done);
   }
   if (p->ev_fwd) (void)hipEventDestroy(p->ev_fwd);
+  if (p->fwd_last) (void)hipEventDestroy(p->fwd_last);
   if (p->prep_stream) { (void)hipStreamSynchronize(p->prep_stream); (void)hipStreamDestroy(p->prep_stream); }
   if (p->prep_done) (void)hipEventDestroy(p->prep_done);
   for (auto& e : p->pairs_done) if (e) (void)hipEventDestroy(e);
@@ -697,6 +699,11 @@ static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_
   int rc;
   if ((g.flags & XCX_F_WHITEN) && !p->whiten_set)
     return set_err(XCX_EINVAL, "XCX_WHITEN set but xcx_plan_set_whiten() not called");
+  // Tm_f / psum / psq are shared by every forward of the plan, whichever stream it runs on (xcx_cc1d_prepare runs it
+  // on the preparation stream while the main stream may still be inside the forward of an unprepared call, and the
+  // other way round): wait for the previous one when it ran on another stream
+  if (!p->fwd_last) HIP_TRY(hipEventCreateWithFlags(&p->fwd_last, hipEventDisableTiming));
+  else if (p->fwd_last_stream && p->fwd_last_stream != ctx->stream) HIP_TRY(hipStreamWaitEvent(ctx->stream, p->fwd_last, 0));
   if (g.band_hi < g.N) {
     // band-limited plan: the forward column pass skips the stores of the out-of-band stretch of every
     // column (60 % of the spectrum bytes for 0.1-10 Hz at 50 Hz), so the buffer is zeroed once per
@@ -756,6 +763,8 @@ static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_
     }
     p->launches += 4;
   }
+  HIP_TRY(hipEventRecord(p->fwd_last, ctx->stream));
+  p->fwd_last_stream = ctx->stream;
   return XCX_OK;
 }
 
