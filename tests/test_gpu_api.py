@@ -243,6 +243,24 @@ def test_prepare_pipelines_the_forward_transforms(ctx):
         CCPlan(ctx, n, stack=True).prepare(da, W, hop)
     with pytest.raises(ValueError):
         plan.prepare(a, W, hop)                    # host array
+    # an UNPREPARED call (its forward transforms run on the main stream) followed at once by a preparation for the
+    # next traces (forward transforms on the side stream): the two share the plan's transform workspace and must
+    # not run at the same time -- sizes at which a forward pass takes about a millisecond
+    S2, n2, hop2, W2 = 48, 20000, 10000, 24
+    T2 = (W2 - 1) * hop2 + n2
+    p2 = np.array([(0, 1), (5, 40), (47, 2), (13, 13), (30, 31), (8, 25)], np.int32)
+    a2 = ctx.array(rng.standard_normal((S2, T2)).astype(np.float32))
+    b2 = ctx.array(rng.standard_normal((S2, T2)).astype(np.float32))
+    big = CCPlan(ctx, n2, normalize=True, demean=True)
+    oa, ob = ctx.empty((len(p2) * W2, big.L)), ctx.empty((len(p2) * W2, big.L))
+    ra = big.pairs(a2, p2, W2, hop2, out=oa).to_host().copy()
+    rb = big.pairs(b2, p2, W2, hop2, out=ob).to_host().copy()
+    for _ in range(3):
+        big.pairs(a2, p2, W2, hop2, out=oa)        # unprepared, asynchronous
+        big.prepare(b2, W2, hop2)                  # must wait for that forward pass, not for its pair phase
+        big.pairs(b2, p2, W2, hop2, out=ob)        # consumes the preparation
+        assert np.array_equal(oa.to_host(), ra) and np.array_equal(ob.to_host(), rb)
+    big.close()
 
 
 def test_column_views_select_window_blocks(ctx):
