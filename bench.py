@@ -276,11 +276,11 @@ def main():
                 plan.stack_add(sd.view, pairs, W, hop, stride_s=T)
             if raws:
                 plan.stack_finish(pairs, out=out, ld_out=ld)
+            else:
+                out.zero()                       # more ranks than days: this rank contributes zeros
         except BaseException:
             plan.stack_reset()                   # do not leave the plan refusing every later call
             raise
-        else:
-            out.zero()                           # more ranks than days: contributes zeros
         if rccl:
             ctx.stack_reduce(out, count=nrows * ld, reduce_scatter=(rccl == 'reduce_scatter'))
 
@@ -422,6 +422,17 @@ def main():
         res['rccl_stack_reduce'] = rccl
         res['rccl_ranks'] = rccl_ranks if rccl else None     # ncclCommCount of the communicator used
         res['config']['station_days'] = ndays
+        if rank == 0:
+            # outside the timed region: the stack the last step left behind is a stack, not zeros
+            # (row 0 = pair (0, 1) lies in rank 0's slice of a reduce-scatter as well): its maximum
+            # sits where the synthetic move-out puts it, 25 samples per station index
+            row0 = out.rows_to_host(0, 1, L)[0]
+            i0, j0 = (int(v) for v in pairs_all[0])
+            want = n - 1 - imin + 25 * (i0 - j0)
+            res['stack_check'] = {'row0_absmax': float(np.abs(row0).max()), 'row0_argmax': int(np.argmax(row0)),
+                                  'row0_argmax_expected': want}
+            if not (res['stack_check']['row0_absmax'] > 0 and (not 0 <= want < L or int(np.argmax(row0)) == want)):
+                raise SystemExit(f"stacked output failed its sanity check: {res['stack_check']}")
     if rank == 0:
         sha = lib_sha256()
         res['lib_sha256'] = sha

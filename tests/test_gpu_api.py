@@ -203,6 +203,25 @@ def test_bench_contract_small(ctx):
     assert len(d['lib_sha256']) == 64
 
 
+def test_bench_stack_days_leaves_a_stack_behind(ctx):
+    """bench.py --stack --days 2 on one rank: the accumulate loop's result survives the step (an `else:` on
+    the wrong block once zeroed it after every successful stack_finish) -- the line carries `stack_check`
+    and the bench refuses to print a line for an all-zero stack."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--stations', '6', '--seconds', '14400',
+                          '--stack', '--days', '2', '--steps', '1', '--warmup', '1', '--no-cpu-baseline'],
+                         capture_output=True, text=True, timeout=300, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+    chk = d['stack_check']
+    assert chk['row0_absmax'] > 0 and chk['row0_argmax'] == chk['row0_argmax_expected']
+    assert d['config']['station_days'] == 2
+
+
 def test_prepare_pipelines_the_forward_transforms(ctx):
     """xcx_cc1d_prepare: spectra computed ahead on a side stream are consumed by the
     matching pairs() call (bit-identical results); a non-matching call discards them."""

@@ -362,6 +362,29 @@ def test_io_keeps_hash_variable(tmp_path):
     assert r.hash.shape == ds.hash.shape and r.hash[0, 2] == 'ab' * 32 and r.hash[0, 0] == 'n/a'
 
 
+def test_io_drops_digests_of_other_schemes(tmp_path):
+    """A container that carries `sha256_hash` (earlier builds of this writer, or the reference's attribute) is
+    written without it and read without it: the only digest in a file is the one computed over its own data."""
+    from scipy.io import netcdf_file
+    from xcorr_amd import io
+    ds = core.init('A.B..C-D.E..F', 0., 3600., sampling_rate=10., window_length=600., window_overlap=.5)
+    ds.status[...] = 1
+    ds.attrs['sha256_hash'] = 'f' * 64
+    ds.attrs['sha256_hash_metadata'] = 'e' * 64
+    path = str(tmp_path / 's.nc')
+    assert io.write(ds, path)
+    with netcdf_file(path, 'r', mmap=False) as nc:
+        assert 'sha256_hash' not in nc._attributes and 'sha256_hash_metadata' not in nc._attributes
+        assert io.nc.HASH_ATTR in nc._attributes
+    # a file of an earlier build: the old attribute is present in the file itself
+    with netcdf_file(path, 'a', mmap=False) as nc:
+        nc.sha256_hash = b'd' * 64
+    r = io.read(path)
+    assert 'sha256_hash' not in r.attrs and io.nc.HASH_ATTR not in r.attrs
+    m = io.merge(r, r)
+    assert 'sha256_hash' not in m.attrs
+
+
 def test_init_hash_variable():
     from xcorr_amd.core import init
     ds = init('IM.H10N1..EDH-IU.RAR.10.BHZ', 0., 7200., sampling_rate=50., window_length=3600., window_overlap=.5,

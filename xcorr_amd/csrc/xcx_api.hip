@@ -143,10 +143,17 @@ extern "C" int xcx_init(int device, xcx_ctx** out) {
   xcx_ctx* ctx = new (std::nothrow) xcx_ctx();
   if (!ctx) return set_err(XCX_ENOMEM, "host allocation failed");
   ctx->device = device;
-  HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-  for (int i = 0; i < 2; ++i) HIP_TRY(hipStreamCreateWithFlags(&ctx->pipe[i], hipStreamNonBlocking));   // see xcx_internal.h
-  HIP_TRY(hipEventCreate(&ctx->ev0));
-  HIP_TRY(hipEventCreate(&ctx->ev1));
+  // streams and events: a failure part-way releases what exists (xcx_destroy copes with null members)
+  hipError_t he = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+  for (int i = 0; i < 2 && he == hipSuccess; ++i)
+    he = hipStreamCreateWithFlags(&ctx->pipe[i], hipStreamNonBlocking);   // see xcx_internal.h
+  if (he == hipSuccess) he = hipEventCreate(&ctx->ev0);
+  if (he == hipSuccess) he = hipEventCreate(&ctx->ev1);
+  if (he != hipSuccess) {
+    (void)hipGetLastError();
+    xcx_destroy(ctx);
+    return set_err(XCX_EHIP, "xcx_init: %s", hipGetErrorString(he));
+  }
   *out = ctx;
   return XCX_OK;
 }
@@ -154,7 +161,7 @@ extern "C" int xcx_init(int device, xcx_ctx** out) {
 extern "C" int xcx_destroy(xcx_ctx* ctx) {
   if (!ctx) return XCX_OK;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   xcx_comm_destroy(ctx);
   if (ctx->ts_plan) xcx_plan_destroy(ctx->ts_plan);
   for (auto* bp : ctx->bs_plan) if (bp) xcx_plan_destroy(bp);
@@ -167,9 +174,9 @@ extern "C" int xcx_destroy(xcx_ctx* ctx) {
   if (ctx->flow_err_host) (void)hipHostFree(ctx->flow_err_host);
   for (auto& ps : ctx->pipe)
     if (ps) { (void)hipStreamSynchronize(ps); (void)hipStreamDestroy(ps); }
-  (void)hipEventDestroy(ctx->ev0);
-  (void)hipEventDestroy(ctx->ev1);
-  (void)hipStreamDestroy(ctx->stream);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return XCX_OK;
 }
@@ -348,6 +355,7 @@ struct xcx_plan {
   // multi-day stacks: the spectra of up to acc_cap adds wait in station-major slots [S][acc_cap * acc_W] and go
   // through ONE Gram update (the read-modify-write of the P x N/2 accumulator is amortised over them)
   int acc_pending = 0, acc_W = 0, acc_cap = 1, acc_grams = 0;
+  bool acc_broken = false;   // an add / flush of the accumulation failed: only xcx_cc1d_stack_reset is accepted
   int fwd_slot_w = 0, fwd_slot_ld = 0;               // forward(): station-major slot mapping (0: dense)
   DevBuf psum, psq;          // partial statistics of a forward chunk
   int L = 0;                 // retained lags
@@ -566,14 +574,15 @@ extern "C" int xcx_plan_set_whiten(xcx_plan* p, double fs, double fmin,
                                    double fmax, double ftaper) {
   if (!p) return set_err(XCX_EINVAL, "null plan");
   if (p->seg) return set_err(XCX_EUNSUPPORTED, "segmented (long-window) plans do not whiten");
-  if (p->acc_count > 0)           // days already transformed with the old band wait for their Gram update
-    return set_err(XCX_EINVAL, "xcx_plan_set_whiten during a stack accumulation (%d adds): finish or reset it first", p->acc_count);
+  if (!(fs > 0) || !(fmin >= 0) || !(fmax > fmin) || ftaper < 0)      // before anything is touched: a refused
+    return set_err(XCX_EINVAL, "bad whitening band");                  // call leaves the plan as it was
+  if (p->acc_count > 0 || p->acc_pending > 0 || p->acc_broken)   // days already transformed with the old band wait for their Gram
+    return set_err(XCX_EINVAL, "xcx_plan_set_whiten during a stack accumulation (%d adds, %d spectra sets "
+                   "pending): finish or reset it first", p->acc_count, p->acc_pending);   // update (also after a failed flush)
   if (p->prep_valid) {            // spectra prepared ahead (xcx_cc1d_prepare) carry the old band: let them finish, drop them
     HIP_TRY(hipStreamWaitEvent(p->ctx->stream, p->prep_done, 0));
     p->prep_valid = false;
   }
-  if (!(fs > 0) || !(fmin >= 0) || !(fmax > fmin) || ftaper < 0)
-    return set_err(XCX_EINVAL, "bad whitening band");
   const double bin = (double)p->g.N / fs;   // bins per Hz
   // band edges in bins, float for the kernels; rounding to float must not carry an edge across an integer bin
   // (fmax * bin = 21377.9994 rounds to 21378.0f and would admit bin 21378): lower edges compare k >= edge,
@@ -772,6 +781,8 @@ static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_
 static int pair_batch(xcx_plan* p, size_t d0, int B, float* out, int nstack, const cf* Xsrc = nullptr) {
   xcx_ctx* ctx = p->ctx;
   const Geom& g = p->g;
+  if (nstack > 2)      // MODE 1 of the column pass sums exactly two slots; longer stacks go through the Gram kernels
+    return set_err(XCX_EINVAL, "pair_batch: a stack of %d windows in the pair column pass (at most 2)", nstack);
   WI1Args a{};
   a.X = Xsrc ? Xsrc : (const cf*)p->spectra.ptr;
   a.spec_pitch = p->spec_pitch;
@@ -811,6 +822,8 @@ static int dual_launch(xcx_plan* p, int chain, size_t d0, int Bc, int nstack, fl
   xcx_plan::Chain& ch = p->chains[chain];
   const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
   cf* Tbase = (cf*)p->T.ptr + (size_t)chain * 2 * tm_per * p->batch;
+  if (nstack > 2)      // MODE 1 of the column pass sums exactly two slots; longer stacks go through the Gram kernels
+    return set_err(XCX_EINVAL, "dual_launch: a stack of %d windows in the pair column pass (at most 2)", nstack);
   WDualArgs a{};
   a.X = Xsrc ? Xsrc : (const cf*)p->spectra.ptr;
   a.spec_pitch = p->spec_pitch;
@@ -937,6 +950,8 @@ static int flow_run(xcx_plan* p, size_t first, size_t count, int nstack, float* 
   const size_t nsync = (size_t)(nbatch + 1) * 8 * kFlowShardInts;     // ints per counter array
   if ((rc = p->flow_sync.ensure(ctx, sizeof(int) * 2 * nsync))) return rc;
   HIP_TRY(hipMemsetAsync(p->flow_sync.ptr, 0, sizeof(int) * 2 * nsync, ctx->stream));
+  if (nstack > 2)      // MODE 1 of the column pass sums exactly two slots; longer stacks go through the Gram kernels
+    return set_err(XCX_EINVAL, "flow_run: a stack of %d windows in the pair column pass (at most 2)", nstack);
   WFlowArgs a{};
   a.X = Xsrc ? Xsrc : (const cf*)p->spectra.ptr;
   a.spec_pitch = p->spec_pitch;
@@ -1105,6 +1120,8 @@ extern "C" int xcx_cc1d_stack_add(xcx_plan* p, const float* traces, int S, int W
   if ((rc = check_pairs(pairs, S, P))) return rc;
   unsigned long long akey = fnv(pairs, sizeof(int) * 2 * (size_t)P, 1469598103934665603ULL);
   akey = fnv(&S, sizeof S, akey) | 1ULL;
+  if (p->acc_broken)
+    return set_err(XCX_EINVAL, "xcx_cc1d_stack_add: an earlier add of this accumulation failed; call xcx_cc1d_stack_reset first");
   if (p->acc_count > 0 && akey != p->acc_key)
     return set_err(XCX_EINVAL, "xcx_cc1d_stack_add: pair list / station count differ from the accumulation in progress");
   const float* dtr = traces;
@@ -1118,7 +1135,9 @@ extern "C" int xcx_cc1d_stack_add(xcx_plan* p, const float* traces, int S, int W
   if ((rc = stack_tables(p, pairs, S, P, p->acc_ld))) return rc;
   // adds of equal W are collected (station-major slots, cap so that the spectra stay below 24 GB) and go
   // through one Gram update; a different W flushes what is pending first
-  if (p->acc_pending > 0 && W != p->acc_W) { if ((rc = stack_flush(p))) return rc; }
+  // (a failure from here on leaves spectra slots and the accumulator in an unknown state: the plan then refuses
+  // everything but xcx_cc1d_stack_reset -- a later add would otherwise index slots past the spectra buffer)
+  if (p->acc_pending > 0 && W != p->acc_W) { if ((rc = stack_flush(p))) { p->acc_broken = true; return rc; } }
   if (p->acc_pending == 0) {
     static const int want = getenv("XCX_STACK_DAYS") ? std::max(1, atoi(getenv("XCX_STACK_DAYS"))) : 4;
     const size_t per_add = sizeof(cf) * p->spec_pitch * (size_t)S * W;
@@ -1129,10 +1148,10 @@ extern "C" int xcx_cc1d_stack_add(xcx_plan* p, const float* traces, int S, int W
   p->fwd_slot_w = W; p->fwd_slot_ld = W * p->acc_cap;
   rc = forward(p, dtr, stride_s, stride_w, W, 0, 0, S * W, p->acc_pending * W);
   p->fwd_slot_w = p->fwd_slot_ld = 0;
-  if (rc) return rc;
+  if (rc) { p->acc_broken = p->acc_count > 0 || p->acc_pending > 0; return rc; }
   p->acc_key = akey; p->acc_S = S; p->acc_P = P;
   p->acc_pending += 1;
-  if (p->acc_pending == p->acc_cap && (rc = stack_flush(p))) return rc;
+  if (p->acc_pending >= p->acc_cap && (rc = stack_flush(p))) { p->acc_broken = true; return rc; }
   if (!on_device) HIP_TRY(hipStreamSynchronize(ctx->stream));     // the staging buffer may be reused
   p->acc_count += 1; p->acc_windows += W;
   return XCX_OK;
@@ -1144,12 +1163,15 @@ extern "C" int xcx_cc1d_stack_reset(xcx_plan* p) {
   // xcx_cc1d_pairs / a new accumulation again; the accumulator is overwritten by the next first flush
   if (p->ctx) (void)hipStreamSynchronize(p->ctx->stream);
   p->acc_count = 0; p->acc_pending = 0; p->acc_grams = 0; p->acc_windows = 0; p->acc_key = 0;
+  p->acc_broken = false;
   return XCX_OK;
 }
 
 extern "C" int xcx_cc1d_stack_finish(xcx_plan* p, const int* pairs, int P, float* out, long ld_out,
                                      int on_device, long long* windows) {
   if (!p || !pairs || !out) return set_err(XCX_EINVAL, "null argument");
+  if (p->acc_broken)
+    return set_err(XCX_EINVAL, "xcx_cc1d_stack_finish: an add of this accumulation failed; call xcx_cc1d_stack_reset");
   if (p->acc_count < 1) return set_err(XCX_EINVAL, "xcx_cc1d_stack_finish: nothing accumulated");
   xcx_ctx* ctx = p->ctx;
   HIP_TRY(hipSetDevice(ctx->device));
@@ -1171,7 +1193,7 @@ extern "C" int xcx_cc1d_stack_finish(xcx_plan* p, const int* pairs, int P, float
     if ((rc = p->dout.ensure(ctx, (size_t)P * (size_t)ld_out * sizeof(float)))) return rc;
     dout = (float*)p->dout.ptr;
   }
-  if ((rc = stack_flush(p))) return rc;
+  if ((rc = stack_flush(p))) { p->acc_broken = true; return rc; }
   if ((rc = stack_inverse(p, P, dout))) return rc;
   if (windows) *windows = p->acc_windows;
   p->acc_count = 0; p->acc_windows = 0; p->acc_grams = 0;
@@ -1188,7 +1210,7 @@ extern "C" int xcx_cc1d_pairs(xcx_plan* p, const float* traces, int S, int W,
                               long stride_s, long stride_w, const int* pairs,
                               int P, float* out, long ld_out, int on_device) {
   if (!p || !traces || !pairs || !out) return set_err(XCX_EINVAL, "null argument");
-  if (p->acc_count > 0)           // before anything touches the spectra that wait for their Gram update
+  if (p->acc_count > 0 || p->acc_pending > 0 || p->acc_broken)   // before anything touches the spectra that wait for their Gram update
     return set_err(XCX_EINVAL, "xcx_cc1d_pairs: a xcx_cc1d_stack_add accumulation is in progress on this plan");
   if (S < 1 || W < 1 || P < 1) return set_err(XCX_EINVAL, "S, W, P must be >= 1");
   xcx_ctx* ctx = p->ctx;

@@ -45,6 +45,10 @@ def ncfile(pair, time, root=None):
 # metadata and every variable of a NetCDF-4 file (xcorr/io/write.py:88-137) -- a different scheme over a
 # different container, so reusing the name would make each side reject the other's files as corrupt.
 HASH_ATTR = 'xcorr_amd_sha256'
+# Files of earlier builds of this writer carry ``sha256_hash`` (their two-variable digest); the reference writes
+# ``sha256_hash`` and ``sha256_hash_metadata`` (io/write.py:98-137).  Neither is this module's digest: they are
+# dropped on read and never written back, so no file leaves here with a digest that no longer matches its data.
+_STALE_HASH_ATTRS = ('sha256_hash', 'sha256_hash_metadata')
 
 
 def _data_hash(ds):
@@ -140,7 +144,8 @@ def write(data, path, close=True, force_write=False, hash_data=True, verb=0):
                 v.long_name, v.standard_name, v.units = ('pair preprocessed stream hash',
                                                          'pair_preprocessed_stream_hash', '-')
             for k, a in data.attrs.items():
-                setattr(nc, k, _attr(a))
+                if k != HASH_ATTR and k not in _STALE_HASH_ATTRS:     # never a digest computed over other data
+                    setattr(nc, k, _attr(a))
             nc.Conventions = 'CF-1.9'
             nc.xcorr_amd_format = 'NetCDF-3 64-bit offset; layout of xcorr/core/init.py:237-320'
             if hash_data:
@@ -205,6 +210,8 @@ def read(path, fast=False, quick_and_dirty=False, extract=False):
         ds.pair_attrs = attrs(nc.variables['pair'])
         ga = attrs(nc)
         stored = ga.pop(HASH_ATTR, None)
+        for k in _STALE_HASH_ATTRS:       # digests of another scheme (earlier builds of this writer, or the
+            ga.pop(k, None)               # reference's): not verifiable here, and stale once rewritten
         ds.attrs = ga
     if stored is not None and not quick_and_dirty and stored != _data_hash(ds):
         raise ValueError(f'{path}: data sha256 hash does not match the stored one')
@@ -265,7 +272,7 @@ def merge(*datasets, extract=False, quick_and_dirty=False):
             out.time_offset[row, cols] = d.time_offset[ip, take]
             if out.hash is not None and getattr(d, 'hash', None) is not None:
                 out.hash[row, cols] = d.hash[ip, take]
-    out.attrs = {k: v for k, v in first.attrs.items() if k != HASH_ATTR}
+    out.attrs = {k: v for k, v in first.attrs.items() if k != HASH_ATTR and k not in _STALE_HASH_ATTRS}
     t0, t1 = _utc(times[0]), _utc(times[-1])
     s0, s1 = t0.strftime('%Y.%j'), t1.strftime('%Y.%j')
     title = str(out.attrs.get('title', '')).split(' - ')[0]

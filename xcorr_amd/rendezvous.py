@@ -10,6 +10,7 @@ provides RANK / WORLD_SIZE / MASTER_PORT; the launcher's pid (the common parent
 of all ranks) and the port make the directory unique per launch.
 """
 import os
+import stat
 import struct
 import time
 
@@ -37,13 +38,19 @@ class FileRendezvous:
 
     def __init__(self, rank, world, key, root=None, timeout=600.0):
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
-        root = root or os.environ.get('XCX_RDZV_DIR') or '/tmp'
+        # a per-user runtime directory when the session has one; /tmp is the last resort
+        root = root or os.environ.get('XCX_RDZV_DIR') or os.environ.get('XDG_RUNTIME_DIR') or '/tmp'
         self.dir = os.path.join(root, f'xcx_rdzv_{key}')
         os.makedirs(self.dir, mode=0o700, exist_ok=True)
-        try:
-            os.chmod(self.dir, 0o700)
-        except OSError:
-            pass
+        # the name is predictable: accept only a real directory of our own that nobody else can write to
+        # (a directory or symlink planted by another user would hand them the acks and the RCCL id)
+        st = os.lstat(self.dir)
+        if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.geteuid():
+            raise PermissionError(f'rendezvous: {self.dir} is not a directory owned by uid {os.geteuid()}')
+        if st.st_mode & 0o077:
+            os.chmod(self.dir, 0o700)                        # ours, created by an older umask: tighten or fail
+            if os.lstat(self.dir).st_mode & 0o077:
+                raise PermissionError(f'rendezvous: {self.dir} is accessible to other users')
         self.seq = 0
         self.session = self._handshake()
 
@@ -175,6 +182,17 @@ def from_env():
     if world <= 1:
         return _Single()
     rank = int(os.environ['RANK'])
-    key = os.environ.get('XCX_RDZV_KEY') or \
-        f"{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'none')}_{os.getppid()}"
+    # unique per launch: the launcher's own ids where it provides them (torchrun: run id + port; Slurm / MPI:
+    # job and step ids), always the launcher's pid and its start time -- two launches from one shell differ in
+    # the latter even when port and run id are defaults
+    ppid = os.getppid()
+    try:
+        with open(f'/proc/{ppid}/stat', 'rb') as fh:
+            born = fh.read().rsplit(b')', 1)[1].split()[19].decode()     # field 22: start time in clock ticks
+    except (OSError, IndexError):
+        born = 'x'
+    ids = [os.environ.get(v, '') for v in ('MASTER_PORT', 'TORCHELASTIC_RUN_ID', 'SLURM_JOB_ID', 'SLURM_STEP_ID',
+                                           'OMPI_MCA_ess_base_jobid', 'PMI_JOBID')]
+    key = os.environ.get('XCX_RDZV_KEY') or '_'.join([v for v in ids if v] + [str(ppid), born])
+    key = ''.join(ch if ch.isalnum() or ch in '-_.' else '-' for ch in key)[:120]    # one path component
     return FileRendezvous(rank, world, key)
