@@ -132,3 +132,34 @@ def test_window_blocks_cover_the_day():
             assert all(b[1] == c[0] for b, c in zip(blocks, blocks[1:]))
             sizes = [b[1] - b[0] for b in blocks]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_rendezvous_directory_must_be_ours_and_private(tmp_path, monkeypatch):
+    """The rendezvous directory has a predictable name: a symlink or a directory that other users can enter
+    is refused (it would hand them the acks and the RCCL unique id), one of our own with a loose mode is
+    tightened; an unusable XDG_RUNTIME_DIR falls back to the next root, an explicit root fails loudly."""
+    import stat
+    from xcorr_amd.rendezvous import FileRendezvous
+    real = tmp_path / 'elsewhere'
+    real.mkdir()
+    link = tmp_path / 'xcx_rdzv_k1'
+    link.symlink_to(real, target_is_directory=True)
+    with pytest.raises(PermissionError):
+        FileRendezvous._claim(str(link))
+    loose = tmp_path / 'xcx_rdzv_k2'
+    loose.mkdir(mode=0o755)
+    os.chmod(loose, 0o755)
+    FileRendezvous._claim(str(loose))
+    assert stat.S_IMODE(os.lstat(loose).st_mode) == 0o700
+    # implicit roots: a dead XDG_RUNTIME_DIR is skipped
+    monkeypatch.delenv('XCX_RDZV_DIR', raising=False)
+    (tmp_path / 'file_not_dir').write_text('x')            # makedirs below it fails with NotADirectoryError
+    monkeypatch.setenv('XDG_RUNTIME_DIR', str(tmp_path / 'file_not_dir' / 'deeper'))
+    r = FileRendezvous(0, 1, f'k3_{os.getpid()}')
+    assert r.dir.startswith('/tmp/')
+    r.close()
+    # explicit root that cannot be used: error, no silent fallback
+    blocker = tmp_path / 'file'
+    blocker.write_text('x')
+    with pytest.raises(OSError):
+        FileRendezvous(0, 1, 'k4', root=str(blocker))

@@ -38,21 +38,37 @@ class FileRendezvous:
 
     def __init__(self, rank, world, key, root=None, timeout=600.0):
         self.rank, self.world, self.timeout = int(rank), int(world), float(timeout)
-        # a per-user runtime directory when the session has one; /tmp is the last resort
-        root = root or os.environ.get('XCX_RDZV_DIR') or os.environ.get('XDG_RUNTIME_DIR') or '/tmp'
-        self.dir = os.path.join(root, f'xcx_rdzv_{key}')
-        os.makedirs(self.dir, mode=0o700, exist_ok=True)
-        # the name is predictable: accept only a real directory of our own that nobody else can write to
-        # (a directory or symlink planted by another user would hand them the acks and the RCCL id)
-        st = os.lstat(self.dir)
-        if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.geteuid():
-            raise PermissionError(f'rendezvous: {self.dir} is not a directory owned by uid {os.geteuid()}')
-        if st.st_mode & 0o077:
-            os.chmod(self.dir, 0o700)                        # ours, created by an older umask: tighten or fail
-            if os.lstat(self.dir).st_mode & 0o077:
-                raise PermissionError(f'rendezvous: {self.dir} is accessible to other users')
+        # a per-user runtime directory when the session has one; /tmp is the last resort.  An explicit root
+        # (argument / XCX_RDZV_DIR) is used or fails loudly; the implicit candidates are tried in order
+        # (XDG_RUNTIME_DIR is often set but absent inside containers).
+        explicit = root or os.environ.get('XCX_RDZV_DIR')
+        roots = [explicit] if explicit else [r for r in (os.environ.get('XDG_RUNTIME_DIR'), '/tmp') if r]
+        last = None
+        for r in roots:
+            try:
+                self.dir = self._claim(os.path.join(r, f'xcx_rdzv_{key}'))
+                break
+            except OSError as e:           # PermissionError included
+                last = e
+        else:
+            raise last
         self.seq = 0
         self.session = self._handshake()
+
+    @staticmethod
+    def _claim(path):
+        """Create (or adopt) the rendezvous directory.  The name is predictable, so only a real directory of our
+        own that nobody else can enter is accepted: a directory or symlink planted by another user would hand
+        them the acks and the RCCL unique id."""
+        os.makedirs(path, mode=0o700, exist_ok=True)
+        st = os.lstat(path)
+        if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.geteuid():
+            raise PermissionError(f'rendezvous: {path} is not a directory owned by uid {os.geteuid()}')
+        if st.st_mode & 0o077:
+            os.chmod(path, 0o700)                            # ours, created under an older umask: tighten or fail
+            if os.lstat(path).st_mode & 0o077:
+                raise PermissionError(f'rendezvous: {path} is accessible to other users')
+        return path
 
     def _path(self, name):
         return os.path.join(self.dir, name)
