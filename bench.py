@@ -320,6 +320,19 @@ def main():
     wall = rdzv.max(time.perf_counter() - t0)
     rdzv.barrier()
 
+    # outside the timed region, before anything else touches `out` (the write-ceiling measurement below overwrites
+    # it): the stack the last step left behind is a stack, not zeros (row 0 = pair (0, 1) lies in rank 0's slice of a
+    # reduce-scatter as well) -- its maximum sits where the synthetic move-out puts it, 25 samples per station index
+    stack_check = None
+    if a.stack and rank == 0:
+        row0 = out.rows_to_host(0, 1, L)[0]
+        i0, j0 = (int(v) for v in pairs_all[0])
+        want = n - 1 - imin + 25 * (i0 - j0)
+        stack_check = {'row0_absmax': float(np.abs(row0).max()), 'row0_argmax': int(np.argmax(row0)),
+                       'row0_argmax_expected': want}
+        if not (stack_check['row0_absmax'] > 0 and (not 0 <= want < L or int(np.argmax(row0)) == want)):
+            raise SystemExit(f'stacked output failed its sanity check: {stack_check}')
+
     units_rank = P * W * a.steps * (len(my_days) if a.stack else 1)
     if a.stack:
         units_all = len(pairs_all) * W_all * ndays * a.steps
@@ -422,17 +435,8 @@ def main():
         res['rccl_stack_reduce'] = rccl
         res['rccl_ranks'] = rccl_ranks if rccl else None     # ncclCommCount of the communicator used
         res['config']['station_days'] = ndays
-        if rank == 0:
-            # outside the timed region: the stack the last step left behind is a stack, not zeros
-            # (row 0 = pair (0, 1) lies in rank 0's slice of a reduce-scatter as well): its maximum
-            # sits where the synthetic move-out puts it, 25 samples per station index
-            row0 = out.rows_to_host(0, 1, L)[0]
-            i0, j0 = (int(v) for v in pairs_all[0])
-            want = n - 1 - imin + 25 * (i0 - j0)
-            res['stack_check'] = {'row0_absmax': float(np.abs(row0).max()), 'row0_argmax': int(np.argmax(row0)),
-                                  'row0_argmax_expected': want}
-            if not (res['stack_check']['row0_absmax'] > 0 and (not 0 <= want < L or int(np.argmax(row0)) == want)):
-                raise SystemExit(f"stacked output failed its sanity check: {res['stack_check']}")
+        if stack_check is not None:
+            res['stack_check'] = stack_check
     if rank == 0:
         sha = lib_sha256()
         res['lib_sha256'] = sha

@@ -155,6 +155,29 @@ def test_timeshift_fft_path(ctx, size):
     assert relerr(S.timeshift(x, delay, fast=False, sampling_rate=fs), ref) < TOL
 
 
+@pytest.mark.parametrize('size,fast', [(6000, True), (5999, False), (40000, True)])
+def test_timeshift_rows_that_share_a_shift(ctx, size, fast):
+    """Rows of a launch group with the same delay share one Dirichlet kernel (generated and transformed
+    once): repeated delays in any order -- the reference's -(pair_offset + time_offset) pattern,
+    core/postprocess.py:118 -- over more than one launch group (256 rows), against the per-row oracle."""
+    rng = np.random.default_rng(size)
+    fs = 50.
+    rows = 300 if size < 10000 else 12
+    x = (rng.standard_normal((rows, size)) * np.hanning(size)).astype(np.float32)
+    vals = np.array([0.0, 0.0049, -0.0131, 0.02, 0.25 / fs])
+    delay = vals[rng.integers(0, len(vals), rows)]
+    delay[7] = 0.777                                   # one shift of its own in the middle of the group
+    got = ops.timeshift(ctx, x, delay, fs, fast=fast)
+    ref = R.timeshift(x, delay, fs) if fast else R.timeshift_fft(x, delay, 1. / fs)
+    assert got.shape == ref.shape
+    worst = max(relerr(got[r], ref[r]) for r in range(rows))
+    assert worst < TOL, worst
+    # every row of one shift: one kernel for the whole call
+    one = ops.timeshift(ctx, x[:40], 0.0049, fs, fast=fast)
+    ref1 = R.timeshift(x[:40], 0.0049, fs) if fast else R.timeshift_fft(x[:40], np.full(40, 0.0049), 1. / fs)
+    assert relerr(one, ref1) < TOL
+
+
 def test_timeshift_full_lag_axis(ctx):
     """L = 359999 lags -> n = 359998 = 2 * 179999 (prime): no FFT of that length
     exists in the engine; the circular convolution runs at N = 737280."""

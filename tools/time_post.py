@@ -22,6 +22,9 @@ t('unbias', lambda: ops.unbias(ctx, x, n))
 t('demean', lambda: ops.demean(ctx, x))
 t('taper', lambda: ops.taper(ctx, x, 250))
 t('timeshift', lambda: ops.timeshift(ctx, x, delay, 50., out=y))
+delay5 = np.array([0.0, 0.0049, -0.0131, 0.02, 0.005])[np.random.default_rng(2).integers(0, 5, rows)]
+t('timeshift/5', lambda: ops.timeshift(ctx, x, delay5, 50., out=y))      # five distinct delays: kernels shared
+t('timeshift/1', lambda: ops.timeshift(ctx, x, 0.0049, 50., out=y))      # scalar delay
 t('sosfiltfilt', lambda: ops.sosfiltfilt(ctx, y, sos))
 t('taper2', lambda: ops.taper(ctx, y, 75))
 x2 = ctx.array((np.random.default_rng(0).standard_normal((rows, L)) * 0.01).astype(np.float32))

@@ -39,6 +39,7 @@ using namespace xcx;
 namespace {
 
 constexpr int NT = 256;
+constexpr int kGS = 16;  // pair slots per tile group of the pair pass (4 x 4 tiles)
 constexpr int CB = 16;   // columns per workgroup: 8 (64-byte segments, 4 workgroups per CU) measured +3 %, 32 (1 per CU) -28 %
 
 // LDS index padding of the row kernels: one extra slot per 16 keeps the stride-16 /
@@ -113,13 +114,29 @@ template <class RX, bool INV>
 __global__ __launch_bounds__(NT) void k2d_cols(const cf* __restrict__ A, const cf* __restrict__ B2, G2 g,
                                                const double* __restrict__ rowss, int normalize,
                                                const int2* __restrict__ pairs,
-                                               cf* __restrict__ out, const cf* __restrict__ tw_sub) {
+                                               cf* __restrict__ out, const cf* __restrict__ tw_sub,
+                                               const int* __restrict__ slots = nullptr, int slot_ncb = 0) {
   extern __shared__ __attribute__((aligned(16))) cf lds[];
   constexpr int P1 = RX::L;
-  const int col0 = blockIdx.x * CB;
-  const int q = blockIdx.y;
+  int col0 = blockIdx.x * CB;
+  int q = blockIdx.y;
   const int ncol = g.R + 1;
   const int pitch = g.pitch;
+  if constexpr (INV) {
+    // XCD-aware order of the pair pass (1-D grid; blockIdx % 8 labels the XCD under round-robin dispatch, used
+    // for locality only): XCD x takes the column blocks cb = x (mod 8); inside an XCD the kGS pair slots of one
+    // tile group (a 4 x 4 biclique of tiles, pair_groups2d below) run back to back for one column block, so the
+    // group's 8 tile slabs (64 KB each at P1 = 512) are fetched into that L2 once and re-read there by the other
+    // pairs of the group: 0.5 instead of 2 slab reads per pair across the fabric.
+    const int x = blockIdx.x & 7, sq = (int)(blockIdx.x >> 3);
+    const int ncx = (slot_ncb + 7) >> 3;
+    const int pg = sq % kGS, cbi = (sq / kGS) % ncx, grp = sq / (kGS * ncx);
+    const int cb = cbi * 8 + x;
+    if (cb >= slot_ncb) return;
+    q = slots[grp * kGS + pg];
+    if (q < 0) return;
+    col0 = cb * CB;
+  }
   if constexpr (!INV) {
     const cf* __restrict__ src = A + (size_t)q * g.F * pitch;
     cf* __restrict__ dst = out + (size_t)q * P1 * pitch;
@@ -166,7 +183,8 @@ __global__ __launch_bounds__(NT) void k2d_cols(const cf* __restrict__ A, const c
 // inverse rows + fftshift map + arg-max: grid (P1, pairs)
 template <class RX>
 __global__ __launch_bounds__(NT) void k2d_rows_inv(const cf* __restrict__ T2, G2 g, float inv_n,
-                                                   float* __restrict__ full, float* __restrict__ rowbest,
+                                                   float* __restrict__ full, const int* __restrict__ oidx,
+                                                   float* __restrict__ rowbest,
                                                    long long* __restrict__ rowidx, const cf* __restrict__ tw_sub,
                                                    const cf* __restrict__ tw_unt) {
   extern __shared__ __attribute__((aligned(16))) cf lds[];
@@ -212,7 +230,8 @@ __global__ __launch_bounds__(NT) void k2d_rows_inv(const cf* __restrict__ T2, G2
   };
   float best = -INFINITY;
   int bestj = 0x7fffffff;                      // column of the row maximum (first occurrence)
-  float* __restrict__ frow = (full && row_ok) ? full + ((size_t)q * OH + i) * OW : nullptr;
+  // the pass runs the pairs in tile-group order; the full map goes to the caller's pair index
+  float* __restrict__ frow = (full && row_ok) ? full + ((size_t)oidx[q] * OH + i) * OW : nullptr;
   auto out_f = [&](int m, int, cf u) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -299,13 +318,35 @@ template <class K> hipError_t big_lds(K kernel, size_t bytes) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-struct Bufs {
-  DevBuf &S1, &S2, &T2, &misc;
+// Pair order of the pair pass: pairs are grouped by the 4 x 4 tile block (a / 4, b / 4) they fall in -- at most kGS
+// pairs on at most 8 tiles per group -- and run in that order (k2d_cols<INV>); `orig` maps back to the caller's index.
+struct PairOrder {
+  std::vector<int2> sorted;        // pairs in run order
+  std::vector<int> orig;           // run order -> caller's pair index
+  std::vector<int> gfirst;         // first run index of every group, plus the end
+  const int2* dsorted = nullptr;   // device copies
+  const int* dorig = nullptr;
+  int* dslots = nullptr;           // [groups of one pass][kGS]: pass-local pair index or -1 (rewritten per pass)
 };
+
+void pair_groups2d(const int* pairs, int P, int T, PairOrder& o) {
+  const long nb = (T + 3) / 4;
+  std::vector<std::pair<long, int>> key(P);
+  for (int i = 0; i < P; ++i) key[i] = {(long)(pairs[2 * i] / 4) * nb + pairs[2 * i + 1] / 4, i};
+  std::stable_sort(key.begin(), key.end(), [](const std::pair<long, int>& a, const std::pair<long, int>& b) { return a.first < b.first; });
+  o.sorted.resize(P); o.orig.resize(P); o.gfirst.clear();
+  for (int r = 0; r < P; ++r) {
+    const int i = key[r].second;
+    o.sorted[r] = make_int2(pairs[2 * i], pairs[2 * i + 1]);
+    o.orig[r] = i;
+    if (r == 0 || key[r].first != key[r - 1].first || r - o.gfirst.back() == kGS) o.gfirst.push_back(r);
+  }
+  o.gfirst.push_back(P);
+}
 
 // everything that depends on the row / column radices
 template <class RXR, class RXC>
-int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const int2* dpairs, int P, int normalize,
+int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const PairOrder& ord, int P, int normalize,
           float* dpeak_val, int* dpeak_idx, float* dfull, const cf* tw_r, const cf* tw_u, const cf* tw_c) {
   constexpr int R = RXR::L, P1 = RXC::L;
   DevBuf &S1 = ctx->scratch[1], &S2 = ctx->scratch[2], &T2 = ctx->scratch[4], &misc = ctx->scratch[5];
@@ -313,11 +354,12 @@ int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const int2* dpa
   const size_t rowb = sizeof(cf) * (size_t)g.pitch;
   if ((rc = S1.ensure(ctx, rowb * g.F * T))) return rc;
   if ((rc = S2.ensure(ctx, rowb * P1 * T))) return rc;
-  // pairs per pass: 512 MiB of intermediate T2 (larger passes amortise the launch tails; keeping
+  // pairs per pass: 1 GiB of intermediate T2 (three tile groups of 16 pairs at 512 x 8192; 512 MiB until round 4) (larger passes amortise the launch tails; keeping
   // T2 inside the 256 MiB Infinity Cache measured 5-10% slower, not faster -- and two overlapped
   // chains of 4-6 pair passes on their own streams, T2 cache-resident, measured the same 51 k
   // pairs/s as this single stream (round 3): the two kernels are not HBM-bound)
-  const int PB = (int)std::max<size_t>(1, std::min<size_t>((size_t)P, ((size_t)512 << 20) / (rowb * P1)));
+  // (whole tile groups per pass: at least one group of kGS pairs)
+  const int PB = (int)std::max<size_t>(kGS, std::min<size_t>((size_t)P, ((size_t)1 << 30) / (rowb * P1)));
   if ((rc = T2.ensure(ctx, rowb * P1 * PB))) return rc;
   if ((rc = misc.ensure(ctx, sizeof(double) * (size_t)T * g.F + (sizeof(float) + sizeof(long long)) * (size_t)P1 * PB + 64)))
     return rc;
@@ -337,22 +379,35 @@ int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const int2* dpa
                      (const double*)rowss, normalize, (const int2*)nullptr, (cf*)S2.ptr, tw_c);
   HIP_TRY(hipGetLastError());
   const float inv_n = 1.0f / ((float)P1 * (float)(2 * R));
-  const size_t OH = 2 * (size_t)g.F - 1, OW = 2 * (size_t)g.L - 1;
-  for (int p0 = 0; p0 < P; p0 += PB) {
-    const int cnt = std::min(PB, P - p0);
-    hipLaunchKernelGGL((k2d_cols<RXC, true>), dim3(ncb, cnt), dim3(NT), lds_c, s, (const cf*)S2.ptr, (const cf*)S2.ptr, g,
-                       (const double*)nullptr, 0, dpairs + p0, (cf*)T2.ptr, tw_c);
+  const size_t OW = 2 * (size_t)g.L - 1;
+  const int ngroups = (int)ord.gfirst.size() - 1;
+  const int ncx = (ncb + 7) / 8;
+  std::vector<int> slots;
+  for (int g0 = 0; g0 < ngroups;) {
+    // a pass = consecutive tile groups while their pairs fit the intermediate
+    int g1 = g0 + 1;
+    while (g1 < ngroups && ord.gfirst[g1 + 1] - ord.gfirst[g0] <= PB) ++g1;
+    const int p0 = ord.gfirst[g0], cnt = ord.gfirst[g1] - p0;
+    slots.assign((size_t)(g1 - g0) * kGS, -1);
+    for (int gi = g0; gi < g1; ++gi)
+      for (int r = ord.gfirst[gi]; r < ord.gfirst[gi + 1]; ++r) slots[(size_t)(gi - g0) * kGS + (r - ord.gfirst[gi])] = r - p0;
+    HIP_TRY(hipMemcpyAsync(ord.dslots, slots.data(), sizeof(int) * slots.size(), hipMemcpyHostToDevice, s));
+    HIP_TRY(hipStreamSynchronize(s));                       // `slots` is rewritten for the next pass
+    hipLaunchKernelGGL((k2d_cols<RXC, true>), dim3(8u * ncx * (g1 - g0) * kGS), dim3(NT), lds_c, s, (const cf*)S2.ptr,
+                       (const cf*)S2.ptr, g, (const double*)nullptr, 0, ord.dsorted + p0, (cf*)T2.ptr, tw_c,
+                       (const int*)ord.dslots, ncb);
     hipLaunchKernelGGL(k2d_rows_inv<RXR>, dim3(P1, cnt), dim3(NT), lds_r, s, (const cf*)T2.ptr, g, inv_n,
-                       dfull ? dfull + (size_t)p0 * OH * OW : nullptr, rowbest, rowidx, tw_r, tw_u);
+                       dfull, ord.dorig + p0, rowbest, rowidx, tw_r, tw_u);
     hipLaunchKernelGGL(k2d_peak, dim3(cnt), dim3(NT), 0, s, rowbest, rowidx, P1, (int)OW, dpeak_val + p0,
                        dpeak_idx + 2 * (size_t)p0);
     HIP_TRY(hipGetLastError());
+    g0 = g1;
   }
   return XCX_OK;
 }
 
 template <class RXR>
-int run2d_cols(int P1, xcx_ctx* ctx, const float* dt, int T, const G2& g, const int2* dp, int P, int nrm, float* pv,
+int run2d_cols(int P1, xcx_ctx* ctx, const float* dt, int T, const G2& g, const PairOrder& dp, int P, int nrm, float* pv,
                int* pi, float* full, const cf* tr, const cf* tu, const cf* tc) {
   switch (P1) {
     case 16: return run2d<RXR, Radices<4, 4>>(ctx, dt, T, g, dp, P, nrm, pv, pi, full, tr, tu, tc);
@@ -391,7 +446,11 @@ extern "C" int xcx_cc2d(xcx_ctx* ctx, const float* tiles, int T, int F, int L, c
   const size_t ntw = (size_t)2 * R + P1;
   const size_t OH = 2 * (size_t)F - 1, OW = 2 * (size_t)L - 1;
   const size_t tile_b = sizeof(float) * (size_t)T * F * L;
-  size_t extra = sizeof(int2) * (size_t)P + sizeof(float) * P + sizeof(int) * 2 * (size_t)P + 64;
+  PairOrder ord;
+  pair_groups2d(pairs, P, T, ord);
+  const size_t nslots = (size_t)(ord.gfirst.size() - 1) * kGS;          // upper bound of one pass
+  size_t extra = sizeof(int2) * (size_t)P + sizeof(float) * P + sizeof(int) * 2 * (size_t)P + sizeof(int) * (size_t)P +
+                 sizeof(int) * nslots + 5 * 64;
   if (!on_device) extra += tile_b + (full ? sizeof(float) * (size_t)P * OH * OW : 0);
   if ((rc = tw.ensure(ctx, sizeof(cf) * ntw + extra + 256))) return rc;
   cf* dtw = (cf*)tw.ptr;
@@ -400,6 +459,9 @@ extern "C" int xcx_cc2d(xcx_ctx* ctx, const float* tiles, int T, int F, int L, c
   int2* dpairs = (int2*)carve(sizeof(int2) * P);
   float* dpv = (float*)carve(sizeof(float) * P);
   int* dpi = (int*)carve(sizeof(int) * 2 * P);
+  int* dorig = (int*)carve(sizeof(int) * P);
+  ord.dslots = (int*)carve(sizeof(int) * nslots);
+  ord.dsorted = dpairs; ord.dorig = dorig;
   const float* dtiles = tiles;
   float* dfull = full;
   if (!on_device) {
@@ -411,24 +473,34 @@ extern "C" int xcx_cc2d(xcx_ctx* ctx, const float* tiles, int T, int F, int L, c
   HIP_TRY(hipMemcpyAsync(dtw, tr.data(), sizeof(cf) * R, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemcpyAsync(dtw + R, tu.data(), sizeof(cf) * R, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemcpyAsync(dtw + 2 * R, tc.data(), sizeof(cf) * P1, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(dpairs, pairs, sizeof(int2) * P, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(dpairs, ord.sorted.data(), sizeof(int2) * P, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(dorig, ord.orig.data(), sizeof(int) * P, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   const cf *ptr_r = dtw, *ptr_u = dtw + R, *ptr_c = dtw + 2 * R;
   switch (R) {
-    case 32: rc = run2d_cols<Radices<8, 4>>(P1, ctx, dtiles, T, g, dpairs, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
-    case 64: rc = run2d_cols<Radices<8, 8>>(P1, ctx, dtiles, T, g, dpairs, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
-    case 128: rc = run2d_cols<Radices<8, 4, 4>>(P1, ctx, dtiles, T, g, dpairs, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
-    case 256: rc = run2d_cols<Radices<16, 16>>(P1, ctx, dtiles, T, g, dpairs, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
-    case 512: rc = run2d_cols<Radices<8, 8, 8>>(P1, ctx, dtiles, T, g, dpairs, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
-    case 1024: rc = run2d_cols<Radices<16, 8, 8>>(P1, ctx, dtiles, T, g, dpairs, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
-    case 2048: rc = run2d_cols<Radices<16, 16, 8>>(P1, ctx, dtiles, T, g, dpairs, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
-    default: rc = run2d_cols<Radices<16, 16, 16>>(P1, ctx, dtiles, T, g, dpairs, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
+    case 32: rc = run2d_cols<Radices<8, 4>>(P1, ctx, dtiles, T, g, ord, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
+    case 64: rc = run2d_cols<Radices<8, 8>>(P1, ctx, dtiles, T, g, ord, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
+    case 128: rc = run2d_cols<Radices<8, 4, 4>>(P1, ctx, dtiles, T, g, ord, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
+    case 256: rc = run2d_cols<Radices<16, 16>>(P1, ctx, dtiles, T, g, ord, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
+    case 512: rc = run2d_cols<Radices<8, 8, 8>>(P1, ctx, dtiles, T, g, ord, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
+    case 1024: rc = run2d_cols<Radices<16, 8, 8>>(P1, ctx, dtiles, T, g, ord, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
+    case 2048: rc = run2d_cols<Radices<16, 16, 8>>(P1, ctx, dtiles, T, g, ord, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
+    default: rc = run2d_cols<Radices<16, 16, 16>>(P1, ctx, dtiles, T, g, ord, P, normalize, dpv, dpi, dfull, ptr_r, ptr_u, ptr_c); break;
   }
   if (rc) return rc;
-  HIP_TRY(hipMemcpyAsync(peak_val, dpv, sizeof(float) * P, hipMemcpyDeviceToHost, ctx->stream));
-  HIP_TRY(hipMemcpyAsync(peak_idx, dpi, sizeof(int) * 2 * P, hipMemcpyDeviceToHost, ctx->stream));
+  // peaks come back in run order: scatter to the caller's pair index
+  std::vector<float> hv(P);
+  std::vector<int> hi(2 * (size_t)P);
+  HIP_TRY(hipMemcpyAsync(hv.data(), dpv, sizeof(float) * P, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipMemcpyAsync(hi.data(), dpi, sizeof(int) * 2 * P, hipMemcpyDeviceToHost, ctx->stream));
   if (!on_device && full)
     HIP_TRY(hipMemcpyAsync(full, dfull, sizeof(float) * (size_t)P * OH * OW, hipMemcpyDeviceToHost, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (int r = 0; r < P; ++r) {
+    const int i = ord.orig[r];
+    peak_val[i] = hv[r];
+    peak_idx[2 * i] = hi[2 * (size_t)r];
+    peak_idx[2 * i + 1] = hi[2 * (size_t)r + 1];
+  }
   return XCX_OK;
 }

@@ -157,16 +157,36 @@ static int timeshift_rows(xcx_ctx* ctx, const float* x, float* y, long batch, lo
   if (!seg && (rc = xcx_internal_spectra(plan, 2 * (size_t)chunk))) return rc;
   std::vector<PwDesc> d(chunk);
   std::vector<const float*> xs(chunk), ys(chunk);
+  // Rows of one launch group that share a shift share ONE Dirichlet kernel: it is generated and transformed once
+  // (the reference's delay is -(pair_offset + time_offset), core/postprocess.py:118 -- constant over long stretches
+  // of a pair's windows, and a scalar `delay` is one value for every row).  ukern[i] = kernel slot of row i.
+  std::vector<int> ukern(chunk);
+  std::vector<double> ualpha;
   for (long r0 = 0; r0 < batch; r0 += chunk) {
     const int cnt = (int)std::min<long>(chunk, batch - r0);
+    ualpha.clear();
+    for (int i = 0; i < cnt; ++i) {
+      const double al = alpha[r0 + i];
+      int u = -1;
+      // groups hold at most 256 rows and real delay sets are tiny: a linear scan of the distinct values is enough
+      for (int k = (int)ualpha.size() - 1; k >= 0; --k) if (ualpha[k] == al) { u = k; break; }
+      if (u < 0) { u = (int)ualpha.size(); ualpha.push_back(al); }
+      ukern[i] = u;
+    }
+    const int nk = (int)ualpha.size();
+    if (nk < cnt) {       // fewer kernels than rows: the distinct shifts replace this group's slice of the device array
+      HIP_TRY(hipMemcpyAsync((double*)dal.ptr + r0, ualpha.data(), sizeof(double) * nk, hipMemcpyHostToDevice, ctx->stream));
+      HIP_TRY(hipStreamSynchronize(ctx->stream));      // `ualpha` is reused by the next group
+    }
     const dim3 grid((unsigned)((n + 255) / 256), (unsigned)cnt);
-    hipLaunchKernelGGL(k_dirichlet, grid, dim3(256), 0, ctx->stream, (float*)hr.ptr, n, (long)cnt,
+    const dim3 kgrid((unsigned)((n + 255) / 256), (unsigned)nk);
+    hipLaunchKernelGGL(k_dirichlet, kgrid, dim3(256), 0, ctx->stream, (float*)hr.ptr, n, (long)nk,
                        (const double*)dal.ptr + r0, direct ? 1 : 0);
     HIP_TRY(hipGetLastError());
     if (direct) {
       if ((rc = xcx_internal_forward(plan, xd + r0 * size, size, 0, 1, 0, 0, cnt, 0, (int)n))) return rc;
-      if ((rc = xcx_internal_forward(plan, (const float*)hr.ptr, L, 0, 1, 0, 0, cnt, cnt, 0))) return rc;
-      for (int i = 0; i < cnt; ++i) d[i] = PwDesc{i, cnt + i, (long long)i * n};
+      if ((rc = xcx_internal_forward(plan, (const float*)hr.ptr, L, 0, 1, 0, 0, nk, cnt, 0))) return rc;
+      for (int i = 0; i < cnt; ++i) d[i] = PwDesc{i, cnt + ukern[i], (long long)i * n};
       if ((rc = xcx_internal_pairs(plan, d.data(), cnt, yd + r0 * n))) return rc;
       if (modulate) {
         hipLaunchKernelGGL(k_modulate, grid, dim3(256), 0, ctx->stream, yd + r0 * n, n, (long)cnt);
@@ -175,12 +195,12 @@ static int timeshift_rows(xcx_ctx* ctx, const float* x, float* y, long batch, lo
       continue;
     }
     if (seg) {
-      for (int i = 0; i < cnt; ++i) { xs[i] = xd + (r0 + i) * size; ys[i] = (const float*)hr.ptr + (long)i * n; }
+      for (int i = 0; i < cnt; ++i) { xs[i] = xd + (r0 + i) * size; ys[i] = (const float*)hr.ptr + (long)ukern[i] * n; }
       if ((rc = xcx_internal_seg_rows(plan, xs.data(), ys.data(), cnt, (float*)lin.ptr, ld))) return rc;
     } else {
       if ((rc = xcx_internal_forward(plan, xd + r0 * size, size, 0, 1, 0, 0, cnt, 0, 0))) return rc;
-      if ((rc = xcx_internal_forward(plan, (const float*)hr.ptr, n, 0, 1, 0, 0, cnt, cnt, 0))) return rc;
-      for (int i = 0; i < cnt; ++i) d[i] = PwDesc{i, cnt + i, (long long)i * ld};
+      if ((rc = xcx_internal_forward(plan, (const float*)hr.ptr, n, 0, 1, 0, 0, nk, cnt, 0))) return rc;
+      for (int i = 0; i < cnt; ++i) d[i] = PwDesc{i, cnt + ukern[i], (long long)i * ld};
       if ((rc = xcx_internal_pairs(plan, d.data(), cnt, (float*)lin.ptr))) return rc;
     }
     hipLaunchKernelGGL(k_fold, grid, dim3(256), 0, ctx->stream, (const float*)lin.ptr, ld, yd + r0 * n, n,
