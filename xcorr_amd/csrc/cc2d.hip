@@ -108,6 +108,44 @@ __global__ __launch_bounds__(NT) void k2d_rows_fwd(const float* __restrict__ til
   }
 }
 
+// Column transform of CB sequences with the inputs of the first stage ALREADY IN REGISTERS: the caller issues every
+// global load of the workgroup's slab up front, branch-free, so that all of them are in flight together.  (As a
+// `load(k1, c)` callback with a bounds check inside, every load pair sat in its own branch behind an
+// s_waitcnt vmcnt(0): 32 serialised memory round trips per thread -- the pair pass ran latency-bound at 3.6 TB/s.)
+// v[it][t] = input (j + t P1/R0, c) of butterfly b = tid + it NT, c = b % CB, j = b / CB.
+template <class RX, bool INV, class Out>
+__device__ __forceinline__ void subfft_regs(cf* __restrict__ lds, const cf* __restrict__ tw,
+                                            cf (&v)[(RX::L / RX::R0) * CB / NT][RX::R0], Out out) {
+  constexpr int L = RX::L, R0 = RX::R0;
+  constexpr int IT = (L / R0) * CB / NT;
+  static_assert((L / R0) * CB % NT == 0 && RX::S >= 2, "whole iterations, at least two stages");
+  const int tid = threadIdx.x;
+  auto lds_ld = [=](int p, int c) -> cf { return lds[p * CB + c]; };
+  auto lds_st = [=](int p, int c, cf w) { lds[p * CB + c] = w; };
+#pragma unroll
+  for (int it = 0; it < IT; ++it) {
+    const int b = tid + it * NT;
+    const int c = b % CB, j = b / CB;
+    Bfly<R0, INV>::run(v[it]);
+#pragma unroll
+    for (int t = 0; t < R0; ++t) lds_st(j * R0 + t, c, v[it][t]);        // Stockham positions of stage 0 (NS = 1)
+  }
+  __syncthreads();
+  if constexpr (RX::S == 2) {
+    fft_stage<L, RX::R1, R0, CB, NT, INV, false>(tw, lds_ld, out);
+  } else {
+    fft_stage<L, RX::R1, R0, CB, NT, INV, true>(tw, lds_ld, lds_st);
+    __syncthreads();
+    if constexpr (RX::S == 3) {
+      fft_stage<L, RX::R2, R0 * RX::R1, CB, NT, INV, false>(tw, lds_ld, out);
+    } else {
+      fft_stage<L, RX::R2, R0 * RX::R1, CB, NT, INV, true>(tw, lds_ld, lds_st);
+      __syncthreads();
+      fft_stage<L, RX::R3, R0 * RX::R1 * RX::R2, CB, NT, INV, false>(tw, lds_ld, out);
+    }
+  }
+}
+
 // columns: grid (ceil((R+1)/16), T or pairs).  INV = false: forward transform of
 // the F rows of S1 (zero rows beyond), scaled; INV = true: A conj(B), inverse.
 template <class RX, bool INV>
@@ -154,7 +192,10 @@ __global__ __launch_bounds__(NT) void k2d_cols(const cf* __restrict__ A, const c
     }
     auto in = [=](int f, int c) -> cf {
       const int col = col0 + c;
-      return (f < F && col < ncol) ? src[(size_t)f * pitch + col] : make_float2(0.f, 0.f);
+      // unconditional load (clamped row; padding columns lie inside the row), then a select: a load inside the
+      // conditional becomes a branch with its own s_waitcnt and serialises the slab's loads
+      const cf v = src[(size_t)(f < F ? f : F - 1) * pitch + col];
+      return (f < F && col < ncol) ? v : make_float2(0.f, 0.f);
     };
     auto o = [=](int k1, int c, cf v) {
       const int col = col0 + c;
@@ -166,17 +207,37 @@ __global__ __launch_bounds__(NT) void k2d_cols(const cf* __restrict__ A, const c
     const cf* __restrict__ a = A + (size_t)pr.x * P1 * pitch;
     const cf* __restrict__ b = B2 + (size_t)pr.y * P1 * pitch;
     cf* __restrict__ dst = out + (size_t)q * P1 * pitch;
-    auto in = [=](int k1, int c) -> cf {
-      const int col = col0 + c;
-      if (col >= ncol) return make_float2(0.f, 0.f);
-      const size_t o2 = (size_t)k1 * pitch + col;
-      return cmulc(a[o2], b[o2]);
-    };
     auto o = [=](int m1, int c, cf v) {
       const int col = col0 + c;
       if (col < ncol) dst[(size_t)m1 * pitch + col] = v;
     };
-    subfft<RX, CB, CB, NT, true, false>(lds, tw_sub, in, o);
+    if constexpr (RX::S >= 2 && (P1 / RX::R0) * CB % NT == 0) {
+      // every load of the slab first (the pitch is a multiple of CB: columns beyond ncol are padding inside the
+      // row, their products are never stored), then the products, then the transform
+      constexpr int R0 = RX::R0, IT = (P1 / R0) * CB / NT;
+      cf va[IT][R0], vb[IT][R0];
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int bq = threadIdx.x + it * NT;
+        const unsigned o2 = (unsigned)(bq / CB) * (unsigned)pitch + (unsigned)(col0 + bq % CB);
+#pragma unroll
+        for (int t = 0; t < R0; ++t) {
+          va[it][t] = a[o2 + (unsigned)(t * (P1 / R0)) * (unsigned)pitch];
+          vb[it][t] = b[o2 + (unsigned)(t * (P1 / R0)) * (unsigned)pitch];
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < IT; ++it)
+#pragma unroll
+        for (int t = 0; t < R0; ++t) va[it][t] = cmulc(va[it][t], vb[it][t]);
+      subfft_regs<RX, true>(lds, tw_sub, va, o);
+    } else {
+      auto in = [=](int k1, int c) -> cf {
+        const size_t o2 = (size_t)k1 * pitch + col0 + c;          // inside the padded row
+        return cmulc(a[o2], b[o2]);
+      };
+      subfft<RX, CB, CB, NT, true, false>(lds, tw_sub, in, o);
+    }
   }
 }
 
@@ -326,13 +387,14 @@ struct PairOrder {
   std::vector<int> gfirst;         // first run index of every group, plus the end
   const int2* dsorted = nullptr;   // device copies
   const int* dorig = nullptr;
-  int* dslots = nullptr;           // [groups of one pass][kGS]: pass-local pair index or -1 (rewritten per pass)
+  int* dslots = nullptr;           // [groups][kGS]: pass-local pair index or -1
 };
 
 void pair_groups2d(const int* pairs, int P, int T, PairOrder& o) {
   const long nb = (T + 3) / 4;
+  static const bool grouped = !(getenv("XCX_CC2D_GROUPS") && atoi(getenv("XCX_CC2D_GROUPS")) == 0);   // 0: caller's order (A/B)
   std::vector<std::pair<long, int>> key(P);
-  for (int i = 0; i < P; ++i) key[i] = {(long)(pairs[2 * i] / 4) * nb + pairs[2 * i + 1] / 4, i};
+  for (int i = 0; i < P; ++i) key[i] = {grouped ? (long)(pairs[2 * i] / 4) * nb + pairs[2 * i + 1] / 4 : (long)(i / kGS), i};
   std::stable_sort(key.begin(), key.end(), [](const std::pair<long, int>& a, const std::pair<long, int>& b) { return a.first < b.first; });
   o.sorted.resize(P); o.orig.resize(P); o.gfirst.clear();
   for (int r = 0; r < P; ++r) {
@@ -382,26 +444,33 @@ int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const PairOrder
   const size_t OW = 2 * (size_t)g.L - 1;
   const int ngroups = (int)ord.gfirst.size() - 1;
   const int ncx = (ncb + 7) / 8;
-  std::vector<int> slots;
+  // slot tables of ALL passes, uploaded once (no host synchronisation inside the loop: the passes queue back to back)
+  std::vector<int> slots((size_t)ngroups * kGS, -1);
+  std::vector<int> pass_g0;
   for (int g0 = 0; g0 < ngroups;) {
     // a pass = consecutive tile groups while their pairs fit the intermediate
     int g1 = g0 + 1;
     while (g1 < ngroups && ord.gfirst[g1 + 1] - ord.gfirst[g0] <= PB) ++g1;
-    const int p0 = ord.gfirst[g0], cnt = ord.gfirst[g1] - p0;
-    slots.assign((size_t)(g1 - g0) * kGS, -1);
+    pass_g0.push_back(g0);
+    const int p0 = ord.gfirst[g0];
     for (int gi = g0; gi < g1; ++gi)
-      for (int r = ord.gfirst[gi]; r < ord.gfirst[gi + 1]; ++r) slots[(size_t)(gi - g0) * kGS + (r - ord.gfirst[gi])] = r - p0;
-    HIP_TRY(hipMemcpyAsync(ord.dslots, slots.data(), sizeof(int) * slots.size(), hipMemcpyHostToDevice, s));
-    HIP_TRY(hipStreamSynchronize(s));                       // `slots` is rewritten for the next pass
+      for (int r = ord.gfirst[gi]; r < ord.gfirst[gi + 1]; ++r) slots[(size_t)gi * kGS + (r - ord.gfirst[gi])] = r - p0;
+    g0 = g1;
+  }
+  pass_g0.push_back(ngroups);
+  HIP_TRY(hipMemcpyAsync(ord.dslots, slots.data(), sizeof(int) * slots.size(), hipMemcpyHostToDevice, s));
+  HIP_TRY(hipStreamSynchronize(s));                         // `slots` goes out of scope with this function
+  for (size_t ip = 0; ip + 1 < pass_g0.size(); ++ip) {
+    const int g0 = pass_g0[ip], g1 = pass_g0[ip + 1];
+    const int p0 = ord.gfirst[g0], cnt = ord.gfirst[g1] - p0;
     hipLaunchKernelGGL((k2d_cols<RXC, true>), dim3(8u * ncx * (g1 - g0) * kGS), dim3(NT), lds_c, s, (const cf*)S2.ptr,
                        (const cf*)S2.ptr, g, (const double*)nullptr, 0, ord.dsorted + p0, (cf*)T2.ptr, tw_c,
-                       (const int*)ord.dslots, ncb);
+                       (const int*)ord.dslots + (size_t)g0 * kGS, ncb);
     hipLaunchKernelGGL(k2d_rows_inv<RXR>, dim3(P1, cnt), dim3(NT), lds_r, s, (const cf*)T2.ptr, g, inv_n,
                        dfull, ord.dorig + p0, rowbest, rowidx, tw_r, tw_u);
     hipLaunchKernelGGL(k2d_peak, dim3(cnt), dim3(NT), 0, s, rowbest, rowidx, P1, (int)OW, dpeak_val + p0,
                        dpeak_idx + 2 * (size_t)p0);
     HIP_TRY(hipGetLastError());
-    g0 = g1;
   }
   return XCX_OK;
 }
