@@ -39,6 +39,9 @@ using namespace xcx;
 namespace {
 
 constexpr int NT = 256;
+#ifndef XCX_C2_WAVES
+#define XCX_C2_WAVES 3      // waves per SIMD of the pair column pass (register budget 168; 4 -> 128 spills 60 registers)
+#endif
 constexpr int kGS = 16;  // pair slots per tile group of the pair pass (4 x 4 tiles)
 constexpr int CB = 16;   // columns per workgroup: 8 (64-byte segments, 4 workgroups per CU) measured +3 %, 32 (1 per CU) -28 %
 
@@ -108,48 +111,17 @@ __global__ __launch_bounds__(NT) void k2d_rows_fwd(const float* __restrict__ til
   }
 }
 
-// Column transform of CB sequences with the inputs of the first stage ALREADY IN REGISTERS: the caller issues every
-// global load of the workgroup's slab up front, branch-free, so that all of them are in flight together.  (As a
-// `load(k1, c)` callback with a bounds check inside, every load pair sat in its own branch behind an
-// s_waitcnt vmcnt(0): 32 serialised memory round trips per thread -- the pair pass ran latency-bound at 3.6 TB/s.)
-// v[it][t] = input (j + t P1/R0, c) of butterfly b = tid + it NT, c = b % CB, j = b / CB.
-template <class RX, bool INV, class Out>
-__device__ __forceinline__ void subfft_regs(cf* __restrict__ lds, const cf* __restrict__ tw,
-                                            cf (&v)[(RX::L / RX::R0) * CB / NT][RX::R0], Out out) {
-  constexpr int L = RX::L, R0 = RX::R0;
-  constexpr int IT = (L / R0) * CB / NT;
-  static_assert((L / R0) * CB % NT == 0 && RX::S >= 2, "whole iterations, at least two stages");
-  const int tid = threadIdx.x;
-  auto lds_ld = [=](int p, int c) -> cf { return lds[p * CB + c]; };
-  auto lds_st = [=](int p, int c, cf w) { lds[p * CB + c] = w; };
-#pragma unroll
-  for (int it = 0; it < IT; ++it) {
-    const int b = tid + it * NT;
-    const int c = b % CB, j = b / CB;
-    Bfly<R0, INV>::run(v[it]);
-#pragma unroll
-    for (int t = 0; t < R0; ++t) lds_st(j * R0 + t, c, v[it][t]);        // Stockham positions of stage 0 (NS = 1)
-  }
-  __syncthreads();
-  if constexpr (RX::S == 2) {
-    fft_stage<L, RX::R1, R0, CB, NT, INV, false>(tw, lds_ld, out);
-  } else {
-    fft_stage<L, RX::R1, R0, CB, NT, INV, true>(tw, lds_ld, lds_st);
-    __syncthreads();
-    if constexpr (RX::S == 3) {
-      fft_stage<L, RX::R2, R0 * RX::R1, CB, NT, INV, false>(tw, lds_ld, out);
-    } else {
-      fft_stage<L, RX::R2, R0 * RX::R1, CB, NT, INV, true>(tw, lds_ld, lds_st);
-      __syncthreads();
-      fft_stage<L, RX::R3, R0 * RX::R1 * RX::R2, CB, NT, INV, false>(tw, lds_ld, out);
-    }
-  }
-}
+// three-stage column configurations whose stages all fill whole 256-thread iterations take the register path of
+// the pair pass (k2d_cols<INV>); LDS floats of its half-size exchange buffer
+template <class RX>
+constexpr bool kColsRegs = RX::S == 3 && (RX::L / RX::R0) * CB % NT == 0 && (RX::L / RX::R1) * CB % NT == 0 &&
+                           (RX::L / RX::R2) * CB % NT == 0;
+constexpr size_t cols_regs_lds_bytes(int P1) { return sizeof(float) * (size_t)(P1 + (P1 >> 3) + 1) * CB; }
 
 // columns: grid (ceil((R+1)/16), T or pairs).  INV = false: forward transform of
 // the F rows of S1 (zero rows beyond), scaled; INV = true: A conj(B), inverse.
 template <class RX, bool INV>
-__global__ __launch_bounds__(NT) void k2d_cols(const cf* __restrict__ A, const cf* __restrict__ B2, G2 g,
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(INV ? XCX_C2_WAVES : 1, INV ? XCX_C2_WAVES : 8))) void k2d_cols(const cf* __restrict__ A, const cf* __restrict__ B2, G2 g,
                                                const double* __restrict__ rowss, int normalize,
                                                const int2* __restrict__ pairs,
                                                cf* __restrict__ out, const cf* __restrict__ tw_sub,
@@ -211,26 +183,62 @@ __global__ __launch_bounds__(NT) void k2d_cols(const cf* __restrict__ A, const c
       const int col = col0 + c;
       if (col < ncol) dst[(size_t)m1 * pitch + col] = v;
     };
-    if constexpr (RX::S >= 2 && (P1 / RX::R0) * CB % NT == 0) {
+    if constexpr (kColsRegs<RX>) {
       // every load of the slab first (the pitch is a multiple of CB: columns beyond ncol are padding inside the
-      // row, their products are never stored), then the products, then the transform
-      constexpr int R0 = RX::R0, IT = (P1 / R0) * CB / NT;
-      cf va[IT][R0], vb[IT][R0];
+      // row, their products are never stored), then the products, then the transform with register-resident
+      // stages that exchange through a HALF-SIZE LDS buffer (real parts, then imaginary parts: 37 KB instead of
+      // 64 KB per workgroup at P1 = 512, four workgroups per CU instead of two)
+      constexpr int R0 = RX::R0, R1 = RX::R1, R2 = RX::R2;
+      using G0 = StageGeom<P1, R0, 1, CB, NT>;
+      using G1 = StageGeom<P1, R1, R0, CB, NT>;
+      using G2s = StageGeom<P1, R2, R0 * R1, CB, NT>;
+      // loads in batches of two butterflies per thread (2 x 2 x R0 loads in flight): a and b of ALL iterations at
+      // once would hold 2 x IT x R0 complex registers (194 VGPRs at P1 = 512: two waves per SIMD)
+      typename G0::Regs va;
+      constexpr int HB = G0::IT >= 2 ? 2 : 1;
 #pragma unroll
-      for (int it = 0; it < IT; ++it) {
-        const int bq = threadIdx.x + it * NT;
-        const unsigned o2 = (unsigned)(bq / CB) * (unsigned)pitch + (unsigned)(col0 + bq % CB);
+      for (int h0 = 0; h0 < G0::IT; h0 += HB) {
+        cf vb[HB][R0];
 #pragma unroll
-        for (int t = 0; t < R0; ++t) {
-          va[it][t] = a[o2 + (unsigned)(t * (P1 / R0)) * (unsigned)pitch];
-          vb[it][t] = b[o2 + (unsigned)(t * (P1 / R0)) * (unsigned)pitch];
+        for (int hh = 0; hh < HB; ++hh) {
+          const int it = h0 + hh;
+          const int bq = threadIdx.x + it * NT;
+          const unsigned o2 = (unsigned)(bq / CB) * (unsigned)pitch + (unsigned)(col0 + bq % CB);
+#pragma unroll
+          for (int t = 0; t < R0; ++t) {
+            va[it][t] = a[o2 + (unsigned)(t * (P1 / R0)) * (unsigned)pitch];
+            vb[hh][t] = b[o2 + (unsigned)(t * (P1 / R0)) * (unsigned)pitch];
+          }
+        }
+#pragma unroll
+        for (int hh = 0; hh < HB; ++hh) {
+          const int it = h0 + hh;
+#pragma unroll
+          for (int t = 0; t < R0; ++t) va[it][t] = cmulc(va[it][t], vb[hh][t]);
+          Bfly<R0, true>::run(va[it]);
         }
       }
+      float* __restrict__ ldsf = reinterpret_cast<float*>(lds);
+      auto idx = [](int p, int c) { return (p + (p >> 3)) * CB + c; };       // one pad row every 8 positions
+      typename G1::Base b1;                       // twiddle bases: loaded where their registers are free
+      stage_tw_base<P1, R1, R0, CB, NT>(tw_sub, b1);
+      typename G1::Regs v1;
+      stage_exchange<P1, R0, 1, R1, CB, NT>(ldsf, idx, va, v1);
+      stage_compute<P1, R1, R0, CB, NT, true>(v1, b1);
+      typename G2s::Base b2;
+      stage_tw_base<P1, R2, R0 * R1, CB, NT>(tw_sub, b2);
+      typename G2s::Regs v2;
+      stage_exchange<P1, R1, R0, R2, CB, NT>(ldsf, idx, v1, v2);
+      stage_compute<P1, R2, R0 * R1, CB, NT, true>(v2, b2);
 #pragma unroll
-      for (int it = 0; it < IT; ++it)
+      for (int it = 0; it < G2s::IT; ++it) {
+        const int bq = threadIdx.x + it * NT;
+        const int c = bq % CB, j = bq / CB;
+        const int k = j % (R0 * R1);
+        const int j0 = (j - k) * R2 + k;
 #pragma unroll
-        for (int t = 0; t < R0; ++t) va[it][t] = cmulc(va[it][t], vb[it][t]);
-      subfft_regs<RX, true>(lds, tw_sub, va, o);
+        for (int t = 0; t < R2; ++t) o(j0 + t * (R0 * R1), c, v2[it][t]);
+      }
     } else {
       auto in = [=](int k1, int c) -> cf {
         const size_t o2 = (size_t)k1 * pitch + col0 + c;          // inside the padded row
@@ -434,8 +442,9 @@ int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const PairOrder
   HIP_TRY(big_lds(k2d_rows_inv<RXR>, lds_r));
   hipLaunchKernelGGL(k2d_rows_fwd<RXR>, dim3(g.F, T), dim3(NT), lds_r, s, dtiles, g, (cf*)S1.ptr, rowss, tw_r, tw_u);
   const size_t lds_c = (RXC::S > 1) ? sizeof(cf) * P1 * CB : 0;
+  const size_t lds_ci = kColsRegs<RXC> ? cols_regs_lds_bytes(P1) : lds_c;      // pair pass: half-size exchange buffer
   HIP_TRY(big_lds((k2d_cols<RXC, false>), lds_c));
-  HIP_TRY(big_lds((k2d_cols<RXC, true>), lds_c));
+  HIP_TRY(big_lds((k2d_cols<RXC, true>), lds_ci));
   const int ncb = (g.R + 1 + CB - 1) / CB;
   hipLaunchKernelGGL((k2d_cols<RXC, false>), dim3(ncb, T), dim3(NT), lds_c, s, (const cf*)S1.ptr, (const cf*)nullptr, g,
                      (const double*)rowss, normalize, (const int2*)nullptr, (cf*)S2.ptr, tw_c);
@@ -463,7 +472,7 @@ int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const PairOrder
   for (size_t ip = 0; ip + 1 < pass_g0.size(); ++ip) {
     const int g0 = pass_g0[ip], g1 = pass_g0[ip + 1];
     const int p0 = ord.gfirst[g0], cnt = ord.gfirst[g1] - p0;
-    hipLaunchKernelGGL((k2d_cols<RXC, true>), dim3(8u * ncx * (g1 - g0) * kGS), dim3(NT), lds_c, s, (const cf*)S2.ptr,
+    hipLaunchKernelGGL((k2d_cols<RXC, true>), dim3(8u * ncx * (g1 - g0) * kGS), dim3(NT), lds_ci, s, (const cf*)S2.ptr,
                        (const cf*)S2.ptr, g, (const double*)nullptr, 0, ord.dsorted + p0, (cf*)T2.ptr, tw_c,
                        (const int*)ord.dslots + (size_t)g0 * kGS, ncb);
     hipLaunchKernelGGL(k2d_rows_inv<RXR>, dim3(P1, cnt), dim3(NT), lds_r, s, (const cf*)T2.ptr, g, inv_n,
