@@ -37,6 +37,35 @@ __device__ inline double block_sum(double v, double* red) {
   return r;
 }
 
+// One-workgroup-per-row loops.  As `for (i = tid; i < n; i += NT) use(row[i])` the compiler emits ONE load per
+// iteration and waits for it before the next (a rolled loop: n / NT serialised memory round trips -- 1400 of them
+// for a full-lag CCF row, ~1.3 us each); here kUL loads are issued back to back and then consumed IN THE SAME
+// ORDER, so every float64 sum keeps its value bit for bit.
+constexpr int kUL = 8;
+template <class F> __device__ inline void row_visit(const float* __restrict__ row, long lo, long hi, F f) {
+  long i = lo + threadIdx.x;
+  for (; i + (kUL - 1) * NT < hi; i += kUL * NT) {
+    float v[kUL];
+#pragma unroll
+    for (int k = 0; k < kUL; ++k) v[k] = row[i + k * NT];
+#pragma unroll
+    for (int k = 0; k < kUL; ++k) f(i + k * NT, v[k]);
+  }
+  for (; i < hi; i += NT) f(i, row[i]);
+}
+// dst[i] = f(i, src[i]) over [lo, hi); dst may be src (each element is read before it is written, by its own thread)
+template <class F> __device__ inline void row_update(const float* src, float* dst, long lo, long hi, F f) {
+  long i = lo + threadIdx.x;
+  for (; i + (kUL - 1) * NT < hi; i += kUL * NT) {
+    float v[kUL];
+#pragma unroll
+    for (int k = 0; k < kUL; ++k) v[k] = src[i + k * NT];
+#pragma unroll
+    for (int k = 0; k < kUL; ++k) dst[i + k * NT] = f(i + k * NT, v[k]);
+  }
+  for (; i < hi; i += NT) dst[i] = f(i, src[i]);
+}
+
 enum { OP_NORM = 0, OP_DEMEAN = 1, OP_DETREND = 2 };
 
 // one workgroup per row; the row is read twice (second time from L2)
@@ -44,35 +73,33 @@ template <int OP>
 __global__ __launch_bounds__(NT) void k_row_reduce_apply(float* __restrict__ x, long n) {
   __shared__ double red[NT];
   float* __restrict__ row = x + (size_t)blockIdx.x * n;
-  const int tid = threadIdx.x;
   if (OP == OP_NORM) {
     double acc = 0.0;
-    for (long i = tid; i < n; i += NT) { double v = row[i]; acc += v * v; }
+    row_visit(row, 0, n, [&](long, float f) { const double v = f; acc += v * v; });
     const double nrm = sqrt(block_sum(acc, red));
     // x / ||x|| in the input precision (signal/normalize.py:80 `y = x/n`)
     const float fn = (float)nrm;
-    for (long i = tid; i < n; i += NT) row[i] = row[i] / fn;
+    row_update(row, row, 0, n, [=](long, float v) { return v / fn; });
   } else if (OP == OP_DEMEAN) {
     double acc = 0.0;
-    for (long i = tid; i < n; i += NT) acc += (double)row[i];
+    row_visit(row, 0, n, [&](long, float v) { acc += (double)v; });
     const float mean = (float)(block_sum(acc, red) / (double)n);
-    for (long i = tid; i < n; i += NT) row[i] = row[i] - mean;
+    row_update(row, row, 0, n, [=](long, float v) { return v - mean; });
   } else {
     // least-squares line over t = 0..n-1 (scipy.stats.linregress)
     const double tbar = 0.5 * (double)(n - 1);
     double sy = 0.0, sty = 0.0;
-    for (long i = tid; i < n; i += NT) {
-      double v = row[i];
+    row_visit(row, 0, n, [&](long i, float f) {
+      const double v = f;
       sy += v;
       sty += ((double)i - tbar) * v;
-    }
+    });
     sy = block_sum(sy, red);
     sty = block_sum(sty, red);
     const double stt = (double)n * ((double)n * (double)n - 1.0) / 12.0;
     const double m = (n > 1) ? sty / stt : 0.0;
     const double b = sy / (double)n - m * tbar;
-    for (long i = tid; i < n; i += NT)
-      row[i] = (float)((double)row[i] - (m * (double)i + b));
+    row_update(row, row, 0, n, [=](long i, float v) { return (float)((double)v - (m * (double)i + b)); });
   }
 }
 
@@ -122,7 +149,6 @@ __global__ __launch_bounds__(NT) void k_row_apply(const float* src, float* dst, 
                                                   long c0, long c1) {
   const float* rin = src + (size_t)blockIdx.y * n;
   float* row = dst + (size_t)blockIdx.y * n;
-  const int tid = threadIdx.x;
   const long per = (c1 - c0 + kParts - 1) / kParts;
   const long lo = c0 + blockIdx.x * per, hi = (lo + per < c1) ? lo + per : c1;
   double s0 = 0.0, s1 = 0.0;
@@ -132,16 +158,16 @@ __global__ __launch_bounds__(NT) void k_row_apply(const float* src, float* dst, 
   }
   if (OP == OP_NORM) {
     const float fn = (float)sqrt(s0);
-    for (long i = lo + tid; i < hi; i += NT) row[i] = rin[i] / fn;
+    row_update(rin, row, lo, hi, [=](long, float v) { return v / fn; });
   } else if (OP == OP_DEMEAN) {
     const float mean = (float)(s0 / (double)n);
-    for (long i = lo + tid; i < hi; i += NT) row[i] = rin[i] - mean;
+    row_update(rin, row, lo, hi, [=](long, float v) { return v - mean; });
   } else {
     const double tbar = 0.5 * (double)(n - 1);
     const double stt = (double)n * ((double)n * (double)n - 1.0) / 12.0;
     const double m = (n > 1) ? s1 / stt : 0.0;
     const double b = s0 / (double)n - m * tbar;
-    for (long i = lo + tid; i < hi; i += NT) row[i] = (float)((double)rin[i] - (m * (double)i + b));
+    row_update(rin, row, lo, hi, [=](long i, float v) { return (float)((double)v - (m * (double)i + b)); });
   }
 }
 
@@ -190,31 +216,28 @@ __global__ void k_unbias(float* __restrict__ x, long batch, long L, long npts, l
 __global__ __launch_bounds__(NT) void k_detrend_nan(float* __restrict__ x, long n, int linear) {
   __shared__ double red[NT];
   float* __restrict__ row = x + (size_t)blockIdx.x * n;
-  const int tid = threadIdx.x;
   double c = 0.0, sy = 0.0, st = 0.0;
-  for (long i = tid; i < n; i += NT) {
-    const float v = row[i];
+  row_visit(row, 0, n, [&](long i, float v) {
     if (v == v) { c += 1.0; sy += (double)v; st += (double)i; }
-  }
+  });
   c = block_sum(c, red); sy = block_sum(sy, red); st = block_sum(st, red);
   if (c == 0.0) return;                                   // all-NaN row stays as it is
   const double ybar = sy / c, tbar = st / c;
   double m = 0.0;
   if (linear) {
     double stt = 0.0, sty = 0.0;
-    for (long i = tid; i < n; i += NT) {
-      const float v = row[i];
+    row_visit(row, 0, n, [&](long i, float v) {
       if (v == v) { const double dt = (double)i - tbar; stt += dt * dt; sty += dt * ((double)v - ybar); }
-    }
+    });
     stt = block_sum(stt, red); sty = block_sum(sty, red);
     m = (stt > 0.0) ? sty / stt : 0.0;
   }
   const double b = ybar - m * tbar;
   if (linear) {
-    for (long i = tid; i < n; i += NT) row[i] = (float)((double)row[i] - (m * (double)i + b));
+    row_update(row, row, 0, n, [=](long i, float v) { return (float)((double)v - (m * (double)i + b)); });
   } else {
     const float mean = (float)ybar;
-    for (long i = tid; i < n; i += NT) row[i] = row[i] - mean;
+    row_update(row, row, 0, n, [=](long, float v) { return v - mean; });
   }
 }
 
@@ -255,7 +278,6 @@ __global__ __launch_bounds__(NT) void k_post_prep(float* __restrict__ x, long L,
                                                    int wtype, int do_unbias) {
   __shared__ double red[NT];
   float* __restrict__ row = x + (size_t)blockIdx.x * L;
-  const int tid = threadIdx.x;
   auto unb = [=](long o, float v) -> float {
     if (!do_unbias) return v;
     long lag = idx_min + o - (npts - 1);
@@ -263,13 +285,13 @@ __global__ __launch_bounds__(NT) void k_post_prep(float* __restrict__ x, long L,
     return v * (float)((double)npts / (double)(npts - lag));
   };
   double acc = 0.0;
-  for (long i = tid; i < L; i += NT) acc += (double)unb(i, row[i]);
+  row_visit(row, 0, L, [&](long i, float v) { acc += (double)unb(i, v); });
   const float mean = (float)(block_sum(acc, red) / (double)L);
-  for (long i = tid; i < L; i += NT) {
-    float v = unb(i, row[i]) - mean;
+  row_update(row, row, 0, L, [=](long i, float x0) {
+    float v = unb(i, x0) - mean;
     if (nmax > 0 && (i < nmax || i >= L - nmax)) v = v * taper_weight(i, L, nmax, wtype);
-    row[i] = v;
-  }
+    return v;
+  });
 }
 
 __global__ void k_onebit(float* __restrict__ x, long total) {
