@@ -88,10 +88,43 @@ def test_device_resident_and_many_pairs(ctx):
     host = full.to_host() if hasattr(full, 'to_host') else full.numpy()
     peak_h, idx_h = ops.correlate2d(ctx, t, pairs)
     assert np.array_equal(peak, peak_h) and np.array_equal(idx, idx_h)
-    for p in (0, 17, 143):
-        a, b = pairs[p]
+    # the pair pass runs in tile-group order (4 x 4 tile blocks): every map and peak lands at the caller's index
+    for p, (a, b) in enumerate(pairs):
         ref = R.correlate2d(t[a], t[b])
-        assert np.abs(host[p] - ref).max() <= TOL * np.abs(ref).max()
+        assert np.abs(host[p] - ref).max() <= TOL * np.abs(ref).max(), (p, a, b)
+        assert abs(peak[p] - ref.max()) <= TOL * abs(ref.max())
+        assert tuple(idx[p]) == np.unravel_index(int(np.argmax(host[p])), host[p].shape)
+
+
+def test_pair_list_over_several_passes():
+    """The same with the intermediate capped at 1 MiB (XCX_CC2D_PASS_MB, read once per process): one tile group
+    per pass, shuffled and repeated pairs -- the slot tables of all passes are uploaded before the first launch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = '''
+import numpy as np
+from oracle import ref_numpy as R
+import xcorr_amd as X
+from xcorr_amd import ops
+rng = np.random.default_rng(8)
+ctx = X.Context(0)
+T, F, L = 11, 16, 200
+t = np.abs(rng.standard_normal((T, F, L))).astype(np.float32)
+pairs = [(int(a), int(b)) for a, b in rng.integers(0, T, (150, 2))]
+peak, idx, full = ops.correlate2d(ctx, t, pairs, full=True)
+worst = 0.0
+for p, (a, b) in enumerate(pairs):
+    ref = R.correlate2d(t[a], t[b])
+    worst = max(worst, float(np.abs(full[p] - ref).max() / np.abs(ref).max()))
+    assert tuple(idx[p]) == np.unravel_index(int(np.argmax(full[p])), full[p].shape), p
+print('WORST', worst)
+assert worst < 1e-5
+'''
+    env = dict(os.environ, XCX_CC2D_PASS_MB='1', PYTHONPATH=root)
+    out = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, timeout=300, cwd=root, env=env)
+    assert out.returncode == 0, out.stdout[-500:] + out.stderr[-1500:]
 
 
 def test_signal_mirror_and_errors(ctx):

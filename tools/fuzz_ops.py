@@ -61,10 +61,21 @@ def run(budget=60.0, seed=0, ctx=None):
         elif kind == 'cc2d':
             F = int(rng.integers(1, 65)); L = int(rng.integers(1, 600)); T = int(rng.integers(2, 5))
             t = np.abs(rng.standard_normal((T, F, L))).astype(np.float32)
-            a, b2 = int(rng.integers(0, T)), int(rng.integers(0, T))
             nrm = bool(rng.random() < 0.5)
-            pk, ix, full = ops.correlate2d(ctx, t, [(a, b2)], normalize=nrm, full=True)
-            e = rel(full[0], R.correlate2d(t[a], t[b2], normalize=nrm)); tol = 1e-5
+            if rng.random() < 0.5:
+                a, b2 = int(rng.integers(0, T)), int(rng.integers(0, T))
+                pk, ix, full = ops.correlate2d(ctx, t, [(a, b2)], normalize=nrm, full=True)
+                e = rel(full[0], R.correlate2d(t[a], t[b2], normalize=nrm)); tol = 1e-5
+            else:       # a pair list over several tile groups (run order != caller's order): every map and peak in place
+                T = int(rng.integers(5, 14)); F = int(rng.integers(1, 9)); L = int(rng.integers(1, 80))
+                t = np.abs(rng.standard_normal((T, F, L))).astype(np.float32)
+                prs = [(int(rng.integers(0, T)), int(rng.integers(0, T))) for _ in range(int(rng.integers(2, 60)))]
+                pk, ix, full = ops.correlate2d(ctx, t, prs, normalize=nrm, full=True)
+                e = 0.0
+                for q, (a, b2) in enumerate(prs):
+                    ref = R.correlate2d(t[a], t[b2], normalize=nrm)
+                    e = max(e, rel(full[q], ref), abs(float(pk[q]) - float(ref.max())) / max(abs(float(ref.max())), 1e-30))
+                tol = 1e-5
         elif kind == 'lanczos':
             n = int(rng.integers(50, 50000)); a_ = int(rng.integers(1, 25)); step = float(rng.uniform(0.2, 7.))
             off = float(rng.uniform(0, 3)); nout = max(1, int((n - 1 - off) / step))
@@ -114,9 +125,13 @@ def run(budget=60.0, seed=0, ctx=None):
             win = sw.hann(2 * nmax, False); wt[:nmax] = win[:nmax]; wt[-nmax:] = win[-nmax:]
             e = rel(got, r * wt); tol = 1e-5
         else:
-            n = int(rng.integers(16, 60000)); x = (rng.standard_normal((3, n)) * np.hanning(n)).astype(np.float32)
-            d = rng.uniform(-1, 1, 3)
-            e = rel(ops.timeshift(ctx, x, d, 50.), R.timeshift(x, d, 50.)); tol = 1e-5
+            n = int(rng.integers(16, 60000)); b = int(rng.choice([3, 3, 40, 300])) if n < 8000 else 3
+            x = (rng.standard_normal((b, n)) * np.hanning(n)).astype(np.float32)
+            # distinct delays, or a handful of values shared by the rows (one Dirichlet kernel per value and launch group)
+            nv = int(rng.integers(1, 5))
+            d = rng.uniform(-1, 1, b) if rng.random() < 0.5 else rng.uniform(-1, 1, nv)[rng.integers(0, nv, b)]
+            got, ref = ops.timeshift(ctx, x, d, 50.), R.timeshift(x, d, 50.)
+            e = max(rel(got[r], ref[r]) for r in range(b)); tol = 1e-5
         cases += 1
         worst[kind] = max(worst.get(kind, 0.0), e)
         if not e < tol:

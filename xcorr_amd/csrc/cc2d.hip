@@ -429,7 +429,9 @@ int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const PairOrder
   // chains of 4-6 pair passes on their own streams, T2 cache-resident, measured the same 51 k
   // pairs/s as this single stream (round 3): the two kernels are not HBM-bound)
   // (whole tile groups per pass: at least one group of kGS pairs)
-  const int PB = (int)std::max<size_t>(kGS, std::min<size_t>((size_t)P, ((size_t)1 << 30) / (rowb * P1)));
+  static const size_t pass_bytes = getenv("XCX_CC2D_PASS_MB") ? (size_t)std::max(1, atoi(getenv("XCX_CC2D_PASS_MB"))) << 20
+                                                                : (size_t)1 << 30;      // (tests force several passes)
+  const int PB = (int)std::max<size_t>(kGS, std::min<size_t>((size_t)P, pass_bytes / (rowb * P1)));
   if ((rc = T2.ensure(ctx, rowb * P1 * PB))) return rc;
   if ((rc = misc.ensure(ctx, sizeof(double) * (size_t)T * g.F + (sizeof(float) + sizeof(long long)) * (size_t)P1 * PB + 64)))
     return rc;
