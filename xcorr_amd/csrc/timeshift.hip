@@ -52,39 +52,65 @@ namespace {
 // Odd n (only reachable through the fft/ifft path, which keeps every sample): all n frequencies
 // |k| <= (n-1)/2 exist and  h[m] = sin(n pi u) / (n sin(pi u)) = -(-1)^m sin(pi n alpha) / (n sin(pi u)),
 // limit 1 at u -> 0.
+// Each thread produces kDK samples t, 64 apart: the first from sincospi(u) as written above, the others by
+// rotating (sin pi u, cos pi u) by the constant step 64 pi/n (float64, <= kDK - 1 roundings) -- one sincospi per
+// kDK samples instead of one per sample (the kernel was 1.7 us of a full-lag row's 9.7).  A rotated sine that
+// comes out below 1e-6 is re-evaluated exactly: next to the kernel's peak the quotient would amplify the
+// rounding of the recurrence.
+constexpr int kDK = 8;
 __global__ void k_dirichlet(float* __restrict__ hr, long n, long rows, const double* __restrict__ alpha, int ext) {
-  // grid (ceil(n / 256), rows): no 64-bit division per sample
+  // grid (ceil(n / (256 kDK)), rows): no 64-bit division per sample
+  // a wave owns 64 kDK consecutive samples; lane l takes t = first + l + 64 k, so every store instruction of the
+  // wave writes 64 consecutive floats and a lane's samples are 64 apart: rotate by -64 pi/n per step
   const long r = blockIdx.y;
-  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n || r >= rows) return;
-  const long m = (t == 0) ? 0 : n - t;
+  const long t0 = ((long)blockIdx.x * blockDim.x + (threadIdx.x & ~63)) * kDK + (threadIdx.x & 63);
+  if (t0 >= n || r >= rows) return;
   const double al = alpha[r];
   const double inv_n = 1.0 / (double)n;
-  double u = (double)m * inv_n - al;
-  const double uw = rint(u);
-  u -= uw;                                          // [-1/2, 1/2]; sin(pi u) changes sign with odd uw (cot does not)
-  const double wsgn = ((long)uw & 1) ? -1.0 : 1.0;
-  double su, cu;
-  sincospi(u, &su, &cu);
   double sa, ca;
   sincospi(fmod((double)n * al, 2.0), &sa, &ca);    // row constants
-  const double sgn = (m & 1) ? -1.0 : 1.0;
-  double h;
-  if (n & 1) {
-    if (fabs(su) < 1e-12) h = 1.0;
-    else h = -sgn * wsgn * sa / su * inv_n;
-  } else {
-    if (fabs(su) < 1e-12) h = ((double)(n - 1) + ca * sgn) * inv_n;
-    else h = -sgn * sa * (cu / su) * inv_n;
-  }
-  if (!ext) {
-    hr[r * n + t] = (float)h;
-  } else {
-    // two periods, g[j] = h[(n-1-j) mod n], j < 2n-1: with R[lag] = sum_j x[j+lag] g[j] (x zero beyond n samples)
-    // the lags -(n-1) .. 0 are y[m], m = n-1+lag.  h[m] = this thread's value (m = (-t) mod n).
-    float* g = hr + r * (2 * n - 1);
-    g[n - 1 - m] = (float)h;
-    if (m >= 1) g[2 * n - 1 - m] = (float)h;
+  double sd, cd;
+  sincospi(64.0 * inv_n, &sd, &cd);                 // 64 samples further in t = 64 samples back in m
+  // state: (sin pi u, cos pi u) of the UNREDUCED u = m/n - alpha.  sincospi is evaluated on the reduced argument
+  // u - rint(u) (a small difference next to the peak) and both values get the sign (-1)^rint(u) back; with the true
+  // sine the odd-n kernel needs no separate reduction sign: sin(n pi u) / sin(pi u) is even in the reduction.
+  auto exact = [&](long m, double& su, double& cu) {
+    double u = (double)m * inv_n - al;
+    const double uw = rint(u);
+    u -= uw;
+    sincospi(u, &su, &cu);
+    if ((long)uw & 1) { su = -su; cu = -cu; }
+  };
+  double su = 0.0, cu = 1.0;
+#pragma unroll
+  for (int k = 0; k < kDK; ++k) {
+    const long t = t0 + 64 * k;
+    if (t >= n) break;
+    const long m = (t == 0) ? 0 : n - t;
+    if (k == 0 || t == 64) exact(m, su, cu);        // t = 0 -> m = 0, t = 64 -> m = n - 64: not one step apart
+    else {
+      const double s2 = su * cd - cu * sd, c2 = cu * cd + su * sd;
+      su = s2; cu = c2;
+      if (fabs(su) < 1e-6) exact(m, su, cu);
+    }
+    const double sgn = (m & 1) ? -1.0 : 1.0;
+    double h;
+    if (n & 1) {
+      if (fabs(su) < 1e-12) h = 1.0;
+      else h = -sgn * sa / su * inv_n;
+    } else {
+      if (fabs(su) < 1e-12) h = ((double)(n - 1) + ca * sgn) * inv_n;
+      else h = -sgn * sa * (cu / su) * inv_n;
+    }
+    if (!ext) {
+      hr[r * n + t] = (float)h;
+    } else {
+      // two periods, g[j] = h[(n-1-j) mod n], j < 2n-1: with R[lag] = sum_j x[j+lag] g[j] (x zero beyond n samples)
+      // the lags -(n-1) .. 0 are y[m], m = n-1+lag.  h[m] = this sample's value (m = (-t) mod n).
+      float* g = hr + r * (2 * n - 1);
+      g[n - 1 - m] = (float)h;
+      if (m >= 1) g[2 * n - 1 - m] = (float)h;
+    }
   }
 }
 
@@ -179,7 +205,7 @@ static int timeshift_rows(xcx_ctx* ctx, const float* x, float* y, long batch, lo
       HIP_TRY(hipStreamSynchronize(ctx->stream));      // `ualpha` is reused by the next group
     }
     const dim3 grid((unsigned)((n + 255) / 256), (unsigned)cnt);
-    const dim3 kgrid((unsigned)((n + 255) / 256), (unsigned)nk);
+    const dim3 kgrid((unsigned)((n + 256 * kDK - 1) / (256 * kDK)), (unsigned)nk);
     hipLaunchKernelGGL(k_dirichlet, kgrid, dim3(256), 0, ctx->stream, (float*)hr.ptr, n, (long)nk,
                        (const double*)dal.ptr + r0, direct ? 1 : 0);
     HIP_TRY(hipGetLastError());
