@@ -4,7 +4,7 @@ set -o pipefail
 tag=$1; ctrs=$2; shift; shift
 root=$(pwd); out=$root/gpurun_out/pmc_$tag; mkdir -p $out
 export TMPDIR=/tmp; cd /tmp
-timeout -k 10 240 rocprofv3 --pmc $ctrs --output-format csv -d $out/run -- python3 $root/"$@" > $out/run.log 2>&1 || { tail -20 $out/run.log; exit 1; }
+timeout -k 10 ${PMC_TIMEOUT:-240} rocprofv3 --pmc $ctrs --output-format csv -d $out/run -- python3 $root/"$@" > $out/run.log 2>&1 || { tail -20 $out/run.log; exit 1; }
 cd $root
 python3 - $out <<'PY'
 import csv, glob, sys, os, re
