@@ -1562,27 +1562,41 @@ extern "C" long xcx_debug_stamps(xcx_plan* p, unsigned long long* host, long max
 // ---------------------------------------------------------------------------
 namespace {
 
-// per row: sum(x), sum(y) then (after the means are known) sum((x-mx)^2 or 1), same for y
+// per row: sum(x), sum(y) then (after the means are known) sum((x-mx)^2 or 1), same for y.
+// A day-long row is split over kSegParts workgroups (one workgroup per row read its 4.32 M samples in a rolled loop,
+// one load pair and one wait per trip: 7.4 ms per call, 59 % of the production window); the loads go out in
+// batches of 8 and are consumed in order, the partial sums are combined in fixed order by k_seg_stats_fin.
+constexpr int kSegParts = 128;
 __global__ __launch_bounds__(256) void k_seg_stats(const float* const* __restrict__ xs, const float* const* __restrict__ ys,
-                                                    long n, int flags, double* __restrict__ st /*[rows][4]: mx, my, sxx, syy*/,
-                                                    int phase) {
+                                                    long n, int flags, const double* __restrict__ st /*[rows][4]: mx, my, sxx, syy*/,
+                                                    double* __restrict__ part /*[rows][kSegParts][2]*/, int phase) {
   __shared__ double red[2][256];
-  const int r = blockIdx.x, tid = threadIdx.x;
+  const int r = blockIdx.y, tid = threadIdx.x;
   const float* __restrict__ x = xs[r];
   const float* __restrict__ y = ys[r];
+  const long per = (n + kSegParts - 1) / kSegParts;
+  const long lo = (long)blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
   double a = 0.0, b = 0.0;
-  if (phase == 0) {
-    if (flags & XCX_F_DEMEAN)
-      for (long i = tid; i < n; i += 256) { a += (double)x[i]; b += (double)y[i]; }
-  } else {
-    const double mx = st[4 * r], my = st[4 * r + 1];
-    const bool ob = flags & XCX_F_ONEBIT;
-    for (long i = tid; i < n; i += 256) {
-      double u = (double)x[i] - mx, v = (double)y[i] - my;
-      if (ob) { u = (u > 0.0) ? 1.0 : ((u < 0.0) ? -1.0 : 0.0); v = (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : 0.0); }
-      else { u = (double)(float)u; v = (double)(float)v; }      // the windows are transformed as float32
-      a += u * u; b += v * v;
+  const double mx = phase ? st[4 * r] : 0.0, my = phase ? st[4 * r + 1] : 0.0;
+  const bool ob = flags & XCX_F_ONEBIT;
+  auto take = [&](float xf, float yf) {
+    if (phase == 0) { a += (double)xf; b += (double)yf; return; }
+    double u = (double)xf - mx, v = (double)yf - my;
+    if (ob) { u = (u > 0.0) ? 1.0 : ((u < 0.0) ? -1.0 : 0.0); v = (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : 0.0); }
+    else { u = (double)(float)u; v = (double)(float)v; }      // the windows are transformed as float32
+    a += u * u; b += v * v;
+  };
+  if (phase == 1 || (flags & XCX_F_DEMEAN)) {
+    constexpr int U = 8;
+    long i = lo + tid;
+    for (; i + (U - 1) * 256 < hi; i += U * 256) {
+      float xv[U], yv[U];
+#pragma unroll
+      for (int k = 0; k < U; ++k) { xv[k] = x[i + k * 256]; yv[k] = y[i + k * 256]; }
+#pragma unroll
+      for (int k = 0; k < U; ++k) take(xv[k], yv[k]);
     }
+    for (; i < hi; i += 256) take(x[i], y[i]);
   }
   red[0][tid] = a; red[1][tid] = b;
   __syncthreads();
@@ -1591,40 +1605,75 @@ __global__ __launch_bounds__(256) void k_seg_stats(const float* const* __restric
     __syncthreads();
   }
   if (tid == 0) {
-    if (phase == 0) { st[4 * r] = red[0][0] / (double)n; st[4 * r + 1] = red[1][0] / (double)n; }
-    else { st[4 * r + 2] = red[0][0]; st[4 * r + 3] = red[1][0]; }
+    part[((size_t)r * kSegParts + blockIdx.x) * 2] = red[0][0];
+    part[((size_t)r * kSegParts + blockIdx.x) * 2 + 1] = red[1][0];
+  }
+}
+__global__ void k_seg_stats_fin(const double* __restrict__ part, long n, double* __restrict__ st, int rows, int phase) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  double a = 0.0, b = 0.0;
+  for (int p = 0; p < kSegParts; ++p) { a += part[((size_t)r * kSegParts + p) * 2]; b += part[((size_t)r * kSegParts + p) * 2 + 1]; }
+  if (phase == 0) { st[4 * r] = a / (double)n; st[4 * r + 1] = b / (double)n; }
+  else { st[4 * r + 2] = a; st[4 * r + 3] = b; }
+}
+
+// Distinct-segment form (round 4).  With Bk = 2 Kb the window of station A_c and block beta starts at sample
+// k0 + (2 beta + c) Kb: it depends on s = 2 beta + c only, so the nb x nc windows of the old layout are 2 nb - 2 + nc
+// DISTINCT segments (64 instead of 432 for the production window).  Per row: NS = 2 nb - 2 + nc segments
+// a[k0 + s Kb + i], i < npr, followed by the nb blocks of b (Bk samples, zero beyond) = W = NS + nb windows of one
+// "station"; every window is transformed ONCE and k_seg_gram forms  G_c[k] = sum_beta A[2 beta + c][k] conj(B[beta][k]).
+__global__ __launch_bounds__(256) void k_seg_gather2(const float* const* __restrict__ as, const float* const* __restrict__ bs,
+                                                      const double* __restrict__ st, int swap, long n, int flags,
+                                                      int Bk, int Kb, int NS, int nb, long k0, float* __restrict__ dst) {
+  const int npr = Bk + Kb;
+  const int w = blockIdx.y, r = blockIdx.z, W = NS + nb;
+  const double ma = st[4 * r + (swap ? 1 : 0)], mb = st[4 * r + (swap ? 0 : 1)];
+  const bool ob = flags & XCX_F_ONEBIT;
+  float* __restrict__ d = dst + ((size_t)r * W + w) * (size_t)npr;
+  const bool isa = w < NS;
+  const float* __restrict__ src = isa ? as[r] : bs[r];
+  const long base = isa ? k0 + (long)w * Kb : (long)(w - NS) * Bk;
+  const int len = isa ? npr : Bk;
+  const double m = isa ? ma : mb;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < npr; i += gridDim.x * 256) {
+    const long j = base + i;
+    const bool in = i < len && j < n;
+    const float x = src[in ? j : 0];                 // unconditional load, then a select (no branch around the load)
+    const double u = (double)x - m;
+    const float v = ob ? ((u > 0.0) ? 1.f : ((u < 0.0) ? -1.f : 0.f)) : (float)u;
+    d[i] = in ? v : 0.f;
   }
 }
 
-// station layout of the sub-call: per row, stations 0..nc-1 = A_c (lag chunks c0..c0+nc-1), station nc = B;
-// every station has nb windows of npr samples
-__global__ __launch_bounds__(256) void k_seg_gather(const float* const* __restrict__ as, const float* const* __restrict__ bs,
-                                                     const double* __restrict__ st, int swap, long n, int flags,
-                                                     int Bk, int Kb, int nb, int nc, int c0, long k0,
-                                                     float* __restrict__ dst) {
-  const int npr = Bk + Kb;
-  const int beta = blockIdx.y;
-  const int stn = blockIdx.z % (nc + 1), r = blockIdx.z / (nc + 1);
-  const double ma = st[4 * r + (swap ? 1 : 0)], mb = st[4 * r + (swap ? 0 : 1)];
-  const bool ob = flags & XCX_F_ONEBIT;
-  float* __restrict__ d = dst + (((size_t)r * (nc + 1) + stn) * nb + beta) * (size_t)npr;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < npr; i += gridDim.x * 256) {
-    float v = 0.f;
-    if (stn < nc) {
-      const long src = (long)beta * Bk + k0 + (long)(c0 + stn) * Kb + i;
-      if (src < n) {
-        const double u = (double)as[r][src] - ma;
-        v = ob ? ((u > 0.0) ? 1.f : ((u < 0.0) ? -1.f : 0.f)) : (float)u;
-      }
-    } else if (i < Bk) {
-      const long src = (long)beta * Bk + i;
-      if (src < n) {
-        const double u = (double)bs[r][src] - mb;
-        v = ob ? ((u > 0.0) ? 1.f : ((u < 0.0) ? -1.f : 0.f)) : (float)u;
-      }
+// C[(r nc + c)][k] = sum_beta X[r W + 2 beta + c][k] conj(X[r W + NS + beta][k]); one frequency per lane (512-byte
+// runs per wave load), kSG chunks per workgroup pass over beta; the repeated A loads of neighbouring beta are cache hits
+constexpr int kSG = 6;
+__global__ __launch_bounds__(256) void k_seg_gram(const cf* __restrict__ X, size_t pitch, int nfreq, int NS, int nb, int nc,
+                                                   cf* __restrict__ C) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= nfreq) return;
+  const int c0 = blockIdx.y * kSG, r = blockIdx.z, W = NS + nb;
+  const cf* __restrict__ Xa = X + (size_t)r * W * pitch + k;
+  const cf* __restrict__ Xb = Xa + (size_t)NS * pitch;
+  cf acc[kSG];
+#pragma unroll
+  for (int j = 0; j < kSG; ++j) acc[j] = make_float2(0.f, 0.f);
+#pragma unroll 4
+  for (int beta = 0; beta < nb; ++beta) {
+    const cf b = Xb[(size_t)beta * pitch];
+    cf a[kSG];
+#pragma unroll
+    for (int j = 0; j < kSG; ++j) a[j] = Xa[(size_t)(2 * beta + min(c0 + j, nc - 1)) * pitch];
+#pragma unroll
+    for (int j = 0; j < kSG; ++j) {
+      acc[j].x += a[j].x * b.x + a[j].y * b.y;      // a conj(b)
+      acc[j].y += a[j].y * b.x - a[j].x * b.y;
     }
-    d[i] = v;
   }
+#pragma unroll
+  for (int j = 0; j < kSG; ++j)
+    if (c0 + j < nc) C[((size_t)r * nc + c0 + j) * pitch + k] = acc[j];
 }
 
 // sub[(r*nc + c)][k'] -> out[r][...]: lag k = k0 + (c0+c) Kb + k' (sign -1 for the exchanged roles)
@@ -1688,10 +1737,8 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
   const int nb = (int)((n + Bk - 1) / Bk);
   const long lmin = (long)g.idx_min - (n - 1), lmax = (long)g.idx_max - 1 - (n - 1);   // retained lags, inclusive
   int rc;
-  // rows per sub-call: the stacking engine's MFMA cross-spectrum kernel takes <= 64 stations
-  const int kMaxSt = 64;
   if ((rc = sg.ptrs.ensure(ctx, sizeof(float*) * 2 * (size_t)rows))) return rc;
-  if ((rc = sg.stats.ensure(ctx, sizeof(double) * 4 * (size_t)rows))) return rc;
+  if ((rc = sg.stats.ensure(ctx, sizeof(double) * (4 + 2 * kSegParts) * (size_t)rows))) return rc;   // totals, then partial sums
   HIP_TRY(hipMemcpyAsync(sg.ptrs.ptr, xs_h, sizeof(float*) * rows, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipMemcpyAsync((const float**)sg.ptrs.ptr + rows, ys_h, sizeof(float*) * rows, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));                 // xs_h / ys_h may be stack arrays of the caller
@@ -1699,9 +1746,11 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
   const float* const* dys = dxs + rows;
   double* st = (double*)sg.stats.ptr;
   HIP_TRY(hipMemsetAsync(st, 0, sizeof(double) * 4 * (size_t)rows, ctx->stream));
-  hipLaunchKernelGGL(k_seg_stats, dim3(rows), dim3(256), 0, ctx->stream, dxs, dys, n, g.flags, st, 0);
-  if (g.flags & XCX_F_NORMALIZE)
-    hipLaunchKernelGGL(k_seg_stats, dim3(rows), dim3(256), 0, ctx->stream, dxs, dys, n, g.flags, st, 1);
+  double* part = st + 4 * (size_t)rows;
+  for (int phase = 0; phase < ((g.flags & XCX_F_NORMALIZE) ? 2 : 1); ++phase) {
+    hipLaunchKernelGGL(k_seg_stats, dim3(kSegParts, rows), dim3(256), 0, ctx->stream, dxs, dys, n, g.flags, (const double*)st, part, phase);
+    hipLaunchKernelGGL(k_seg_stats_fin, dim3((rows + 63) / 64), dim3(64), 0, ctx->stream, (const double*)part, n, st, rows, phase);
+  }
   HIP_TRY(hipGetLastError());
   // two passes: non-negative lags (a = x, b = y), then negative lags (a = y, b = x, lags 1..-lmin)
   for (int pass = 0; pass < 2; ++pass) {
@@ -1712,32 +1761,38 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
     const int nchunks = (int)((kend - k0 + Kb - 1) / Kb);
     const float* const* as = pass == 0 ? dxs : dys;
     const float* const* bs = pass == 0 ? dys : dxs;
-    for (int c0 = 0; c0 < nchunks; c0 += kMaxSt - 1) {
-      const int nc = std::min(kMaxSt - 1, nchunks - c0);
-      const int rper = std::max(1, kMaxSt / (nc + 1));          // rows per sub-call
-      for (int r0 = 0; r0 < rows; r0 += rper) {
-        const int rr = std::min(rper, rows - r0);
-        const int S = rr * (nc + 1), P = rr * nc;
-        if ((rc = sg.segbuf.ensure(ctx, sizeof(float) * (size_t)S * nb * npr))) return rc;
-        if ((rc = sg.subout.ensure(ctx, sizeof(float) * (size_t)P * Kb))) return rc;
-        hipLaunchKernelGGL(k_seg_gather, dim3(std::min(64, (npr + 255) / 256), nb, S), dim3(256), 0, ctx->stream,
-                           as + r0, bs + r0, st + 4 * (size_t)r0, pass, n, g.flags, Bk, Kb, nb, nc, c0, k0,
-                           (float*)sg.segbuf.ptr);
-        HIP_TRY(hipGetLastError());
-        std::vector<int> pr(2 * (size_t)P);
-        for (int r = 0; r < rr; ++r)
-          for (int c = 0; c < nc; ++c) {
-            pr[2 * ((size_t)r * nc + c)] = r * (nc + 1) + c;
-            pr[2 * ((size_t)r * nc + c) + 1] = r * (nc + 1) + nc;
-          }
-        if ((rc = xcx_cc1d_pairs(sg.sub, (const float*)sg.segbuf.ptr, S, nb, (long)nb * npr, npr, pr.data(), P,
-                                 (float*)sg.subout.ptr, Kb, 1)))
-          return rc;
-        hipLaunchKernelGGL(k_seg_scatter, dim3(std::min(64, (Kb + 255) / 256), nc, rr), dim3(256), 0, ctx->stream,
-                           (const float*)sg.subout.ptr, st + 4 * (size_t)r0, g.flags, n, Kb, nc, c0, k0, kend,
-                           pass == 0 ? 1 : -1, (long)g.idx_min, L, out + (size_t)r0 * ld_out, ld_out);
-        HIP_TRY(hipGetLastError());
-      }
+    // every distinct segment of a and every block of b is transformed once (k_seg_gather2 / k_seg_gram above)
+    xcx_plan* sub = sg.sub;
+    const int NS = 2 * nb - 2 + nchunks, W = NS + nb;
+    const size_t pitch = sub->spec_pitch;
+    const size_t per_row = (size_t)W * ((size_t)npr * sizeof(float) + pitch * sizeof(cf)) +
+                           (size_t)nchunks * (pitch * sizeof(cf) + (size_t)Kb * sizeof(float));
+    const int rper = (int)std::max<size_t>(1, std::min<size_t>((size_t)rows, ((size_t)6 << 30) / per_row));
+    for (int r0 = 0; r0 < rows; r0 += rper) {
+      const int rr = std::min(rper, rows - r0);
+      const int P = rr * nchunks;
+      if ((rc = sg.segbuf.ensure(ctx, sizeof(float) * (size_t)rr * W * npr))) return rc;
+      if ((rc = sg.subout.ensure(ctx, sizeof(float) * (size_t)P * Kb))) return rc;
+      if ((rc = sub->spectra.ensure(ctx, sizeof(cf) * pitch * (size_t)rr * W))) return rc;
+      if ((rc = sub->gramC.ensure(ctx, sizeof(cf) * pitch * (size_t)P))) return rc;
+      hipLaunchKernelGGL(k_seg_gather2, dim3(std::min(64, (npr + 255) / 256), W, rr), dim3(256), 0, ctx->stream,
+                         as + r0, bs + r0, st + 4 * (size_t)r0, pass, n, g.flags, Bk, Kb, NS, nb, k0, (float*)sg.segbuf.ptr);
+      HIP_TRY(hipGetLastError());
+      if ((rc = forward(sub, (const float*)sg.segbuf.ptr, (long)W * npr, npr, W, 0, 0, rr * W, 0))) return rc;
+      const int nfreq = sub->g.N1 * (sub->g.N2h + 1);
+      hipLaunchKernelGGL(k_seg_gram, dim3((nfreq + 255) / 256, (nchunks + kSG - 1) / kSG, rr), dim3(256), 0, ctx->stream,
+                         (const cf*)sub->spectra.ptr, pitch, nfreq, NS, nb, nchunks, (cf*)sub->gramC.ptr);
+      HIP_TRY(hipGetLastError());
+      // one inverse per (row, chunk): descriptor q reads row q of the cross-spectrum buffer, writes Kb lags at q Kb
+      sub->hdescs.resize(P);
+      for (int q = 0; q < P; ++q) sub->hdescs[q] = PwDesc{q, q, (long long)q * Kb};
+      sub->desc_key = 0; sub->gram_key = 0;
+      if ((rc = upload(ctx, sub->descs, sub->hdescs.data(), (size_t)P * sizeof(PwDesc)))) return rc;
+      if ((rc = stack_inverse(sub, P, (float*)sg.subout.ptr))) return rc;
+      hipLaunchKernelGGL(k_seg_scatter, dim3(std::min(64, (Kb + 255) / 256), nchunks, rr), dim3(256), 0, ctx->stream,
+                         (const float*)sg.subout.ptr, st + 4 * (size_t)r0, g.flags, n, Kb, nchunks, 0, k0, kend,
+                         pass == 0 ? 1 : -1, (long)g.idx_min, L, out + (size_t)r0 * ld_out, ld_out);
+      HIP_TRY(hipGetLastError());
     }
   }
   return XCX_OK;
