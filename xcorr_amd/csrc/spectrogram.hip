@@ -47,36 +47,52 @@ struct SgArgs {
   const float2* Wsum;            // [tiles*16] sum_m D[f][m]
   const float* sc;               // [tiles*16] per-frequency scale (one-sided doubling included)
   long n, nseg; int nfreq, tiles, win_len, edge, detrend;
+  int hop;                       // samples between segment starts (1: the hop-1 spectrogram; > 1: spectrogram_mtc)
+  int tcs;                       // segments per workgroup: a multiple of 32, <= TC, (tcs - 1) hop + 2 KS floats of LDS
+  long ldS;                      // floats per output row [b][f]: n (hop 1, zero edge columns) or nseg (scipy layout)
 };
 
 template <int KS>
 __global__ __launch_bounds__(NT) void k_spectrogram(SgArgs a) {
-  __shared__ float xs[TC + 2 * KS];
+  extern __shared__ float xs[];                       // (tcs - 1) hop + 2 KS samples of the row
   __shared__ float mu[TC];
   __shared__ float red[NT / 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const long b = blockIdx.z;
-  const long t0 = (long)blockIdx.x * TC;
+  const long t0 = (long)blockIdx.x * a.tcs;            // first segment of the workgroup
+  const long g0 = t0 * a.hop;                          // its first sample
+  const int hop = a.hop, span = (a.tcs - 1) * hop + 2 * KS;
   const float* __restrict__ xr = a.x + b * a.n;
   // ---- stage the row chunk, remove its mean, running means of every window ----
   float part = 0.f;
-  for (int i = tid; i < TC + 2 * KS; i += NT) {
-    const long g = t0 + i;
-    const float v = g < a.n ? xr[g] : 0.f;
-    xs[i] = v;
-    part += v;
+  {
+    int i = tid;
+    for (; i + 3 * NT < span; i += 4 * NT) {            // four loads in flight per trip (a rolled loop waits for each)
+      float v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const long g = g0 + i + k * NT; v[k] = xr[g < a.n ? g : a.n - 1]; }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float w = (g0 + i + k * NT < a.n) ? v[k] : 0.f; xs[i + k * NT] = w; part += w; }
+    }
+    for (; i < span; i += NT) {
+      const long g = g0 + i;
+      const float v = g < a.n ? xr[g] : 0.f;
+      xs[i] = v;
+      part += v;
+    }
   }
   if (a.detrend) {
     for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o);
     if (lane == 0) red[wave] = part;
     __syncthreads();
-    const long valid = std::min<long>(TC + 2 * KS, a.n - t0);
+    const long valid = std::min<long>(span, a.n - g0);
     const float cm = (red[0] + red[1] + red[2] + red[3]) / (float)valid;
-    for (int i = tid; i < TC + 2 * KS; i += NT)
-      if (t0 + i < a.n) xs[i] -= cm;
+    for (int i = tid; i < span; i += NT)
+      if (g0 + i < a.n) xs[i] -= cm;
     __syncthreads();
     float s = 0.f;
-    for (int k = 0; k < a.win_len; ++k) s += xs[tid + k];          // TC == NT
+    if (tid < a.tcs)                                    // TC == NT: one segment mean per thread
+      for (int k = 0; k < a.win_len; ++k) s += xs[tid * hop + k];
     mu[tid] = s / (float)a.win_len;
   } else {
     mu[tid] = 0.f;
@@ -99,12 +115,12 @@ __global__ __launch_bounds__(NT) void k_spectrogram(SgArgs a) {
       W[4 * h + s] = a.Wsum[f];
       scl[4 * h + s] = a.sc[f];
     }
-  float* __restrict__ Sb = a.S + (size_t)b * a.nfreq * a.n;
-  for (int nt = 0; nt < TC / 32; ++nt) {
+  float* __restrict__ Sb = a.S + (size_t)b * a.nfreq * a.ldS;
+  for (int nt = 0; nt < a.tcs / 32; ++nt) {
     const long t = t0 + nt * 32 + col;
     if (t0 + nt * 32 >= a.nseg) break;                              // wave-uniform
     f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const float* __restrict__ xb = xs + nt * 32 + col + g;
+    const float* __restrict__ xb = xs + (nt * 32 + col) * hop + g;   // Hankel with stride hop: B[k][j] = x[(t0 + j) hop + k]
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(A[ks], xb[2 * ks], acc, 0, 0, 0);
@@ -118,7 +134,7 @@ __global__ __launch_bounds__(NT) void k_spectrogram(SgArgs a) {
           if (f < a.nfreq) {
             const float re = acc[8 * h + s] - m * W[4 * h + s].x;
             const float im = acc[8 * h + 4 + s] - m * W[4 * h + s].y;
-            Sb[(size_t)f * a.n + a.edge + t] = (re * re + im * im) * scl[4 * h + s];
+            Sb[(size_t)f * a.ldS + a.edge + t] = (re * re + im * im) * scl[4 * h + s];
           }
         }
     }
@@ -137,19 +153,12 @@ __global__ void k_sg_edges(float* __restrict__ S, long rows, long n, long edge, 
 
 }  // namespace
 
-extern "C" int xcx_spectrogram(xcx_ctx* ctx, const float* x, float* S, long batch, long n, int win_len, int nfft,
-                               const double* window, double scale, int detrend, int on_device) {
-  if (!ctx || !x || !S || !window) return set_err(XCX_EINVAL, "null argument");
-  if (batch < 1 || n < 1) return set_err(XCX_EINVAL, "batch and n must be >= 1");
-  if (win_len < 2 || win_len > 256) return set_err(XCX_EUNSUPPORTED, "win_len %d outside [2, 256]", win_len);
-  if (nfft < win_len || nfft > 8192) return set_err(XCX_EINVAL, "nfft %d outside [win_len, 8192]", nfft);
-  if (n < win_len) return set_err(XCX_EINVAL, "row shorter than one segment (%ld < %d)", n, win_len);
-  HIP_TRY(hipSetDevice(ctx->device));
+// tables + launch shared by the hop-1 spectrogram and the segmented one (device pointers)
+static int sg_launch(xcx_ctx* ctx, const float* xd, float* Sd, long batch, long n, int win_len, int nfft,
+                     const double* window, double scale, int detrend, long hop, long nseg, long ldS, long edge) {
   const int nfreq = nfft / 2 + 1;
   const int tiles = (nfreq + 15) / 16;
   const int KS = win_len <= 64 ? 32 : win_len <= 128 ? 64 : win_len <= 192 ? 96 : 128;
-  const long nseg = n - win_len + 1;
-  const long edge = (long)std::rint(win_len / 2.0);                 // spectrogram.py:121 (np.rint: half to even)
   // ---- tables (float64 on the host), cached per (win_len, nfft, window, scale) ----
   const size_t nD = (size_t)tiles * KS * 64, nW = (size_t)tiles * 16;
   const size_t bD = sizeof(float) * nD, bW = sizeof(float2) * nW, bS = sizeof(float) * nW;
@@ -198,6 +207,34 @@ extern "C" int xcx_spectrogram(xcx_ctx* ctx, const float* x, float* S, long batc
     ctx->sg_key = key;
   }
   char* tp = (char*)tab.ptr;
+  // segments per workgroup: as many as 32 KB of LDS hold at this hop (256 at hop 1 ... 32 at the largest hops)
+  int tcs = (int)std::min<long>(TC, ((long)(8192 - 2 * KS) / hop + 1) / 32 * 32);
+  if (tcs < 32) tcs = 32;
+  const size_t lds = sizeof(float) * ((size_t)(tcs - 1) * hop + 2 * KS);
+  SgArgs a{xd, Sd, (const float*)tp, (const float2*)(tp + bD), (const float*)(tp + bD + bW),
+           n, nseg, nfreq, tiles, win_len, (int)edge, detrend ? 1 : 0, (int)hop, tcs, ldS};
+  const dim3 grid((unsigned)((nseg + tcs - 1) / tcs), (unsigned)((tiles + 3) / 4), (unsigned)batch);
+  switch (KS) {
+    case 32: hipLaunchKernelGGL(k_spectrogram<32>, grid, dim3(NT), lds, ctx->stream, a); break;
+    case 64: hipLaunchKernelGGL(k_spectrogram<64>, grid, dim3(NT), lds, ctx->stream, a); break;
+    case 96: hipLaunchKernelGGL(k_spectrogram<96>, grid, dim3(NT), lds, ctx->stream, a); break;
+    default: hipLaunchKernelGGL(k_spectrogram<128>, grid, dim3(NT), lds, ctx->stream, a); break;
+  }
+  if (hipGetLastError() != hipSuccess) return set_err(XCX_EHIP, "k_spectrogram launch failed");
+  return XCX_OK;
+}
+
+extern "C" int xcx_spectrogram(xcx_ctx* ctx, const float* x, float* S, long batch, long n, int win_len, int nfft,
+                               const double* window, double scale, int detrend, int on_device) {
+  if (!ctx || !x || !S || !window) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || n < 1) return set_err(XCX_EINVAL, "batch and n must be >= 1");
+  if (win_len < 2 || win_len > 256) return set_err(XCX_EUNSUPPORTED, "win_len %d outside [2, 256]", win_len);
+  if (nfft < win_len || nfft > 8192) return set_err(XCX_EINVAL, "nfft %d outside [win_len, 8192]", nfft);
+  if (n < win_len) return set_err(XCX_EINVAL, "row shorter than one segment (%ld < %d)", n, win_len);
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int nfreq = nfft / 2 + 1;
+  const long nseg = n - win_len + 1;
+  const long edge = (long)std::rint(win_len / 2.0);                 // spectrogram.py:121 (np.rint: half to even)
   const size_t in_b = sizeof(float) * (size_t)batch * n, out_b = in_b * nfreq;
   const float* xd = x; float* Sd = S;
   void *ha = nullptr, *hb = nullptr;
@@ -207,17 +244,7 @@ extern "C" int xcx_spectrogram(xcx_ctx* ctx, const float* x, float* S, long batc
     (void)hipMemcpyAsync(ha, x, in_b, hipMemcpyHostToDevice, ctx->stream);
     xd = (const float*)ha; Sd = (float*)hb;
   }
-  SgArgs a{xd, Sd, (const float*)tp, (const float2*)(tp + bD), (const float*)(tp + bD + bW),
-           n, nseg, nfreq, tiles, win_len, (int)edge, detrend ? 1 : 0};
-  const dim3 grid((unsigned)((nseg + TC - 1) / TC), (unsigned)((tiles + 3) / 4), (unsigned)batch);
-  switch (KS) {
-    case 32: hipLaunchKernelGGL(k_spectrogram<32>, grid, dim3(NT), 0, ctx->stream, a); break;
-    case 64: hipLaunchKernelGGL(k_spectrogram<64>, grid, dim3(NT), 0, ctx->stream, a); break;
-    case 96: hipLaunchKernelGGL(k_spectrogram<96>, grid, dim3(NT), 0, ctx->stream, a); break;
-    default: hipLaunchKernelGGL(k_spectrogram<128>, grid, dim3(NT), 0, ctx->stream, a); break;
-  }
-  rc = XCX_OK;
-  if (hipGetLastError() != hipSuccess) rc = set_err(XCX_EHIP, "k_spectrogram launch failed");
+  int rc = sg_launch(ctx, xd, Sd, batch, n, win_len, nfft, window, scale, detrend, 1, nseg, n, edge);
   if (rc == XCX_OK && n > nseg) {
     const long rows = batch * nfreq;
     hipLaunchKernelGGL(k_sg_edges, dim3((unsigned)std::min<long>((rows * (n - nseg) + 255) / 256, 8192)), dim3(256), 0,
@@ -310,6 +337,26 @@ extern "C" int xcx_spectrogram_seg(xcx_ctx* ctx, const float* x, float* S, long 
   HIP_TRY(hipSetDevice(ctx->device));
   const long nseg = (n - win_len) / hop + 1;
   const int nfreq = nfft / 2 + 1;
+  if (win_len <= 256 && nfft <= 8192) {
+    // short segments: the same Hankel GEMM on the matrix cores as the hop-1 spectrogram, with column stride `hop`
+    // (the DFT-engine route below spent 205 us on a row the hop-1 kernel, with 25 x the segments, does in 14)
+    const size_t in_b = sizeof(float) * (size_t)batch * n, out_b = sizeof(float) * (size_t)batch * nfreq * nseg;
+    const float* xd = x; float* Sd = S;
+    void *ha = nullptr, *hb = nullptr;
+    if (!on_device) {
+      HIP_TRY(hipMalloc(&ha, in_b));
+      if (hipMalloc(&hb, out_b) != hipSuccess) { (void)hipFree(ha); return set_err(XCX_ENOMEM, "spectrogram output (%zu bytes)", out_b); }
+      (void)hipMemcpyAsync(ha, x, in_b, hipMemcpyHostToDevice, ctx->stream);
+      xd = (const float*)ha; Sd = (float*)hb;
+    }
+    int rc = sg_launch(ctx, xd, Sd, batch, n, win_len, nfft, window, scale, detrend, hop, nseg, nseg, 0);
+    if (!on_device && rc == XCX_OK && hipMemcpyAsync(S, Sd, out_b, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+      rc = set_err(XCX_EHIP, "copy back failed");
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == XCX_OK) rc = set_err(XCX_EHIP, "stream sync failed");
+    if (ha) (void)hipFree(ha);
+    if (hb) (void)hipFree(hb);
+    return rc;
+  }
   const int cplx = nfft & 1;                        // xcx_rfft handles even lengths; odd ones go through the complex DFT
   const long total = batch * nseg;
   // frames per chunk: bound the temporaries to ~256 MB
