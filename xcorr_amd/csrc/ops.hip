@@ -317,13 +317,23 @@ __global__ __launch_bounds__(NT) void k_snr(const float* __restrict__ x, long n,
   double acc = 0.0, cnt = 0.0;
   float best = -1.f;
   long bi = 0x7fffffffffffffffL;
-  for (long i = tid; i < n; i += NT) {
-    const float v = row[i];
-    if (noise[i]) { acc += (double)v * (double)v; cnt += 1.0; }
-    if (sig[i]) {
+  auto take = [&](long i, float v, unsigned char nz, unsigned char sg) {
+    if (nz) { acc += (double)v * (double)v; cnt += 1.0; }
+    if (sg) {
       const float a = fabsf(v);
       if (a > best) { best = a; bi = i; }        // strided scan keeps the smallest index per thread
     }
+  };
+  {
+    long i = tid;
+    for (; i + (kUL - 1) * NT < n; i += kUL * NT) {     // row and masks of kUL trips in flight, consumed in order
+      float v[kUL]; unsigned char nz[kUL], sg[kUL];
+#pragma unroll
+      for (int k = 0; k < kUL; ++k) { v[k] = row[i + k * NT]; nz[k] = noise[i + k * NT]; sg[k] = sig[i + k * NT]; }
+#pragma unroll
+      for (int k = 0; k < kUL; ++k) take(i + k * NT, v[k], nz[k], sg[k]);
+    }
+    for (; i < n; i += NT) take(i, row[i], noise[i], sig[i]);
   }
   const double ss = block_sum(acc, red);
   const double cc = block_sum(cnt, red);

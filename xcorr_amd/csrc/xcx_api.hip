@@ -1463,8 +1463,7 @@ extern "C" int xcx_cc1d(xcx_plan* p, const float* x, const float* y, int batch,
   const int kRows = 256;   // rows per chunk
   const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
   if ((rc = p->spectra.ensure(ctx, sizeof(cf) * p->spec_pitch * 2 * (size_t)std::min(batch, kRows)))) return rc;
-  if ((rc = p->T.ensure(ctx, sizeof(cf) * tm_per * p->batch))) return rc;
-  if ((rc = p->descs.ensure(ctx, sizeof(PwDesc) * kRows))) return rc;
+  if ((rc = p->T.ensure(ctx, sizeof(cf) * tm_per * p->batch * 2 * (p->dual ? p->nchains : 1)))) return rc;
   p->desc_key = 0;
   const float *dx = x, *dy = y;
   float* dout = out;
@@ -1481,17 +1480,28 @@ extern "C" int xcx_cc1d(xcx_plan* p, const float* x, const float* y, int batch,
     dy = dx + (size_t)batch * n;
     dout = (float*)p->dout.ptr;
   }
-  std::vector<PwDesc> d;
+  // descriptors of every chunk in one upload (row i of a chunk: spectrum slots i and cnt + i), so that the chunks
+  // queue back to back without a host synchronisation between them
+  {
+    std::vector<PwDesc> d((size_t)batch);
+    for (int r0 = 0; r0 < batch; r0 += kRows) {
+      const int cnt = std::min(kRows, batch - r0);
+      for (int i = 0; i < cnt; ++i) d[(size_t)r0 + i] = PwDesc{i, cnt + i, (long long)(r0 + i) * L};
+    }
+    if ((rc = upload(ctx, p->descs, d.data(), sizeof(PwDesc) * (size_t)batch))) return rc;
+  }
   for (int r0 = 0; r0 < batch; r0 += kRows) {
     const int cnt = std::min(kRows, batch - r0);
     if ((rc = forward(p, dx + (size_t)r0 * n, n, 0, 1, 0, 0, cnt, 0))) return rc;
     if ((rc = forward(p, dy + (size_t)r0 * n, n, 0, 1, 0, 0, cnt, cnt))) return rc;
-    d.resize(cnt);
-    for (int i = 0; i < cnt; ++i) d[i] = PwDesc{i, cnt + i, (long long)(r0 + i) * L};
-    HIP_TRY(hipMemcpyAsync(p->descs.ptr, d.data(), sizeof(PwDesc) * cnt, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    for (int q0 = 0; q0 < cnt; q0 += p->batch)
-      if ((rc = pair_batch(p, q0, std::min(p->batch, cnt - q0), dout, 1))) return rc;
+    // the rows of a chunk through the dual pipelines (row pass of one batch overlapped with the column pass of the
+    // next, two launch chains) where the size has them; batch by batch, columns then rows, otherwise
+    if (p->dual) {
+      if ((rc = dual_run(p, (size_t)r0, (size_t)cnt, 1, dout))) return rc;
+    } else {
+      for (int q0 = 0; q0 < cnt; q0 += p->batch)
+        if ((rc = pair_batch(p, (size_t)r0 + q0, std::min(p->batch, cnt - q0), dout, 1))) return rc;
+    }
   }
   if (!on_device) {
     HIP_TRY(hipMemcpyAsync(out, dout, (size_t)batch * L * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
@@ -1514,11 +1524,12 @@ int xcx_internal_pairs(xcx_plan* p, const PwDesc* hdesc, int count, float* out) 
   int rc;
   const Geom& g = p->g;
   const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
-  if ((rc = p->T.ensure(ctx, sizeof(cf) * tm_per * p->batch * 2))) return rc;
+  if ((rc = p->T.ensure(ctx, sizeof(cf) * tm_per * p->batch * 2 * (p->dual ? p->nchains : 1)))) return rc;
   if ((rc = p->descs.ensure(ctx, sizeof(PwDesc) * (size_t)count))) return rc;
   p->desc_key = 0;
   HIP_TRY(hipMemcpyAsync(p->descs.ptr, hdesc, sizeof(PwDesc) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  if (p->dual) return dual_run(p, 0, (size_t)count, 1, out);
   for (int q0 = 0; q0 < count; q0 += p->batch)
     if ((rc = pair_batch(p, q0, std::min(p->batch, count - q0), out, 1))) return rc;
   return XCX_OK;
