@@ -1,4 +1,6 @@
 """Array-level preprocess ops with ObsPy's parameter names (see package docstring)."""
+import functools
+
 import numpy as np
 import scipy.signal
 
@@ -88,6 +90,14 @@ def decimate(x, sampling_rate, factor, no_filter=False, ctx=None):
     return _ops.decimate(ctx, x, factor, sos), sampling_rate / float(factor)
 
 
+@functools.lru_cache(maxsize=4)
+def _named_window_half(name, npts):
+    """First npts // 2 + 1 samples of ``ifftshift(get_window(name, npts))`` as float32 (read-only, shared)."""
+    w = np.fft.ifftshift(scipy.signal.get_window(name, npts))[:npts // 2 + 1].astype(np.float32)
+    w.setflags(write=False)
+    return w
+
+
 def resample(x, sampling_rate, new_sampling_rate, window='hann', no_filter=True, strict_length=False, ctx=None):
     """``Trace.resample(sampling_rate, window='hann', no_filter=True, strict_length=False)``: Fourier
     method -- rfft, frequency-domain window ``ifftshift(get_window(window, npts))`` (or a callable
@@ -115,8 +125,10 @@ def resample(x, sampling_rate, new_sampling_rate, window='hann', no_filter=True,
                 raise ValueError('Window has to be the same shape as the data.')
             large_w = window.astype(np.float64)
         else:
-            large_w = np.fft.ifftshift(scipy.signal.get_window(str(window), npts))
-        wh = large_w[:npts // 2 + 1]
+            large_w = None
+            wh = _named_window_half(str(window), npts)       # cached: 4.32 M samples of a window cost more than the transform
+        if large_w is not None:
+            wh = large_w[:npts // 2 + 1]
     # bin position of new frequency j: (j * new_rate / num) / (old_rate / npts)
     ratio = (float(new_sampling_rate) / num) / (float(sampling_rate) / npts)
     return _ops.resample(ctx, x, num, ratio, wh), float(new_sampling_rate)
