@@ -226,6 +226,12 @@ int xcx_taper_table(xcx_ctx* ctx, float* x, long batch, long n, const float* fla
 int xcx_post_prep(xcx_ctx* ctx, float* x, long batch, long npts, long idx_min, long idx_max,
                   int unbias, long taper_nmax, int wtype, int on_device);
 int xcx_onebit(xcx_ctx* ctx, float* x, long batch, long n, int on_device);
+/* Row scaling and row maxima for the ObsPy-named preprocess ops that are a division by one number per trace
+ * (stream/process.py:29-94: `remove_sensitivity` = Trace.remove_sensitivity, `normalize` = Trace.normalize):
+ * x[r][:] *= factor[r] (factor: `batch` host doubles; the product is formed in float64 and rounded once), and
+ * out[r] = max |x[r][:]| (out: `batch` host floats). */
+int xcx_scale_rows(xcx_ctx* ctx, float* x, long batch, long n, const double* factor, int on_device);
+int xcx_absmax_rows(xcx_ctx* ctx, const float* x, long batch, long n, float* out, int on_device);
 /* Running-absolute-mean temporal normalisation (Bensen et al. 2007 eq. 1; self-defined,
  * the reference has none): x[t] /= mean(|x[t-h .. t+h]|), the window truncated at the
  * row ends and averaged over the samples it holds; 0 where the mean is 0.  h <= 3072. */

@@ -115,6 +115,47 @@ def test_device_resident_rows(ctx, raw):
     assert relerr(z.to_host(), R.lanczos_interpolation(raw, 3.25, 5.0, 1000, 20)) < TOL
 
 
+def test_operation_list_on_device_resident_rows(ctx, raw):
+    """The whole list of scripts/cc.py's EDH channel (without remove_response) with the rows staying on the device:
+    trim (a column slice), remove_sensitivity and normalize (row scaling) included -- against the same list on the
+    host arrays, op for op the same kernels, and against the oracle."""
+    chain = [
+        ('detrend', {'type': 'demean'}),
+        ('filter', {'type': 'highpass', 'freq': .05}),
+        ('remove_sensitivity', {}),
+        ('decimate', {'factor': 5}),
+        ('trim', {}),
+        ('detrend', {'type': 'demean'}),
+        ('taper', {'type': 'cosine', 'max_percentage': 0.05, 'max_length': 30.}),
+        ('normalize', {}),
+    ]
+    n = raw.shape[-1]
+    t1, t2 = 3.0, (n - 1) / 250. - 5.0                  # cut 3 s at the start and 5 s at the end
+    kw = dict(ctx=ctx, t0=0.0, starttime=t1, endtime=t2, sensitivity=6.1e8, return_t0=True)
+    yh, fh, t0h = stream.apply_operations(raw, 250., chain, **kw)
+    d = ctx.array(raw)
+    yd, fd, t0d = stream.apply_operations(d, 250., chain, **kw)
+    assert fd == fh == 50. and t0d == t0h and tuple(yd.shape) == yh.shape
+    got = yd.to_host()
+    assert relerr(got, yh) < TOL
+    assert np.allclose(np.abs(got).max(axis=-1), 1.0, rtol=1e-6)      # normalize: unit absolute maximum per row
+    r = R.demean(raw)
+    r = R.sosfilt(stream.butter_sos('highpass', 250., 4, freq=.05), r) / 6.1e8
+    r = R.decimate(r, 250., 5)
+    i0 = int(round(t1 * 50.)); i1 = int(round(t2 * 50.)) + 1
+    r = R.demean(r[:, i0:i1])
+    r = r * R.cosine_taper_obspy(r.shape[-1], 50., 0.05, 30.)
+    r = r / np.abs(r).max(axis=-1, keepdims=True)
+    assert got.shape == r.shape and relerr(got, r) < 5 * TOL
+    # the row ops by themselves
+    x = (np.random.default_rng(5).standard_normal((7, 50001)) * 3).astype(np.float32)
+    dx = ctx.array(x)
+    assert np.array_equal(ops.absmax_rows(ctx, dx), np.abs(x).max(axis=-1))
+    f = np.linspace(0.5, 2.0, 7)
+    assert np.array_equal(ops.scale_rows(ctx, dx, f).to_host(), (x.astype(np.float64) * f[:, None]).astype(np.float32))
+    assert np.array_equal(ops.scale_rows(ctx, x, 0.25), x * np.float32(0.25))          # host rows, scalar factor
+
+
 def test_filter_zerophase_is_obspys_two_pass_form(ctx, raw):
     """Trace.filter(zerophase=True) = sosfilt forward from rest, then sosfilt of the
     reversed signal from rest -- NOT scipy's sosfiltfilt (odd padding + steady-state start)."""

@@ -74,6 +74,8 @@ SIGNATURES = {
     'xcx_taper': [_vp, _vp, _l, _l, _l, _i, _i],
     'xcx_unbias': [_vp, _vp, _l, _l, _l, _l, _i],
     'xcx_onebit': [_vp, _vp, _l, _l, _i],
+    'xcx_scale_rows': [_vp, _vp, _l, _l, _vp, _i],
+    'xcx_absmax_rows': [_vp, _vp, _l, _l, _vp, _i],
     'xcx_detrend_nan': [_vp, _vp, _l, _l, _i, _i],
     'xcx_taper_table': [_vp, _vp, _l, _l, _vp, _l, _i],
     'xcx_post_prep': [_vp, _vp, _l, _l, _l, _l, _i, _l, _i, _i],

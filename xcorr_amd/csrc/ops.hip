@@ -372,6 +372,9 @@ struct Staged {
     }
     return XCX_OK;
   }
+  void staged_discard() {                   // read-only op: nothing to copy back (the stream is idle)
+    if (staged) (void)hipFree(dev);
+  }
 };
 
 inline int grid_for(long total) {
@@ -521,6 +524,73 @@ extern "C" int xcx_post_prep(xcx_ctx* ctx, float* x, long batch, long npts, long
                      wtype, unbias);
   HIP_TRY(hipGetLastError());
   return st.end();
+}
+
+// x[r][:] *= factor[r] (float64 factor, product rounded once to float32): Trace.remove_sensitivity / Trace.normalize
+// of the preprocess lists (stream/process.py:29-94) on device-resident rows
+__global__ void k_scale_rows(float* __restrict__ x, long n, const double* __restrict__ f) {
+  const double fr = f[blockIdx.y];
+  float* __restrict__ row = x + (size_t)blockIdx.y * n;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    row[i] = (float)((double)row[i] * fr);
+}
+// out[r][part] = max |x[r][i]| over the part's slice (NaN ignored like a comparison does); the host takes the maximum
+__global__ __launch_bounds__(NT) void k_absmax_part(const float* __restrict__ x, long n, float* __restrict__ out) {
+  __shared__ float red[NT];
+  const float* __restrict__ row = x + (size_t)blockIdx.y * n;
+  const long per = (n + gridDim.x - 1) / gridDim.x;
+  const long lo = (long)blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+  float m = 0.f;
+  row_visit(row, lo, hi, [&](long, float v) { const float a = fabsf(v); m = a > m ? a : m; });
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = NT / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0];
+}
+
+extern "C" int xcx_scale_rows(xcx_ctx* ctx, float* x, long batch, long n, const double* factor, int on_device) {
+  if (!ctx || !x || !factor) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || n < 1 || batch > 65535) return set_err(XCX_EINVAL, "batch in [1, 65535] and n >= 1 required");
+  HIP_TRY(hipSetDevice(ctx->device));
+  DevBuf& fb = ctx->scratch[0];
+  int rc;
+  if ((rc = fb.ensure(ctx, sizeof(double) * (size_t)batch))) return rc;
+  HIP_TRY(hipMemcpyAsync(fb.ptr, factor, sizeof(double) * (size_t)batch, hipMemcpyHostToDevice, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));          // `factor` is the caller's
+  Staged st;
+  if ((rc = st.begin(ctx, x, (size_t)batch * n * sizeof(float), on_device))) return rc;
+  hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)std::min<long>((n + NT - 1) / NT, 4096), (unsigned)batch), dim3(NT), 0,
+                     ctx->stream, st.dev, n, (const double*)fb.ptr);
+  HIP_TRY(hipGetLastError());
+  return st.end();
+}
+
+extern "C" int xcx_absmax_rows(xcx_ctx* ctx, const float* x, long batch, long n, float* out, int on_device) {
+  if (!ctx || !x || !out) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || n < 1 || batch > 65535) return set_err(XCX_EINVAL, "batch in [1, 65535] and n >= 1 required");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const int parts = (int)std::max<long>(1, std::min<long>(64, n / 4096));
+  DevBuf& pb = ctx->scratch[0];
+  int rc;
+  if ((rc = pb.ensure(ctx, sizeof(float) * (size_t)batch * parts))) return rc;
+  Staged st;
+  if ((rc = st.begin(ctx, const_cast<float*>(x), (size_t)batch * n * sizeof(float), on_device))) return rc;
+  hipLaunchKernelGGL(k_absmax_part, dim3((unsigned)parts, (unsigned)batch), dim3(NT), 0, ctx->stream, (const float*)st.dev, n,
+                     (float*)pb.ptr);
+  HIP_TRY(hipGetLastError());
+  std::vector<float> h((size_t)batch * parts);
+  HIP_TRY(hipMemcpyAsync(h.data(), pb.ptr, sizeof(float) * h.size(), hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (long r = 0; r < batch; ++r) {
+    float m = 0.f;
+    for (int q = 0; q < parts; ++q) m = std::max(m, h[(size_t)r * parts + q]);
+    out[r] = m;
+  }
+  st.staged_discard();
+  return XCX_OK;
 }
 
 extern "C" int xcx_onebit(xcx_ctx* ctx, float* x, long batch, long n, int on_device) {

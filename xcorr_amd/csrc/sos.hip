@@ -341,7 +341,14 @@ std::vector<ld> mat_mul(const std::vector<ld>& a, const std::vector<ld>& b, int 
 }
 
 // A^e for the one-step zero-input transition A of the cascade
+std::vector<ld> transition_power_ld(const SosParams& P, long e);
 std::vector<double> transition_power(const SosParams& P, long e) {
+  const std::vector<ld> R = transition_power_ld(P, e);
+  std::vector<double> out(R.size());
+  for (size_t i = 0; i < out.size(); ++i) out[i] = (double)R[i];
+  return out;
+}
+std::vector<ld> transition_power_ld(const SosParams& P, long e) {
   const int D = 2 * P.K;
   std::vector<ld> A((size_t)D * D, 0), R((size_t)D * D, 0);
   for (int j = 0; j < D; ++j) {
@@ -356,9 +363,7 @@ std::vector<double> transition_power(const SosParams& P, long e) {
     A = mat_mul(A, A, D);
     e >>= 1;
   }
-  std::vector<double> out((size_t)D * D);
-  for (size_t i = 0; i < out.size(); ++i) out[i] = (double)R[i];
-  return out;
+  return R;
 }
 
 int parse_sos(const double* sos, int K, SosParams& P) {
@@ -432,21 +437,35 @@ int run_pass(xcx_ctx* ctx, float* x, long rows, long n, const SosParams& P,
     for (size_t i = 0; i < bytes; ++i) { key ^= c[i]; key *= 1099511628211ULL; }
   };
   mix(&P.K, sizeof P.K); mix(P.c, sizeof(SosCoef) * P.K); mix(&Lc, sizeof Lc); mix(&last_len, sizeof last_len);
-  if (key != ctx->sos_key || !ctx->sos_tab.ptr) {
+  int slot = -1;
+  for (int i = 0; i < xcx_ctx::kSosTabs; ++i)
+    if (ctx->sos_key[i] == key && ctx->sos_tab[i].ptr) slot = i;
+  if (slot < 0) {
+    // A^(j Lc) and A^(last_len + (j-1) Lc), j = 0 .. kScanG, by ONE long-double product per table entry from A^Lc and
+    // A^last_len (computing every power from scratch by repeated squaring cost 12 ms for a 6-section filter)
     std::vector<double> tab(nmat * D * D);
+    const std::vector<ld> M = transition_power_ld(P, Lc), Ml = transition_power_ld(P, last_len);
+    std::vector<ld> a((size_t)D * D, 0), b((size_t)D * D, 0);
+    for (int i = 0; i < D; ++i) a[(size_t)i * D + i] = b[(size_t)i * D + i] = 1;      // j = 0: identity for both
     for (int j = 0; j <= kScanG; ++j) {
-      const std::vector<double> a = transition_power(P, (long)j * Lc);
-      const std::vector<double> b = transition_power(P, j == 0 ? 0 : last_len + (long)(j - 1) * Lc);
-      std::copy(a.begin(), a.end(), tab.begin() + (size_t)j * D * D);
-      std::copy(b.begin(), b.end(), tab.begin() + ((size_t)(kScanG + 1) + j) * D * D);
+      if (j == 1) b = Ml;
+      else if (j > 1) b = mat_mul(b, M, D);
+      if (j >= 1) a = mat_mul(a, M, D);
+      for (size_t i = 0; i < (size_t)D * D; ++i) {
+        tab[(size_t)j * D * D + i] = (double)a[i];
+        tab[((size_t)(kScanG + 1) + j) * D * D + i] = (double)b[i];
+      }
     }
-    ctx->sos_key = 0;
-    if ((rc = ctx->sos_tab.ensure(ctx, sizeof(double) * tab.size()))) return rc;
-    HIP_TRY(hipMemcpyAsync(ctx->sos_tab.ptr, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
+    slot = ctx->sos_next;
+    ctx->sos_next = (ctx->sos_next + 1) % xcx_ctx::kSosTabs;
+    ctx->sos_key[slot] = 0;
+    if ((rc = ctx->sos_tab[slot].ensure(ctx, sizeof(double) * tab.size()))) return rc;
+    // the slot may still be read by queued kernels of an earlier call: the copy is stream-ordered behind them
+    HIP_TRY(hipMemcpyAsync(ctx->sos_tab[slot].ptr, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    ctx->sos_key = key;
+    ctx->sos_key[slot] = key;
   }
-  const double* PW = (const double*)ctx->sos_tab.ptr;
+  const double* PW = (const double*)ctx->sos_tab[slot].ptr;
   const double* PWs = PW + (size_t)(kScanG + 1) * D * D;
   const double* Mfull = PW + (size_t)D * D;                  // A^Lc
   const double* Mlast = PWs + (size_t)D * D;                 // A^last_len

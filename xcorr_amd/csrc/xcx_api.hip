@@ -166,7 +166,7 @@ extern "C" int xcx_destroy(xcx_ctx* ctx) {
   if (ctx->ts_plan) xcx_plan_destroy(ctx->ts_plan);
   for (auto* bp : ctx->bs_plan) if (bp) xcx_plan_destroy(bp);
   ctx->sg_tab.release();
-  ctx->sos_tab.release();
+  for (auto& t : ctx->sos_tab) t.release();
   ctx->bs_tab.release();
   for (auto& b : ctx->scratch) b.release();
   if (ctx->flow_T) (void)hipFree(ctx->flow_T);

@@ -44,8 +44,13 @@ struct xcx_ctx {
   long bs_tab_n = 0;
   xcx::DevBuf sg_tab;                    // cached DFT-matrix tables of xcx_spectrogram
   unsigned long long sg_key = 0;
-  xcx::DevBuf sos_tab;                   // cached transition-matrix powers of the chunked SOS scan
-  unsigned long long sos_key = 0;
+  // cached transition-matrix powers of the chunked SOS scan, one table per (filter, chunk geometry): a preprocess
+  // list alternates between its filters (high-pass, anti-alias low-pass, low-pass ...), so one slot would miss
+  // on every call
+  static constexpr int kSosTabs = 8;
+  xcx::DevBuf sos_tab[kSosTabs];
+  unsigned long long sos_key[kSosTabs] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int sos_next = 0;
   // flow pair kernel (one launch per pair phase, in-kernel batch dependencies): device error
   // flag + pinned host mirror, checked by every synchronising entry point
   void* flow_T = nullptr; size_t flow_T_bytes = 0;   // uncached T ring, shared by the context's plans (grow-only)

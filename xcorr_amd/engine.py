@@ -5,6 +5,7 @@ DeviceArray (caller-owned HBM buffer) and CCPlan (cross-correlation plan).
 This is plumbing only; all arithmetic happens in libxcx.so.
 """
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -23,9 +24,11 @@ class DeviceArray:
         self.shape = tuple(int(s) for s in np.atleast_1d(shape))
         self.dtype = np.dtype(dtype)
         self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
-        p = C.c_void_p()
-        check(_ffi.lib().xcx_malloc(ctx.handle, self.nbytes, C.byref(p)))
-        self.ptr = p.value
+        self.ptr = ctx._pool_take(self.nbytes)
+        if self.ptr is None:
+            p = C.c_void_p()
+            check(_ffi.lib().xcx_malloc(ctx.handle, self.nbytes, C.byref(p)))
+            self.ptr = p.value
         ctx._children.add(self)
 
     def columns_from(self, col0):
@@ -49,7 +52,8 @@ class DeviceArray:
         # a context that is already closed has released everything it owned
         # (finalisers may run in any order at interpreter exit)
         if self.ptr and self.ctx.handle:
-            check(_ffi.lib().xcx_free(self.ctx.handle, C.c_void_p(self.ptr)))
+            if not self.ctx._pool_give(self.ptr, self.nbytes):
+                check(_ffi.lib().xcx_free(self.ctx.handle, C.c_void_p(self.ptr)))
         self.ptr = None
 
     close = free
@@ -109,6 +113,38 @@ class Context:
         self._pin_pool = {}                     # capacity -> [addresses] of idle page-locked blocks
         self._pin_idle = 0                      # bytes held by those idle blocks
         self._plans = {}                        # (n, lag slice, flags) -> CCPlan kept for repeated driver calls
+        # Freed device buffers of a chain of row ops are handed to the next result of the same size instead of going
+        # through hipFree / hipMalloc (milliseconds each for day-long rows, and hipFree drains the device): exact-size
+        # free lists, bounded (XCX_DEV_POOL_MB, default 8192; 0 = off; single blocks up to half of it).
+        self._dev_pool = {}                     # nbytes -> [device pointers]
+        self._dev_pool_bytes = 0
+        self._dev_pool_cap = max(0, int(os.environ.get('XCX_DEV_POOL_MB', '8192'))) << 20
+
+    def _pool_take(self, nbytes):
+        blocks = self._dev_pool.get(nbytes)
+        if not blocks:
+            return None
+        p = blocks.pop()
+        self._dev_pool_bytes -= nbytes
+        # the previous owner's kernels may still be queued on the context's streams, and host copies run on another
+        # (blocking) stream: wait once here -- what hipFree used to do implicitly
+        check(_ffi.lib().xcx_sync(self.handle))
+        return p
+
+    def _pool_give(self, p, nbytes):
+        if nbytes < (1 << 20) or nbytes > self._dev_pool_cap // 2 or self._dev_pool_bytes + nbytes > self._dev_pool_cap:
+            return False
+        self._dev_pool.setdefault(nbytes, []).append(p)
+        self._dev_pool_bytes += nbytes
+        return True
+
+    def trim_pool(self):
+        """Return every pooled device buffer to the driver."""
+        for blocks in self._dev_pool.values():
+            for p in blocks:
+                _ffi.lib().xcx_free(self.handle, C.c_void_p(p))
+        self._dev_pool = {}
+        self._dev_pool_bytes = 0
 
     def plan(self, n, index_min=0, index_max=None, **flags):
         """A :class:`CCPlan` owned by the context and reused by later calls with the same arguments
@@ -127,6 +163,7 @@ class Context:
             self._plans = {}
             for child in list(self._children):
                 child.close()
+            self.trim_pool()
             for blocks in self._pin_pool.values():
                 for addr in blocks:
                     _ffi.lib().xcx_host_free(self.handle, C.c_void_p(addr))

@@ -22,12 +22,22 @@ __all__ = ['copy', 'norm1d', 'demean', 'detrend_linear', 'taper', 'taper_table',
 
 
 def _prep(x):
-    """-> (buffer, batch, n, on_device, restore)"""
+    """-> (buffer, batch, n, on_device, restore).  Host rows are copied (the ops work in place on their argument, the
+    mirrors of the reference return a new array): for a megabyte and more the copy lives in page-locked memory from
+    the default context's pool, so that the library's H2D / D2H of it run at link speed -- through pageable memory
+    the two transfers of a 68 MB block of CCF rows took 17 of a call's 21 ms."""
     if isinstance(x, DeviceArray):
         n = x.shape[-1]
         batch = int(np.prod(x.shape[:-1])) if len(x.shape) > 1 else 1
         return x, batch, n, 1, None
-    a = np.array(x, dtype=np.float32, order='C', copy=True)
+    src = np.asarray(x)
+    if src.ndim == 0:
+        raise ValueError('array with at least one dimension required')
+    if src.size * 4 >= (1 << 20):
+        a = default_context().pinned_empty(src.shape, np.float32)
+        np.copyto(a, src, casting='unsafe')
+    else:
+        a = np.array(src, dtype=np.float32, order='C', copy=True)
     if a.ndim == 0:
         raise ValueError('array with at least one dimension required')
     n = a.shape[-1]
@@ -145,6 +155,32 @@ def post_prep(ctx, x, npts, index_min=0, index_max=0, unbiased=True, taper_nmax=
     check(_ffi.lib().xcx_post_prep(ctx.handle, ptr(buf), b, int(npts), int(index_min), int(index_max),
                                    int(bool(unbiased)), int(taper_nmax), wt, dev))
     return buf
+
+
+def scale_rows(ctx, x, factor):
+    """x[r] *= factor[r] in place (one float64 factor per row, or a scalar): the division by a sensitivity or a
+    norm of the ObsPy-named preprocess ops on device-resident (or host) rows."""
+    ctx = _ctx(ctx, x)
+    buf, b, n, dev, _ = _prep(x)
+    f = np.ascontiguousarray(np.broadcast_to(np.asarray(factor, dtype=np.float64).reshape(-1), (b,)))
+    check(_ffi.lib().xcx_scale_rows(ctx.handle, ptr(buf), b, n, ptr(f), dev))
+    return buf
+
+
+def absmax_rows(ctx, x):
+    """max |x[r]| per row -> host float32 array [rows]."""
+    ctx = _ctx(ctx, x)
+    if isinstance(x, DeviceArray):
+        src, dev = x, 1
+        n = x.shape[-1]
+        b = int(np.prod(x.shape[:-1])) if len(x.shape) > 1 else 1
+    else:
+        src = np.ascontiguousarray(x, dtype=np.float32)
+        dev, n = 0, src.shape[-1]
+        b = int(np.prod(src.shape[:-1])) if src.ndim > 1 else 1
+    out = np.empty(b, np.float32)
+    check(_ffi.lib().xcx_absmax_rows(ctx.handle, ptr(src), b, n, ptr(out), dev))
+    return out
 
 
 def onebit(ctx, x):

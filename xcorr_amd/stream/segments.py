@@ -99,11 +99,33 @@ def _fill(gap, left, right, fill_value):
     return gap
 
 
+def _is_device(x):
+    from ..engine import DeviceArray
+    return isinstance(x, DeviceArray)
+
+
+def _device_columns(x, i0, i1):
+    """Columns [i0, i1) of device-resident rows as a contiguous DeviceArray (row-wise device copies)."""
+    import ctypes as C
+    from .. import _ffi
+    from ..engine import DeviceArray
+    rows = int(np.prod(x.shape[:-1])) if len(x.shape) > 1 else 1
+    n, w, isz = x.shape[-1], i1 - i0, x.dtype.itemsize
+    pitch = getattr(x, '_pitch', n * isz)
+    y = DeviceArray(x.ctx, tuple(x.shape[:-1]) + (w,), x.dtype)
+    for r in range(rows):
+        _ffi.check(_ffi.lib().xcx_memcpy_d2d(x.ctx.handle, C.c_void_p(y.ptr + r * w * isz),
+                                             C.c_void_p(x.ptr + r * pitch + i0 * isz), w * isz))
+    return y
+
+
 def trim(x, sampling_rate, t0, starttime=None, endtime=None, pad=False, nearest_sample=True, fill_value=None):
     """``Trace.trim``: cut (or, with `pad`, extend) to [starttime, endtime] seconds.
     nearest_sample=True selects the samples nearest to the bounds; False only samples
     inside them.  Padding uses `fill_value` (None: NaN).  Returns ``(y, new_t0)``."""
-    x = np.asarray(x)
+    dev = _is_device(x)
+    if not dev:
+        x = np.asarray(x)
     fs = float(sampling_rate)
     n = x.shape[-1]
     if starttime is not None and endtime is not None and starttime > endtime:
@@ -120,6 +142,14 @@ def trim(x, sampling_rate, t0, starttime=None, endtime=None, pad=False, nearest_
             i1 = n + int(math.floor(round((endtime - t_end) * fs, 7)))
     if not pad:
         i0, i1 = max(i0, 0), min(i1, n)
+    if dev:
+        # device-resident rows: the cut is a column slice copied into a buffer of its own; padding (samples that
+        # do not exist) and empty results stay host features
+        if i0 < 0 or i1 > n or i1 <= i0:
+            raise ValueError('trim of device-resident rows must select existing samples (pad=False, non-empty)')
+        if i0 == 0 and i1 == n:
+            return x, t0
+        return _device_columns(x, i0, i1), t0 + i0 / fs
     if i1 <= i0:
         return x[..., :0].copy(), t0 + i0 / fs
     fill = np.nan if fill_value is None else fill_value
@@ -137,7 +167,10 @@ def trim(x, sampling_rate, t0, starttime=None, endtime=None, pad=False, nearest_
 
 def remove_sensitivity(x, sensitivity):
     """``Trace.remove_sensitivity``: divide by the overall sensitivity of the channel
-    (``inventory.get_response(...).instrument_sensitivity.value``)."""
+    (``inventory.get_response(...).instrument_sensitivity.value``).  Device-resident rows are scaled in place."""
+    if _is_device(x):
+        from .. import ops as _ops
+        return _ops.scale_rows(x.ctx, x, 1.0 / np.asarray(sensitivity, dtype=np.float64))
     x = np.asarray(x)
     return (x / sensitivity).astype(x.dtype if x.dtype.kind == 'f' else np.float64)
 
@@ -146,6 +179,16 @@ def normalize(x, norm=None):
     """``Trace.normalize(norm=None)``: divide by the absolute maximum of the trace (or by `norm`; a negative
     `norm` is used by its absolute value, as ObsPy does with a warning).  An all-zero trace is returned
     unchanged.  Documented ObsPy behaviour restated, unverified vs obspy."""
+    if _is_device(x):
+        from .. import ops as _ops
+        if norm is None:
+            m = _ops.absmax_rows(x.ctx, x).astype(np.float64)
+            f = np.where(m == 0, 1.0, 1.0 / np.where(m == 0, 1.0, m))
+        else:
+            if float(norm) == 0:
+                return x
+            f = 1.0 / abs(float(norm))
+        return _ops.scale_rows(x.ctx, x, f)
     x = np.asarray(x)
     if norm is None:
         norm = np.abs(x).max(axis=-1, keepdims=True) if x.size else 1.0
