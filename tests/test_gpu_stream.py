@@ -60,6 +60,17 @@ def test_lanczos_interpolate(ctx, raw, new_rate, a):
         stream.interpolate(x, 250., new_rate, a=a, npts=10 ** 9, ctx=ctx)
 
 
+def test_lanczos_positions_next_to_a_sample(ctx, raw):
+    """Interpolation points a rounding error away from an input sample (250 -> 333.3 Hz: k * 0.750075 passes
+    30003.000000000004): the kernel's sines come from a rotation per tap, the centre taps from sinpi itself."""
+    x = raw[:, :50000]
+    for step, off, a in ((0.750075, 0.0, 12), (1.0 + 1e-13, 1e-12, 20), (2.5, 3.0000000001, 8), (0.2 + 1e-14, 2.0 - 1e-13, 3)):
+        nout = int((x.shape[1] - 1 - off) / step)
+        got = ops.lanczos(ctx, x, nout, off, step, a)
+        ref = R.lanczos_interpolation(x, off, step, nout, a)
+        assert relerr(got, ref) < TOL, (step, off, a)
+
+
 def test_lanczos_bandlimited_signal_is_recovered(ctx):
     t = np.arange(20000) / 250.
     x = np.sin(2 * np.pi * 2.3 * t).astype(np.float32)[None]

@@ -78,7 +78,11 @@ def run(budget=60.0, seed=0, ctx=None):
                 tol = 1e-5
         elif kind == 'lanczos':
             n = int(rng.integers(50, 50000)); a_ = int(rng.integers(1, 25)); step = float(rng.uniform(0.2, 7.))
-            off = float(rng.uniform(0, 3)); nout = max(1, int((n - 1 - off) / step))
+            off = float(rng.uniform(0, 3))
+            if rng.random() < 0.3:       # positions a rounding away from a sample: the centre tap's sine is ~1e-12
+                step = float(rng.choice([0.75, 0.750075, 2.5, 1.0 + 1e-13, 0.2 + 1e-14]))
+                off = float(rng.choice([0.0, 1e-12, 3.0000000001, 2.0 - 1e-13]))
+            nout = max(1, int((n - 1 - off) / step))
             x = rng.standard_normal((2, n)).astype(np.float32)
             e = rel(ops.lanczos(ctx, x, nout, off, step, a_), R.lanczos_interpolation(x, off, step, nout, a_)); tol = 1e-5
         elif kind == 'timeshift_fft':
