@@ -257,8 +257,8 @@ __global__ __launch_bounds__(NT) void k2d_rows_inv(const cf* __restrict__ T2, G2
                                                    long long* __restrict__ rowidx, const cf* __restrict__ tw_sub,
                                                    const cf* __restrict__ tw_unt) {
   extern __shared__ __attribute__((aligned(16))) cf lds[];
-  __shared__ float bv[NT];
-  __shared__ long long bi[NT];
+  __shared__ float bv[NT / 64];
+  __shared__ long long bi[NT / 64];
   constexpr int R = RX::L;
   const int m1 = blockIdx.x, q = blockIdx.y;
   const int P1 = g.P1, P2 = 2 * R;
@@ -329,20 +329,21 @@ __global__ __launch_bounds__(NT) void k2d_rows_inv(const cf* __restrict__ T2, G2
     __syncthreads();
     fft_stage_c<R, RX::R2, RX::R0 * RX::R1, 1, NT, true, false, false>(b2, lds_ld, out_f);
   }
-  bv[threadIdx.x] = best;
-  bi[threadIdx.x] = bestj == 0x7fffffff ? 0x7fffffffffffffffLL : (long long)i * OW + bestj;
-  __syncthreads();
-  for (int o = NT / 2; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) {
-      const float v2 = bv[threadIdx.x + o];
-      const long long i2 = bi[threadIdx.x + o];
-      if (v2 > bv[threadIdx.x] || (v2 == bv[threadIdx.x] && i2 < bi[threadIdx.x])) {
-        bv[threadIdx.x] = v2; bi[threadIdx.x] = i2;
-      }
-    }
-    __syncthreads();
+  // first maximum of the row: lanes by shuffles, the four waves through LDS (one barrier instead of nine)
+  long long bix = bestj == 0x7fffffff ? 0x7fffffffffffffffLL : (long long)i * OW + bestj;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float v2 = __shfl_down(best, o);
+    const long long i2 = __shfl_down(bix, o);
+    if (v2 > best || (v2 == best && i2 < bix)) { best = v2; bix = i2; }
   }
-  if (threadIdx.x == 0) { rowbest[(size_t)q * P1 + m1] = bv[0]; rowidx[(size_t)q * P1 + m1] = bi[0]; }
+  if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = bix; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < NT / 64; ++w)
+      if (bv[w] > best || (bv[w] == best && bi[w] < bix)) { best = bv[w]; bix = bi[w]; }
+    rowbest[(size_t)q * P1 + m1] = best; rowidx[(size_t)q * P1 + m1] = bix;
+  }
 }
 
 // final reduction over the P1 rows of a pair
