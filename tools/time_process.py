@@ -22,3 +22,12 @@ import cProfile, pstats
 ds = core.init('A-B', 0., 86400., sampling_rate=fs, window_length=wl, window_overlap=.5)
 pr = cProfile.Profile(); pr.enable(); core.process(ds, client, ctx=ctx); pr.disable()
 pstats.Stats(pr).sort_stats('cumulative').print_stats(14)
+# ... and the post-processing of that container (core/postprocess.py: unbias -> demean -> taper -> timeshift -> filter -> taper)
+ds.pair_offset[...] = 0.0049
+for rep in range(3):
+    t0 = time.perf_counter()
+    pp = core.postprocess(ds, ctx=ctx)
+    ctx.sync()
+    print(f'postprocess {1e3*(time.perf_counter()-t0):.1f} ms for {int((ds.status==1).sum())} rows of {ds.cc.shape[-1]} lags', flush=True)
+pr = cProfile.Profile(); pr.enable(); core.postprocess(ds, ctx=ctx); pr.disable()
+pstats.Stats(pr).sort_stats('cumulative').print_stats(14)

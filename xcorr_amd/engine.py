@@ -73,7 +73,9 @@ class DeviceArray:
         return self
 
     def to_host(self):
-        out = np.empty(self.shape, dtype=self.dtype)
+        # page-locked from the context's pool for a megabyte and more: D2H at link speed
+        out = (self.ctx.pinned_empty(self.shape, self.dtype) if self.nbytes >= (1 << 20)
+               else np.empty(self.shape, dtype=self.dtype))
         check(_ffi.lib().xcx_memcpy_d2h(self.ctx.handle, ptr(out),
                                         C.c_void_p(self.ptr), self.nbytes))
         return out
