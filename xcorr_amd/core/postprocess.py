@@ -82,7 +82,15 @@ def postprocess(ds, lag_lim=None, lag_min=None, lag_max=None, filter_kwargs=None
     valid = ds.status == 1
     if not valid.any():
         raise ValueError("No data after extracting valid times")
-    rows = np.ascontiguousarray(ds.cc[valid][:, i0:i1], dtype=np.float32)
+    # one gather of the valid rows' lag slice (boolean indexing of the whole rows followed by the slice copied the
+    # block twice; a container without gaps needs no gather at all)
+    cc2 = ds.cc.reshape(-1, ds.cc.shape[-1])
+    vflat = valid.reshape(-1)
+    if vflat.all():
+        rows = cc2[:, i0:i1]
+    else:
+        rows = cc2[np.flatnonzero(vflat), i0:i1]
+    rows = np.ascontiguousarray(rows, dtype=np.float32)
     delay = -(ds.pair_offset + ds.time_offset)[valid]
     ctx = ctx or default_context()
     y = postprocess_rows(rows, delay, fs, npts, imin, imax, filter_kwargs=fk, ctx=ctx)   # one H2D, one D2H
@@ -91,7 +99,7 @@ def postprocess(ds, lag_lim=None, lag_min=None, lag_max=None, filter_kwargs=None
                     {**la, 'index_min': imin, 'index_max': imin + n},
                     {**ds.cc_attrs, 'unbiased': np.byte(1), 'postprocess': 'xcorr_amd'},
                     ds.time_attrs, dtype=ds.cc.dtype)
-    out.cc[valid] = y.astype(ds.cc.dtype)
+    out.cc[valid] = y.astype(ds.cc.dtype, copy=False)
     out.status[...] = ds.status
     out.pair_offset[...] = ds.pair_offset
     out.time_offset[...] = ds.time_offset
