@@ -175,6 +175,8 @@ int bluestein_core(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom
   const size_t in_row = (size_t)g.in_pitch * (g.in_complex == 1 ? 8 : 4);
   const size_t out_row = (size_t)(g.out_pitch ? g.out_pitch : g.nout) * (real_only ? 4 : 8);
   const bool stage_in = !in_dev, stage_out = !out_dev;
+  HostPin pin_in(stage_in ? in : nullptr, in_row * (size_t)batch);          // host rows: DMA at link speed
+  HostPin pin_out(stage_out ? out : nullptr, out_row * (size_t)batch);
   const float* ind = in;
   float* outd = out;
   if (stage_in) {

@@ -110,9 +110,14 @@ __global__ __launch_bounds__(NT) void k_block_rms(const float* __restrict__ x, f
 struct IO {
   xcx_ctx* ctx; const float* in_d = nullptr; float* out_d = nullptr; float* out_h = nullptr;
   void *a = nullptr, *b = nullptr; size_t out_bytes = 0; int on_device;
+  void *pin_in = nullptr, *pin_out = nullptr;      // host buffers page-registered for the call (link-speed DMA)
   int begin(xcx_ctx* c, const float* in, size_t in_bytes, float* out, size_t ob, int dev) {
     ctx = c; on_device = dev; out_bytes = ob;
     if (dev) { in_d = in; out_d = out; return XCX_OK; }
+    if (in_bytes >= ((size_t)1 << 20) && hipHostRegister(const_cast<float*>(in), in_bytes, hipHostRegisterDefault) == hipSuccess) pin_in = const_cast<float*>(in);
+    else (void)hipGetLastError();
+    if (ob >= ((size_t)1 << 20) && hipHostRegister(out, ob, hipHostRegisterDefault) == hipSuccess) pin_out = out;
+    else (void)hipGetLastError();
     HIP_TRY(hipMalloc(&a, in_bytes));
     HIP_TRY(hipMalloc(&b, ob));
     HIP_TRY(hipMemcpyAsync(a, in, in_bytes, hipMemcpyHostToDevice, c->stream));
@@ -128,6 +133,9 @@ struct IO {
     if (a) (void)hipFree(a);
     if (b) (void)hipFree(b);
     a = b = nullptr;
+    if (pin_in) (void)hipHostUnregister(pin_in);        // after the synchronisation above
+    if (pin_out) (void)hipHostUnregister(pin_out);
+    pin_in = pin_out = nullptr;
     return rc;
   }
 };

@@ -553,6 +553,7 @@ int filt_entry(xcx_ctx* ctx, float* x, long batch, long n, const double* sos, in
   HIP_TRY(hipSetDevice(ctx->device));
   float* dx = x;
   const size_t bytes = (size_t)batch * n * sizeof(float);
+  HostPin pin_x(on_device ? nullptr : x, bytes);
   if (!on_device) {
     HIP_TRY(hipMalloc((void**)&dx, bytes));
     HIP_TRY(hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, ctx->stream));

@@ -238,6 +238,7 @@ extern "C" int xcx_spectrogram(xcx_ctx* ctx, const float* x, float* S, long batc
   const size_t in_b = sizeof(float) * (size_t)batch * n, out_b = in_b * nfreq;
   const float* xd = x; float* Sd = S;
   void *ha = nullptr, *hb = nullptr;
+  HostPin pin_x(on_device ? nullptr : x, in_b), pin_S(on_device ? nullptr : S, out_b);
   if (!on_device) {
     HIP_TRY(hipMalloc(&ha, in_b));
     if (hipMalloc(&hb, out_b) != hipSuccess) { (void)hipFree(ha); return set_err(XCX_ENOMEM, "spectrogram output (%zu bytes)", out_b); }
@@ -343,6 +344,7 @@ extern "C" int xcx_spectrogram_seg(xcx_ctx* ctx, const float* x, float* S, long 
     const size_t in_b = sizeof(float) * (size_t)batch * n, out_b = sizeof(float) * (size_t)batch * nfreq * nseg;
     const float* xd = x; float* Sd = S;
     void *ha = nullptr, *hb = nullptr;
+    HostPin pin_x(on_device ? nullptr : x, in_b), pin_S(on_device ? nullptr : S, out_b);
     if (!on_device) {
       HIP_TRY(hipMalloc(&ha, in_b));
       if (hipMalloc(&hb, out_b) != hipSuccess) { (void)hipFree(ha); return set_err(XCX_ENOMEM, "spectrogram output (%zu bytes)", out_b); }

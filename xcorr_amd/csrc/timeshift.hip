@@ -172,6 +172,8 @@ static int timeshift_rows(xcx_ctx* ctx, const float* x, float* y, long batch, lo
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   const float* xd = x;
   float* yd = y;
+  HostPin pin_x(on_device ? nullptr : x, sizeof(float) * (size_t)size * batch);      // host rows: DMA at link speed
+  HostPin pin_y(on_device ? nullptr : y, sizeof(float) * (size_t)n * batch);
   if (!on_device) {
     if ((rc = dx.ensure(ctx, sizeof(float) * size * batch))) return rc;
     if ((rc = dy.ensure(ctx, sizeof(float) * n * batch))) return rc;

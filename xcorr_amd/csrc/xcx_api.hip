@@ -103,24 +103,6 @@ __global__ __launch_bounds__(kNT) void k_wstats(
 // ---------------------------------------------------------------------------
 static int flow_check(xcx_ctx* ctx);
 
-// Host-pointer entry points (on_device = 0): the caller's buffer is pinned IN PLACE for the
-// duration of the call (hipHostRegister), so the DMA engines move it at PCIe speed (~55 GB/s
-// instead of ~9 GB/s through the runtime's pageable staging).  If the registration is refused
-// (read-only mapping, ulimit -l, already registered) the copy silently stays pageable.
-// XCX_PIN=0 turns it off.
-struct HostPin {
-  void* ptr = nullptr;
-  HostPin(const void* p, size_t bytes) {
-    static const bool on = !(getenv("XCX_PIN") && atoi(getenv("XCX_PIN")) == 0);
-    if (!on || !p || bytes < ((size_t)1 << 20)) return;       // small copies: not worth a syscall
-    if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) ptr = const_cast<void*>(p);
-    else (void)hipGetLastError();
-  }
-  ~HostPin() { if (ptr) (void)hipHostUnregister(ptr); }
-  HostPin(const HostPin&) = delete;
-  HostPin& operator=(const HostPin&) = delete;
-};
-
 extern "C" int xcx_device_count(int* count) {
   if (!count) return set_err(XCX_EINVAL, "count is null");
   int c = 0;

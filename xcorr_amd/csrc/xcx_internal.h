@@ -1,6 +1,7 @@
 // xcx_internal.h -- shared between the translation units of libxcx.so
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <cstddef>
 
 struct xcx_ctx;
@@ -12,6 +13,24 @@ constexpr int kMaxTransformN = 786432;
 
 namespace xcx {
 int set_err(int code, const char* fmt, ...);
+
+// Host-pointer entry points (on_device = 0): the caller's buffer is pinned IN PLACE for the
+// duration of the call (hipHostRegister), so the DMA engines move it at PCIe speed (~55 GB/s
+// instead of ~9 GB/s through the runtime's pageable staging).  If the registration is refused
+// (read-only mapping, ulimit -l, already registered or page-locked) the copy silently stays as it is.
+// XCX_PIN=0 turns it off.  The object must outlive the stream synchronisation that ends the copies.
+struct HostPin {
+  void* ptr = nullptr;
+  HostPin(const void* p, size_t bytes) {
+    static const bool on = !(getenv("XCX_PIN") && atoi(getenv("XCX_PIN")) == 0);
+    if (!on || !p || bytes < ((size_t)1 << 20)) return;       // small copies: not worth a syscall
+    if (hipHostRegister(const_cast<void*>(p), bytes, hipHostRegisterDefault) == hipSuccess) ptr = const_cast<void*>(p);
+    else (void)hipGetLastError();
+  }
+  ~HostPin() { if (ptr) (void)hipHostUnregister(ptr); }
+  HostPin(const HostPin&) = delete;
+  HostPin& operator=(const HostPin&) = delete;
+};
 
 struct DevBuf {
   void* ptr = nullptr;
