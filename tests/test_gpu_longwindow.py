@@ -136,3 +136,16 @@ def test_production_postprocess_chain(ctx):
     ref = R.postprocess_chain(rows.astype(np.float64), n, fs, i0, i1, delay)
     assert got.shape == ref.shape == (2, 1620000)
     assert _rel(got, ref) < 2 * TOL                 # six chained float32 stages
+
+
+def test_segmented_plan_random_sweep(ctx):
+    """tools/fuzz_seg.py for a few seconds: random window lengths (ragged last blocks), lag slices on either side of
+    zero lag, flags and batches, segmentation forced at block transforms of 4096 / 8192 points -- against the
+    single-transform plan and the oracle."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        'fuzz_seg', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools', 'fuzz_seg.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cases, worst = mod.run(5.0, seed=4)
+    assert cases >= 3 and worst < 1e-5
