@@ -57,6 +57,15 @@ def run(budget=60.0, seed=0):
             o = R.cc_fair(xo, yo, normalize=True, dtype=np.float64)
             e = max(e, float(np.abs(got[0] / w - o[imin:imax]).max() / np.abs(o).max()))
         tol = 1e-5
+        if rng.random() < 0.3 and not kw.get('unbiased'):
+            # the pairs(traces, windows) form: rows that share a station window share its segment transforms
+            S_ = int(rng.integers(2, 5)); W_ = int(rng.integers(1, 3)); hop_ = int(rng.integers(1, 900))
+            tr = (rng.standard_normal((S_, n + (W_ - 1) * hop_)) + 0.3).astype(np.float32)
+            pr = np.array([(int(rng.integers(0, S_)), int(rng.integers(0, S_))) for _ in range(int(rng.integers(1, 7)))], np.int32)
+            a_ = np.asarray(seg.pairs(tr, pr, W_, hop_), np.float64)
+            b_ = np.asarray(ref_plan.pairs(tr, pr, W_, hop_), np.float64)
+            sc = float(np.abs(np.asarray(full.pairs(tr, pr, W_, hop_))).max())
+            e = max(e, float(np.abs(a_ - b_).max() / sc))
         cases += 1
         worst = max(worst, e)
         if not e < tol:

@@ -23,3 +23,17 @@ ctx.sync()
 dt = (time.perf_counter() - t0) / 3
 print(f'production day window: {rows} pair-days in {dt*1e3:.2f} ms -> {dt/rows*1e3:.3f} ms per pair-day '
       f'({rows * plan.L / dt / 1e9:.2f} G lag samples/s)')
+
+# all pairs of S stations for one day-long window: rows that share a station share its segment transforms
+S = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+tr = ctx.array(rng.standard_normal((S, n), dtype=np.float32))
+pairs = np.array([(i, j) for i in range(S) for j in range(i + 1, S)], np.int32)
+outp = ctx.empty((len(pairs), 1, plan.L))
+def runp():
+    plan.pairs(tr, pairs, 1, n, out=outp)
+runp(); ctx.sync()
+t0 = time.perf_counter()
+for _ in range(3): runp()
+ctx.sync()
+dt = (time.perf_counter() - t0) / 3
+print(f'production day window, all {len(pairs)} pairs of {S} stations: {dt*1e3:.2f} ms -> {dt/len(pairs)*1e3:.3f} ms per pair-day')

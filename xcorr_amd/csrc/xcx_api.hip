@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/xcx.h"
@@ -1555,100 +1556,99 @@ extern "C" long xcx_debug_stamps(xcx_plan* p, unsigned long long* host, long max
 // ---------------------------------------------------------------------------
 namespace {
 
-// per row: sum(x), sum(y) then (after the means are known) sum((x-mx)^2 or 1), same for y.
-// A day-long row is split over kSegParts workgroups (one workgroup per row read its 4.32 M samples in a rolled loop,
-// one load pair and one wait per trip: 7.4 ms per call, 59 % of the production window); the loads go out in
-// batches of 8 and are consumed in order, the partial sums are combined in fixed order by k_seg_stats_fin.
+// Window statistics, once per DISTINCT window of the call (`ptrs`: the windows that occur as x or y of some row):
+// su[2u] = mean (0 without demean), su[2u + 1] = energy of what is transformed (after the mean / one-bit), both float64.
+// A day-long window is split over kSegParts workgroups (one workgroup per row read its 4.32 M samples in a rolled
+// loop, one load and one wait per trip: 7.4 ms per call, 59 % of the production window, until round 4); the loads go
+// out in batches of 8 and are consumed in order, the partial sums are combined in fixed order by k_seg_stats_fin.
 constexpr int kSegParts = 128;
-__global__ __launch_bounds__(256) void k_seg_stats(const float* const* __restrict__ xs, const float* const* __restrict__ ys,
-                                                    long n, int flags, const double* __restrict__ st /*[rows][4]: mx, my, sxx, syy*/,
-                                                    double* __restrict__ part /*[rows][kSegParts][2]*/, int phase) {
-  __shared__ double red[2][256];
-  const int r = blockIdx.y, tid = threadIdx.x;
-  const float* __restrict__ x = xs[r];
-  const float* __restrict__ y = ys[r];
+__global__ __launch_bounds__(256) void k_seg_stats(const float* const* __restrict__ ptrs, long n, int flags,
+                                                    const double* __restrict__ su, double* __restrict__ part /*[nu][kSegParts]*/,
+                                                    int phase) {
+  __shared__ double red[256];
+  const int u = blockIdx.y, tid = threadIdx.x;
+  const float* __restrict__ x = ptrs[u];
   const long per = (n + kSegParts - 1) / kSegParts;
   const long lo = (long)blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
-  double a = 0.0, b = 0.0;
-  const double mx = phase ? st[4 * r] : 0.0, my = phase ? st[4 * r + 1] : 0.0;
+  double a = 0.0;
+  const double mx = phase ? su[2 * u] : 0.0;
   const bool ob = flags & XCX_F_ONEBIT;
-  auto take = [&](float xf, float yf) {
-    if (phase == 0) { a += (double)xf; b += (double)yf; return; }
-    double u = (double)xf - mx, v = (double)yf - my;
-    if (ob) { u = (u > 0.0) ? 1.0 : ((u < 0.0) ? -1.0 : 0.0); v = (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : 0.0); }
-    else { u = (double)(float)u; v = (double)(float)v; }      // the windows are transformed as float32
-    a += u * u; b += v * v;
+  auto take = [&](float xf) {
+    if (phase == 0) { a += (double)xf; return; }
+    double v = (double)xf - mx;
+    if (ob) v = (v > 0.0) ? 1.0 : ((v < 0.0) ? -1.0 : 0.0);
+    else v = (double)(float)v;                                 // the windows are transformed as float32
+    a += v * v;
   };
   if (phase == 1 || (flags & XCX_F_DEMEAN)) {
     constexpr int U = 8;
     long i = lo + tid;
     for (; i + (U - 1) * 256 < hi; i += U * 256) {
-      float xv[U], yv[U];
+      float xv[U];
 #pragma unroll
-      for (int k = 0; k < U; ++k) { xv[k] = x[i + k * 256]; yv[k] = y[i + k * 256]; }
+      for (int k = 0; k < U; ++k) xv[k] = x[i + k * 256];
 #pragma unroll
-      for (int k = 0; k < U; ++k) take(xv[k], yv[k]);
+      for (int k = 0; k < U; ++k) take(xv[k]);
     }
-    for (; i < hi; i += 256) take(x[i], y[i]);
+    for (; i < hi; i += 256) take(x[i]);
   }
-  red[0][tid] = a; red[1][tid] = b;
+  red[tid] = a;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
-    if (tid < o) { red[0][tid] += red[0][tid + o]; red[1][tid] += red[1][tid + o]; }
+    if (tid < o) red[tid] += red[tid + o];
     __syncthreads();
   }
-  if (tid == 0) {
-    part[((size_t)r * kSegParts + blockIdx.x) * 2] = red[0][0];
-    part[((size_t)r * kSegParts + blockIdx.x) * 2 + 1] = red[1][0];
-  }
+  if (tid == 0) part[(size_t)u * kSegParts + blockIdx.x] = red[0];
 }
-__global__ void k_seg_stats_fin(const double* __restrict__ part, long n, double* __restrict__ st, int rows, int phase) {
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
-  double a = 0.0, b = 0.0;
-  for (int p = 0; p < kSegParts; ++p) { a += part[((size_t)r * kSegParts + p) * 2]; b += part[((size_t)r * kSegParts + p) * 2 + 1]; }
-  if (phase == 0) { st[4 * r] = a / (double)n; st[4 * r + 1] = b / (double)n; }
-  else { st[4 * r + 2] = a; st[4 * r + 3] = b; }
+__global__ void k_seg_stats_fin(const double* __restrict__ part, long n, double* __restrict__ su, int nu, int phase) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= nu) return;
+  double a = 0.0;
+  for (int p = 0; p < kSegParts; ++p) a += part[(size_t)u * kSegParts + p];
+  if (phase == 0) su[2 * u] = a / (double)n;
+  else su[2 * u + 1] = a;
 }
 
 // Distinct-segment form (round 4).  With Bk = 2 Kb the window of station A_c and block beta starts at sample
-// k0 + (2 beta + c) Kb: it depends on s = 2 beta + c only, so the nb x nc windows of the old layout are 2 nb - 2 + nc
-// DISTINCT segments (64 instead of 432 for the production window).  Per row: NS = 2 nb - 2 + nc segments
-// a[k0 + s Kb + i], i < npr, followed by the nb blocks of b (Bk samples, zero beyond) = W = NS + nb windows of one
-// "station"; every window is transformed ONCE and k_seg_gram forms  G_c[k] = sum_beta A[2 beta + c][k] conj(B[beta][k]).
-__global__ __launch_bounds__(256) void k_seg_gather2(const float* const* __restrict__ as, const float* const* __restrict__ bs,
-                                                      const double* __restrict__ st, int swap, long n, int flags,
-                                                      int Bk, int Kb, int NS, int nb, long k0, float* __restrict__ dst) {
-  const int npr = Bk + Kb;
-  const int w = blockIdx.y, r = blockIdx.z, W = NS + nb;
-  const double ma = st[4 * r + (swap ? 1 : 0)], mb = st[4 * r + (swap ? 0 : 1)];
+// k0 + (2 beta + c) Kb: it depends on s = 2 beta + c only, so the nb x nc windows of the old layout are
+// NS = 2 nb - 2 + nc DISTINCT segments (64 instead of 432 for the production window).  And they depend on the window
+// they are cut from, not on the row: rows (pairs) that share a window share its spectra.  Per chunk of rows:
+//   k_seg_gather : for every distinct a-window NS segments a[k0 + s Kb + i], i < npr; for every distinct b-window
+//                  nb blocks of Bk samples (zero beyond) -- each transformed ONCE
+//   k_seg_gram   : G_c[k] = sum_beta A[ia(r)][2 beta + c][k] conj(B[ib(r)][beta][k])  for row r
+// windows: (ids, nwin) -> dst[(v nwin + w)][npr], sample base0 + w * wstride + i for i < len (zero beyond, and beyond n)
+__global__ __launch_bounds__(256) void k_seg_gather(const float* const* __restrict__ ptrs, const double* __restrict__ su,
+                                                     const int* __restrict__ ids, long n, int flags, int npr, int nwin,
+                                                     long base0, long wstride, int len, float* __restrict__ dst) {
+  const int w = blockIdx.y, v = blockIdx.z;
+  const int u = ids[v];
+  const float* __restrict__ src = ptrs[u];
+  const double m = su[2 * u];
   const bool ob = flags & XCX_F_ONEBIT;
-  float* __restrict__ d = dst + ((size_t)r * W + w) * (size_t)npr;
-  const bool isa = w < NS;
-  const float* __restrict__ src = isa ? as[r] : bs[r];
-  const long base = isa ? k0 + (long)w * Kb : (long)(w - NS) * Bk;
-  const int len = isa ? npr : Bk;
-  const double m = isa ? ma : mb;
+  float* __restrict__ d = dst + ((size_t)v * nwin + w) * (size_t)npr;
+  const long base = base0 + (long)w * wstride;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < npr; i += gridDim.x * 256) {
     const long j = base + i;
     const bool in = i < len && j < n;
     const float x = src[in ? j : 0];                 // unconditional load, then a select (no branch around the load)
-    const double u = (double)x - m;
-    const float v = ob ? ((u > 0.0) ? 1.f : ((u < 0.0) ? -1.f : 0.f)) : (float)u;
-    d[i] = in ? v : 0.f;
+    const double uu = (double)x - m;
+    const float val = ob ? ((uu > 0.0) ? 1.f : ((uu < 0.0) ? -1.f : 0.f)) : (float)uu;
+    d[i] = in ? val : 0.f;
   }
 }
 
-// C[(r nc + c)][k] = sum_beta X[r W + 2 beta + c][k] conj(X[r W + NS + beta][k]); one frequency per lane (512-byte
-// runs per wave load), kSG chunks per workgroup pass over beta; the repeated A loads of neighbouring beta are cache hits
+// C[(r nc + c)][k] = sum_beta X[ia[r] NS + 2 beta + c][k] conj(X[slotB + ib[r] nb + beta][k]); one frequency per lane
+// (512-byte runs per wave load), kSG chunks per workgroup pass over beta; the repeated A loads of neighbouring beta are
+// cache hits
 constexpr int kSG = 6;
 __global__ __launch_bounds__(256) void k_seg_gram(const cf* __restrict__ X, size_t pitch, int nfreq, int NS, int nb, int nc,
+                                                   size_t slotB, const int* __restrict__ ia, const int* __restrict__ ib,
                                                    cf* __restrict__ C) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= nfreq) return;
-  const int c0 = blockIdx.y * kSG, r = blockIdx.z, W = NS + nb;
-  const cf* __restrict__ Xa = X + (size_t)r * W * pitch + k;
-  const cf* __restrict__ Xb = Xa + (size_t)NS * pitch;
+  const int c0 = blockIdx.y * kSG, r = blockIdx.z;
+  const cf* __restrict__ Xa = X + (size_t)ia[r] * NS * pitch + k;
+  const cf* __restrict__ Xb = X + (slotB + (size_t)ib[r] * nb) * pitch + k;
   cf acc[kSG];
 #pragma unroll
   for (int j = 0; j < kSG; ++j) acc[j] = make_float2(0.f, 0.f);
@@ -1670,12 +1670,13 @@ __global__ __launch_bounds__(256) void k_seg_gram(const cf* __restrict__ X, size
 }
 
 // sub[(r*nc + c)][k'] -> out[r][...]: lag k = k0 + (c0+c) Kb + k' (sign -1 for the exchanged roles)
-__global__ __launch_bounds__(256) void k_seg_scatter(const float* __restrict__ sub, const double* __restrict__ st, int flags,
+__global__ __launch_bounds__(256) void k_seg_scatter(const float* __restrict__ sub, const double* __restrict__ su,
+                                                      const int* __restrict__ rx, const int* __restrict__ ry, int flags,
                                                       long n, int Kb, int nc, int c0, long k0, long kend /*exclusive*/,
                                                       int sign, long idx_min, long L, float* __restrict__ out, long ld_out) {
   const int r = blockIdx.z, c = blockIdx.y;
   double scale = 1.0;
-  if (flags & XCX_F_NORMALIZE) scale = 1.0 / (sqrt(st[4 * r + 2]) * sqrt(st[4 * r + 3]));
+  if (flags & XCX_F_NORMALIZE) scale = 1.0 / (sqrt(su[2 * rx[r] + 1]) * sqrt(su[2 * ry[r] + 1]));
   const float* __restrict__ srow = sub + ((size_t)r * nc + c) * (size_t)Kb;
   for (int kk = blockIdx.x * 256 + threadIdx.x; kk < Kb; kk += gridDim.x * 256) {
     const long k = k0 + (long)(c0 + c) * Kb + kk;
@@ -1730,21 +1731,35 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
   const int nb = (int)((n + Bk - 1) / Bk);
   const long lmin = (long)g.idx_min - (n - 1), lmax = (long)g.idx_max - 1 - (n - 1);   // retained lags, inclusive
   int rc;
-  if ((rc = sg.ptrs.ensure(ctx, sizeof(float*) * 2 * (size_t)rows))) return rc;
-  if ((rc = sg.stats.ensure(ctx, sizeof(double) * (4 + 2 * kSegParts) * (size_t)rows))) return rc;   // totals, then partial sums
-  HIP_TRY(hipMemcpyAsync(sg.ptrs.ptr, xs_h, sizeof(float*) * rows, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipMemcpyAsync((const float**)sg.ptrs.ptr + rows, ys_h, sizeof(float*) * rows, hipMemcpyHostToDevice, ctx->stream));
-  HIP_TRY(hipStreamSynchronize(ctx->stream));                 // xs_h / ys_h may be stack arrays of the caller
-  const float* const* dxs = (const float* const*)sg.ptrs.ptr;
-  const float* const* dys = dxs + rows;
-  double* st = (double*)sg.stats.ptr;
-  HIP_TRY(hipMemsetAsync(st, 0, sizeof(double) * 4 * (size_t)rows, ctx->stream));
-  double* part = st + 4 * (size_t)rows;
+  // the distinct windows of the call: statistics and transforms belong to a window, not to a row
+  std::vector<const float*> uptr;
+  std::vector<int> ix(rows), iy(rows);
+  {
+    std::unordered_map<const float*, int> id;
+    auto get = [&](const float* q) {
+      auto it = id.find(q);
+      if (it != id.end()) return it->second;
+      const int k = (int)uptr.size();
+      id.emplace(q, k); uptr.push_back(q);
+      return k;
+    };
+    for (int r = 0; r < rows; ++r) { ix[r] = get(xs_h[r]); iy[r] = get(ys_h[r]); }
+  }
+  const int nu = (int)uptr.size();
+  if ((rc = upload(ctx, sg.ptrs, uptr.data(), sizeof(float*) * (size_t)nu))) return rc;
+  if ((rc = sg.stats.ensure(ctx, sizeof(double) * (2 + kSegParts) * (size_t)nu))) return rc;   // totals, then partial sums
+  const float* const* dptr = (const float* const*)sg.ptrs.ptr;
+  double* su = (double*)sg.stats.ptr;
+  HIP_TRY(hipMemsetAsync(su, 0, sizeof(double) * 2 * (size_t)nu, ctx->stream));
+  double* part = su + 2 * (size_t)nu;
   for (int phase = 0; phase < ((g.flags & XCX_F_NORMALIZE) ? 2 : 1); ++phase) {
-    hipLaunchKernelGGL(k_seg_stats, dim3(kSegParts, rows), dim3(256), 0, ctx->stream, dxs, dys, n, g.flags, (const double*)st, part, phase);
-    hipLaunchKernelGGL(k_seg_stats_fin, dim3((rows + 63) / 64), dim3(64), 0, ctx->stream, (const double*)part, n, st, rows, phase);
+    hipLaunchKernelGGL(k_seg_stats, dim3(kSegParts, nu), dim3(256), 0, ctx->stream, dptr, n, g.flags, (const double*)su, part, phase);
+    hipLaunchKernelGGL(k_seg_stats_fin, dim3((nu + 63) / 64), dim3(64), 0, ctx->stream, (const double*)part, n, su, nu, phase);
   }
   HIP_TRY(hipGetLastError());
+  xcx_plan* sub = sg.sub;
+  const size_t pitch = sub->spec_pitch;
+  const int nfreq = sub->g.N1 * (sub->g.N2h + 1);
   // two passes: non-negative lags (a = x, b = y), then negative lags (a = y, b = x, lags 1..-lmin)
   for (int pass = 0; pass < 2; ++pass) {
     long k0, kend;            // lags [k0, kend) of C[k] = sum a[t+k] b[t]
@@ -1752,29 +1767,66 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
     else { k0 = std::max<long>(1, -lmax); kend = -lmin + 1; }
     if (kend <= k0) continue;
     const int nchunks = (int)((kend - k0 + Kb - 1) / Kb);
-    const float* const* as = pass == 0 ? dxs : dys;
-    const float* const* bs = pass == 0 ? dys : dxs;
-    // every distinct segment of a and every block of b is transformed once (k_seg_gather2 / k_seg_gram above)
-    xcx_plan* sub = sg.sub;
-    const int NS = 2 * nb - 2 + nchunks, W = NS + nb;
-    const size_t pitch = sub->spec_pitch;
-    const size_t per_row = (size_t)W * ((size_t)npr * sizeof(float) + pitch * sizeof(cf)) +
-                           (size_t)nchunks * (pitch * sizeof(cf) + (size_t)Kb * sizeof(float));
-    const int rper = (int)std::max<size_t>(1, std::min<size_t>((size_t)rows, ((size_t)6 << 30) / per_row));
-    for (int r0 = 0; r0 < rows; r0 += rper) {
-      const int rr = std::min(rper, rows - r0);
+    const std::vector<int>& ida = pass == 0 ? ix : iy;
+    const std::vector<int>& idb = pass == 0 ? iy : ix;
+    const int NS = 2 * nb - 2 + nchunks;
+    // bytes per distinct a-window (NS segments: samples + spectra), per distinct b-window (nb blocks), per row
+    // (nchunks cross-spectra + Kb lags each)
+    const size_t per_win = (size_t)npr * sizeof(float) + pitch * sizeof(cf);
+    const size_t per_a = (size_t)NS * per_win, per_b = (size_t)nb * per_win;
+    const size_t per_row = (size_t)nchunks * (pitch * sizeof(cf) + (size_t)Kb * sizeof(float));
+    const size_t budget = (size_t)16 << 30;
+    std::vector<int> ua, ub, ia, ib, ints;
+    std::unordered_map<int, int> posa, posb;
+    for (int r0 = 0; r0 < rows;) {
+      // rows of the chunk: as many as fit the budget with their distinct windows (at most 1024: grid limit margin)
+      ua.clear(); ub.clear(); ia.clear(); ib.clear(); posa.clear(); posb.clear();
+      int rr = 0;
+      size_t bytes = 0;
+      while (r0 + rr < rows && rr < 1024) {
+        const int a = ida[r0 + rr], b = idb[r0 + rr];
+        const size_t add = per_row + (posa.count(a) ? 0 : per_a) + (posb.count(b) ? 0 : per_b);
+        if (rr > 0 && bytes + add > budget) break;
+        bytes += add;
+        if (!posa.count(a)) { posa.emplace(a, (int)ua.size()); ua.push_back(a); }
+        if (!posb.count(b)) { posb.emplace(b, (int)ub.size()); ub.push_back(b); }
+        ia.push_back(posa[a]); ib.push_back(posb[b]);
+        ++rr;
+      }
+      const int na = (int)ua.size(), nbw = (int)ub.size();
       const int P = rr * nchunks;
-      if ((rc = sg.segbuf.ensure(ctx, sizeof(float) * (size_t)rr * W * npr))) return rc;
+      const size_t slotB = (size_t)na * NS, slots = slotB + (size_t)nbw * nb;
+      if ((rc = sg.segbuf.ensure(ctx, sizeof(float) * slots * npr))) return rc;
       if ((rc = sg.subout.ensure(ctx, sizeof(float) * (size_t)P * Kb))) return rc;
-      if ((rc = sub->spectra.ensure(ctx, sizeof(cf) * pitch * (size_t)rr * W))) return rc;
+      if ((rc = sub->spectra.ensure(ctx, sizeof(cf) * pitch * slots))) return rc;
       if ((rc = sub->gramC.ensure(ctx, sizeof(cf) * pitch * (size_t)P))) return rc;
-      hipLaunchKernelGGL(k_seg_gather2, dim3(std::min(64, (npr + 255) / 256), W, rr), dim3(256), 0, ctx->stream,
-                         as + r0, bs + r0, st + 4 * (size_t)r0, pass, n, g.flags, Bk, Kb, NS, nb, k0, (float*)sg.segbuf.ptr);
+      // int tables of the chunk in one upload: [ua | ub | ia | ib | rx | ry]
+      ints.clear();
+      ints.insert(ints.end(), ua.begin(), ua.end());
+      ints.insert(ints.end(), ub.begin(), ub.end());
+      ints.insert(ints.end(), ia.begin(), ia.end());
+      ints.insert(ints.end(), ib.begin(), ib.end());
+      ints.insert(ints.end(), ix.begin() + r0, ix.begin() + r0 + rr);
+      ints.insert(ints.end(), iy.begin() + r0, iy.begin() + r0 + rr);
+      if ((rc = upload(ctx, sg.pairs, ints.data(), sizeof(int) * ints.size()))) return rc;
+      const int* d_ua = (const int*)sg.pairs.ptr;
+      const int* d_ub = d_ua + na;
+      const int* d_ia = d_ub + nbw;
+      const int* d_ib = d_ia + rr;
+      const int* d_rx = d_ib + rr;
+      const int* d_ry = d_rx + rr;
+      float* segA = (float*)sg.segbuf.ptr;
+      float* segB = segA + slotB * npr;
+      const unsigned gx = (unsigned)std::min(64, (npr + 255) / 256);
+      hipLaunchKernelGGL(k_seg_gather, dim3(gx, NS, na), dim3(256), 0, ctx->stream, dptr, (const double*)su, d_ua, n, g.flags,
+                         npr, NS, k0, (long)Kb, npr, segA);
+      hipLaunchKernelGGL(k_seg_gather, dim3(gx, nb, nbw), dim3(256), 0, ctx->stream, dptr, (const double*)su, d_ub, n, g.flags,
+                         npr, nb, 0L, (long)Bk, Bk, segB);
       HIP_TRY(hipGetLastError());
-      if ((rc = forward(sub, (const float*)sg.segbuf.ptr, (long)W * npr, npr, W, 0, 0, rr * W, 0))) return rc;
-      const int nfreq = sub->g.N1 * (sub->g.N2h + 1);
+      if ((rc = forward(sub, segA, (long)NS * npr, npr, NS, 0, 0, na * NS, 0))) return rc;
+      if ((rc = forward(sub, segB, (long)nb * npr, npr, nb, 0, 0, nbw * nb, (int)slotB))) return rc;
       hipLaunchKernelGGL(k_seg_gram, dim3((nfreq + 255) / 256, (nchunks + kSG - 1) / kSG, rr), dim3(256), 0, ctx->stream,
-                         (const cf*)sub->spectra.ptr, pitch, nfreq, NS, nb, nchunks, (cf*)sub->gramC.ptr);
+                         (const cf*)sub->spectra.ptr, pitch, nfreq, NS, nb, nchunks, slotB, d_ia, d_ib, (cf*)sub->gramC.ptr);
       HIP_TRY(hipGetLastError());
       // one inverse per (row, chunk): descriptor q reads row q of the cross-spectrum buffer, writes Kb lags at q Kb
       sub->hdescs.resize(P);
@@ -1783,9 +1835,10 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
       if ((rc = upload(ctx, sub->descs, sub->hdescs.data(), (size_t)P * sizeof(PwDesc)))) return rc;
       if ((rc = stack_inverse(sub, P, (float*)sg.subout.ptr))) return rc;
       hipLaunchKernelGGL(k_seg_scatter, dim3(std::min(64, (Kb + 255) / 256), nchunks, rr), dim3(256), 0, ctx->stream,
-                         (const float*)sg.subout.ptr, st + 4 * (size_t)r0, g.flags, n, Kb, nchunks, 0, k0, kend,
+                         (const float*)sg.subout.ptr, (const double*)su, d_rx, d_ry, g.flags, n, Kb, nchunks, 0, k0, kend,
                          pass == 0 ? 1 : -1, (long)g.idx_min, L, out + (size_t)r0 * ld_out, ld_out);
       HIP_TRY(hipGetLastError());
+      r0 += rr;
     }
   }
   return XCX_OK;
