@@ -273,7 +273,8 @@ def test_post_prep_is_bitwise_the_three_ops(ctx):
     """xcx_post_prep (fused unbias -> demean -> taper, f1) == xcx_unbias + xcx_demean + xcx_taper, bit for bit,
     on full and clipped lag slices, device and host rows."""
     rng = np.random.default_rng(31)
-    for npts, imin, imax, nmax in ((3000, 0, 5999, 250), (3000, 1000, 4500, 75), (500, 499, 999, 10), (2000, 0, 3999, 0)):
+    for npts, imin, imax, nmax in ((3000, 0, 5999, 250), (3000, 1000, 4500, 75), (500, 499, 999, 10), (2000, 0, 3999, 0),
+                                   (40000, 0, 79999, 250), (50000, 1000, 90001, 75)):      # the last two: rows split over workgroups
         L = imax - imin
         x = (rng.standard_normal((7, L)) * 0.01 + 0.003).astype(np.float32)
         ref = ops.unbias(ctx, x, npts, imin, imax)

@@ -294,6 +294,62 @@ __global__ __launch_bounds__(NT) void k_post_prep(float* __restrict__ x, long L,
   });
 }
 
+// The same for few long rows (the production lag axis: 1.62 M lags per row): the row split over kParts workgroups
+// exactly like k_row_partial / k_row_apply of xcx_demean (same slices, same order of the float64 sums), so that the
+// result stays bit-identical to xcx_unbias + xcx_demean + xcx_taper there too.  One workgroup per row read such a
+// row at 0.7 TB/s.
+__global__ __launch_bounds__(NT) void k_post_partial(const float* __restrict__ x, long L, long npts, long idx_min, int do_unbias,
+                                                      double* __restrict__ part) {
+  __shared__ double red[NT];
+  const float* __restrict__ row = x + (size_t)blockIdx.y * L;
+  const int tid = threadIdx.x;
+  const long per = ((L + kParts - 1) / kParts + 3) & ~3L;
+  const long lo = blockIdx.x * per, hi = (lo + per < L) ? lo + per : L;
+  auto unb = [=](long o, float v) -> float {
+    if (!do_unbias) return v;
+    long lag = idx_min + o - (npts - 1);
+    if (lag < 0) lag = -lag;
+    return v * (float)((double)npts / (double)(npts - lag));
+  };
+  double a0 = 0.0;
+  long i0 = lo;
+  if ((reinterpret_cast<unsigned long long>(row) & 15ULL) == 0) {
+    const long nv = (hi > lo) ? (hi - lo) / 4 : 0;
+    for (long q = tid; q < nv; q += NT) {
+      const long i = lo + 4 * q;
+      const float4 v = *reinterpret_cast<const float4*>(row + i);
+      a0 += (double)unb(i, v.x); a0 += (double)unb(i + 1, v.y); a0 += (double)unb(i + 2, v.z); a0 += (double)unb(i + 3, v.w);
+    }
+    i0 = lo + 4 * nv;
+  }
+  for (long i = i0 + tid; i < hi; i += NT) a0 += (double)unb(i, row[i]);
+  a0 = block_sum(a0, red);
+  if (tid == 0) {
+    part[((size_t)blockIdx.y * kParts + blockIdx.x) * 2] = a0;
+    part[((size_t)blockIdx.y * kParts + blockIdx.x) * 2 + 1] = 0.0;
+  }
+}
+__global__ __launch_bounds__(NT) void k_post_apply(float* __restrict__ x, long L, long npts, long idx_min, long nmax, int wtype,
+                                                    int do_unbias, const double* __restrict__ part) {
+  float* __restrict__ row = x + (size_t)blockIdx.y * L;
+  const long per = (L + kParts - 1) / kParts;
+  const long lo = blockIdx.x * per, hi = (lo + per < L) ? lo + per : L;
+  double s0 = 0.0;
+  for (int p = 0; p < kParts; ++p) s0 += part[((size_t)blockIdx.y * kParts + p) * 2];
+  const float mean = (float)(s0 / (double)L);
+  row_update(row, row, lo, hi, [=](long i, float x0) {
+    float v = x0;
+    if (do_unbias) {
+      long lag = idx_min + i - (npts - 1);
+      if (lag < 0) lag = -lag;
+      v = v * (float)((double)npts / (double)(npts - lag));
+    }
+    v = v - mean;
+    if (nmax > 0 && (i < nmax || i >= L - nmax)) v = v * taper_weight(i, L, nmax, wtype);
+    return v;
+  });
+}
+
 __global__ void k_onebit(float* __restrict__ x, long total) {
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long)gridDim.x * blockDim.x) {
@@ -520,6 +576,16 @@ extern "C" int xcx_post_prep(xcx_ctx* ctx, float* x, long batch, long npts, long
   Staged st;
   int rc = st.begin(ctx, x, (size_t)batch * L * sizeof(float), on_device);
   if (rc) return rc;
+  if (batch < 1024 && L >= 65536) {          // few long rows: split like xcx_demean does (same sums, bit for bit)
+    if ((rc = ctx->scratch[0].ensure(ctx, sizeof(double) * 2 * kParts * (size_t)batch))) return rc;
+    double* part = (double*)ctx->scratch[0].ptr;
+    hipLaunchKernelGGL(k_post_partial, dim3(kParts, (unsigned)batch), dim3(NT), 0, ctx->stream, (const float*)st.dev, L, npts,
+                       idx_min, unbias, part);
+    hipLaunchKernelGGL(k_post_apply, dim3(kParts, (unsigned)batch), dim3(NT), 0, ctx->stream, st.dev, L, npts, idx_min,
+                       taper_nmax, wtype, unbias, (const double*)part);
+    HIP_TRY(hipGetLastError());
+    return st.end();
+  }
   hipLaunchKernelGGL(k_post_prep, dim3((unsigned)batch), dim3(NT), 0, ctx->stream, st.dev, L, npts, idx_min, taper_nmax,
                      wtype, unbias);
   HIP_TRY(hipGetLastError());
