@@ -38,7 +38,7 @@ int xcx_internal_forward(xcx_plan* p, const float* traces, long stride_s, long s
 int xcx_internal_pairs(xcx_plan* p, const PwDesc* hdesc, int count, float* out);
 int xcx_internal_spectra(xcx_plan* p, size_t slots);
 bool xcx_internal_segmented(xcx_plan* p);
-int xcx_internal_seg_rows(xcx_plan* p, const float* const* xs, const float* const* ys, int count, float* out, long ld);
+int xcx_internal_seg_conv(xcx_plan* p, const float* const* xs, const float* const* ks, int count, float* out, long ld);
 
 namespace {
 
@@ -161,12 +161,14 @@ static int timeshift_rows(xcx_ctx* ctx, const float* x, float* y, long batch, lo
   const bool direct = ctx->ts_direct;
   const long L = 2 * n - 1;
   const long ld = (L + 31) / 32 * 32;
-  const int kRows = n > 400000 ? 16 : 256;            // rows per launch group: bounded workspace for long rows; 128 -> 256 measured -5 % (launch tails)
+  const int kRows = n > 400000 ? 64 : 256;            // rows per launch group: bounded workspace for long rows; 128 -> 256 measured -5 % (launch tails)
   DevBuf &hr = ctx->scratch[1], &lin = ctx->scratch[2], &dal = ctx->scratch[3], &dx = ctx->scratch[4],
          &dy = ctx->scratch[5];
   const int chunk = (int)std::min<long>(kRows, batch);
-  if ((rc = hr.ensure(ctx, sizeof(float) * (direct ? L : n) * chunk))) return rc;
-  if (!direct && (rc = lin.ensure(ctx, sizeof(float) * ld * chunk))) return rc;
+  const bool seg = xcx_internal_segmented(plan);     // rows longer than one transform: block decomposition
+  const bool two = direct || seg;                    // kernels of two periods: the n retained lags are the convolution itself
+  if ((rc = hr.ensure(ctx, sizeof(float) * (two ? L : n) * chunk))) return rc;
+  if (!two && (rc = lin.ensure(ctx, sizeof(float) * ld * chunk))) return rc;
   if ((rc = dal.ensure(ctx, sizeof(double) * batch))) return rc;
   HIP_TRY(hipMemcpyAsync(dal.ptr, alpha.data(), sizeof(double) * batch, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -181,7 +183,6 @@ static int timeshift_rows(xcx_ctx* ctx, const float* x, float* y, long batch, lo
     xd = (const float*)dx.ptr;
     yd = (float*)dy.ptr;
   }
-  const bool seg = xcx_internal_segmented(plan);     // rows longer than one transform: block decomposition
   if (!seg && (rc = xcx_internal_spectra(plan, 2 * (size_t)chunk))) return rc;
   std::vector<PwDesc> d(chunk);
   std::vector<const float*> xs(chunk), ys(chunk);
@@ -209,7 +210,7 @@ static int timeshift_rows(xcx_ctx* ctx, const float* x, float* y, long batch, lo
     const dim3 grid((unsigned)((n + 255) / 256), (unsigned)cnt);
     const dim3 kgrid((unsigned)((n + 256 * kDK - 1) / (256 * kDK)), (unsigned)nk);
     hipLaunchKernelGGL(k_dirichlet, kgrid, dim3(256), 0, ctx->stream, (float*)hr.ptr, n, (long)nk,
-                       (const double*)dal.ptr + r0, direct ? 1 : 0);
+                       (const double*)dal.ptr + r0, two ? 1 : 0);
     HIP_TRY(hipGetLastError());
     if (direct) {
       if ((rc = xcx_internal_forward(plan, xd + r0 * size, size, 0, 1, 0, 0, cnt, 0, (int)n))) return rc;
@@ -223,8 +224,16 @@ static int timeshift_rows(xcx_ctx* ctx, const float* x, float* y, long batch, lo
       continue;
     }
     if (seg) {
-      for (int i = 0; i < cnt; ++i) { xs[i] = xd + (r0 + i) * size; ys[i] = (const float*)hr.ptr + (long)ukern[i] * n; }
-      if ((rc = xcx_internal_seg_rows(plan, xs.data(), ys.data(), cnt, (float*)lin.ptr, ld))) return rc;
+      // block-decomposed convolution with the two-period kernel in the segment role: one pass, the n values written
+      // in place (rows that share a delay share the kernel's segment transforms; before round 4: both lag signs
+      // against one period, 2n - 1 lags, then a fold)
+      for (int i = 0; i < cnt; ++i) { xs[i] = xd + (r0 + i) * size; ys[i] = (const float*)hr.ptr + (long)ukern[i] * L; }
+      if ((rc = xcx_internal_seg_conv(plan, xs.data(), ys.data(), cnt, yd + r0 * n, n))) return rc;
+      if (modulate) {
+        hipLaunchKernelGGL(k_modulate, grid, dim3(256), 0, ctx->stream, yd + r0 * n, n, (long)cnt);
+        HIP_TRY(hipGetLastError());
+      }
+      continue;
     } else {
       if ((rc = xcx_internal_forward(plan, xd + r0 * size, size, 0, 1, 0, 0, cnt, 0, 0))) return rc;
       if ((rc = xcx_internal_forward(plan, (const float*)hr.ptr, n, 0, 1, 0, 0, nk, cnt, 0))) return rc;

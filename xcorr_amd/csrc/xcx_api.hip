@@ -405,7 +405,8 @@ static int upload(xcx_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
 }
 
 static int seg_plan_create(xcx_ctx* ctx, int n, int idx_min, int idx_max, int flags, xcx_plan** out);
-static int seg_run(xcx_plan* p, const float* const* xs, const float* const* ys, int rows, float* out, long ld_out);
+static int seg_run(xcx_plan* p, const float* const* xs, const float* const* ys, int rows, float* out, long ld_out,
+                   long conv_len = 0);
 
 extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
                              int idx_max, int flags, xcx_plan** out) {
@@ -1523,8 +1524,9 @@ int xcx_internal_spectra(xcx_plan* p, size_t slots) {
 xcx_ctx* xcx_internal_ctx(xcx_plan* p) { return p->ctx; }
 // long windows (block decomposition): device row pointers x[i], y[i] -> out + i*ld
 bool xcx_internal_segmented(xcx_plan* p) { return p->seg != nullptr; }
-int xcx_internal_seg_rows(xcx_plan* p, const float* const* xs, const float* const* ys, int count, float* out, long ld) {
-  return seg_run(p, xs, ys, count, out, ld);
+// circular convolution of rows xs (n samples) with two-period kernels ks (2n - 1 samples): see seg_run(conv_len)
+int xcx_internal_seg_conv(xcx_plan* p, const float* const* xs, const float* const* ks, int count, float* out, long ld) {
+  return seg_run(p, xs, ks, count, out, ld, 2L * p->g.n - 1);
 }
 
 #ifdef XCX_STAMPS
@@ -1609,13 +1611,15 @@ __global__ void k_seg_stats_fin(const double* __restrict__ part, long n, double*
   else su[2 * u + 1] = a;
 }
 
-// Distinct-segment form (round 4).  With Bk = 2 Kb the window of station A_c and block beta starts at sample
-// k0 + (2 beta + c) Kb: it depends on s = 2 beta + c only, so the nb x nc windows of the old layout are
-// NS = 2 nb - 2 + nc DISTINCT segments (64 instead of 432 for the production window).  And they depend on the window
-// they are cut from, not on the row: rows (pairs) that share a window share its spectra.  Per chunk of rows:
+// Distinct-segment form (round 4).  With Bk = Kb the window of chunk c and block beta starts at sample
+// k0 + (beta + c) Kb: it depends on s = beta + c only, so the nb x nc windows are NS = nb - 1 + nc DISTINCT segments
+// (32 instead of 216 for the production window).  And they depend on the window they are cut from, not on the row:
+// rows (pairs) that share a window share its spectra.  The block is the SHORT operand of the sub-plan (Bk samples of
+// N = Bk + Kb, lags -(Kb-1) .. 0 of (block, segment) retained: alias-free at N, kPlanShortOperand) -- before: the
+// generic rule N >= npr + Kb with Bk = 2 Kb = N/2, i.e. twice the inverse transforms per lag.  Per chunk of rows:
 //   k_seg_gather : for every distinct a-window NS segments a[k0 + s Kb + i], i < npr; for every distinct b-window
 //                  nb blocks of Bk samples (zero beyond) -- each transformed ONCE
-//   k_seg_gram   : G_c[k] = sum_beta A[ia(r)][2 beta + c][k] conj(B[ib(r)][beta][k])  for row r
+//   k_seg_gram   : G_c[k] = sum_beta B[ib(r)][beta][k] conj(A[ia(r)][beta + c][k])  for row r
 // windows: (ids, nwin) -> dst[(v nwin + w)][npr], sample base0 + w * wstride + i for i < len (zero beyond, and beyond n)
 __global__ __launch_bounds__(256) void k_seg_gather(const float* const* __restrict__ ptrs, const double* __restrict__ su,
                                                      const int* __restrict__ ids, long n, int flags, int npr, int nwin,
@@ -1637,39 +1641,58 @@ __global__ __launch_bounds__(256) void k_seg_gather(const float* const* __restri
   }
 }
 
-// C[(r nc + c)][k] = sum_beta X[ia[r] NS + 2 beta + c][k] conj(X[slotB + ib[r] nb + beta][k]); one frequency per lane
-// (512-byte runs per wave load), kSG chunks per workgroup pass over beta; the repeated A loads of neighbouring beta are
-// cache hits
-constexpr int kSG = 6;
+// C[(r nc + c)][k] = sum_beta X[slotB + ib[r] nb + beta][k] conj(X[ia[r] NS + beta + c][k]); one frequency per lane
+// (512-byte runs per wave load), SG chunks per workgroup.  The SG segments a block meets are a WINDOW of the segment
+// axis that slides by one per block: it lives in registers and ONE load per block refills it (2 loads per block and
+// SG products; the first form loaded every operand of every product: 7 loads per 6 products).
+template <int SG>
 __global__ __launch_bounds__(256) void k_seg_gram(const cf* __restrict__ X, size_t pitch, int nfreq, int NS, int nb, int nc,
                                                    size_t slotB, const int* __restrict__ ia, const int* __restrict__ ib,
                                                    cf* __restrict__ C) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= nfreq) return;
-  const int c0 = blockIdx.y * kSG, r = blockIdx.z;
-  const cf* __restrict__ Xa = X + (size_t)ia[r] * NS * pitch + k;
+  const int c0 = blockIdx.y * SG, r = blockIdx.z;
+  const cf* __restrict__ Xa = X + ((size_t)ia[r] * NS + c0) * pitch + k;
   const cf* __restrict__ Xb = X + (slotB + (size_t)ib[r] * nb) * pitch + k;
-  cf acc[kSG];
+  const int smax = NS - 1 - c0;                      // segments past the last one belong to chunks >= nc (not stored)
+  cf acc[SG], a[SG];
 #pragma unroll
-  for (int j = 0; j < kSG; ++j) acc[j] = make_float2(0.f, 0.f);
-#pragma unroll 4
+  for (int j = 0; j < SG; ++j) {
+    acc[j] = make_float2(0.f, 0.f);
+    a[j] = Xa[(size_t)min(j, smax) * pitch];
+  }
   for (int beta = 0; beta < nb; ++beta) {
     const cf b = Xb[(size_t)beta * pitch];
-    cf a[kSG];
+    const cf nx = Xa[(size_t)min(beta + SG, smax) * pitch];
 #pragma unroll
-    for (int j = 0; j < kSG; ++j) a[j] = Xa[(size_t)(2 * beta + min(c0 + j, nc - 1)) * pitch];
-#pragma unroll
-    for (int j = 0; j < kSG; ++j) {
-      acc[j].x += a[j].x * b.x + a[j].y * b.y;      // a conj(b)
-      acc[j].y += a[j].y * b.x - a[j].x * b.y;
+    for (int j = 0; j < SG; ++j) {
+      acc[j].x += b.x * a[j].x + b.y * a[j].y;      // b conj(a)
+      acc[j].y += b.y * a[j].x - b.x * a[j].y;
     }
+#pragma unroll
+    for (int j = 0; j + 1 < SG; ++j) a[j] = a[j + 1];
+    a[SG - 1] = nx;
   }
 #pragma unroll
-  for (int j = 0; j < kSG; ++j)
+  for (int j = 0; j < SG; ++j)
     if (c0 + j < nc) C[((size_t)r * nc + c0 + j) * pitch + k] = acc[j];
 }
+using SegGramFn = void (*)(const cf*, size_t, int, int, int, int, size_t, const int*, const int*, cf*);
+struct SegGramVar { int sg; SegGramFn fn; };
+static const SegGramVar kSegGram[] = {{3, k_seg_gram<3>}, {6, k_seg_gram<6>}, {9, k_seg_gram<9>}, {12, k_seg_gram<12>}};
+// fewest loads per row: groups x (SG + 2 nb); ties go to the wider window
+static const SegGramVar& seg_gram_pick(int nc, int nb) {
+  const SegGramVar* best = &kSegGram[0];
+  long bc = -1;
+  for (const SegGramVar& v : kSegGram) {
+    const long cost = (long)((nc + v.sg - 1) / v.sg) * (v.sg + 2L * nb);
+    if (bc < 0 || cost <= bc) { bc = cost; best = &v; }
+  }
+  return *best;
+}
 
-// sub[(r*nc + c)][k'] -> out[r][...]: lag k = k0 + (c0+c) Kb + k' (sign -1 for the exchanged roles)
+// sub[(r*nc + c)][Kb-1-k'] -> out[r][...]: lag k = k0 + (c0+c) Kb + k' (the sub-plan's lags run -(Kb-1) .. 0; sign -1 for
+// the exchanged roles)
 __global__ __launch_bounds__(256) void k_seg_scatter(const float* __restrict__ sub, const double* __restrict__ su,
                                                       const int* __restrict__ rx, const int* __restrict__ ry, int flags,
                                                       long n, int Kb, int nc, int c0, long k0, long kend /*exclusive*/,
@@ -1683,7 +1706,7 @@ __global__ __launch_bounds__(256) void k_seg_scatter(const float* __restrict__ s
     if (k >= kend) continue;
     const long j = (n - 1) + sign * k - idx_min;
     if (j < 0 || j >= L) continue;
-    double v = (double)srow[kk] * scale;
+    double v = (double)srow[Kb - 1 - kk] * scale;
     if (flags & XCX_F_UNBIAS) v *= (double)n / (double)(n - k);
     out[(size_t)r * ld_out + j] = (float)v;
   }
@@ -1702,7 +1725,7 @@ static int seg_plan_create(xcx_ctx* ctx, int n, int idx_min, int idx_max, int fl
   p->L = idx_max - idx_min;
   p->seg = new (std::nothrow) xcx_plan::Seg();
   if (!p->seg) { delete p; return set_err(XCX_ENOMEM, "host allocation failed"); }
-  // block geometry on the tuned transform N' = 368 640 = Bk + 2 Kb (XCX_SEG_N overrides)
+  // block geometry on the tuned transform N' = 368 640 = Bk + Kb, Bk = Kb (XCX_SEG_N overrides)
   long Np = 368640;
   if (const char* e = getenv("XCX_SEG_N")) {
     Np = atol(e);
@@ -1711,25 +1734,34 @@ static int seg_plan_create(xcx_ctx* ctx, int n, int idx_min, int idx_max, int fl
       return set_err(XCX_EINVAL, "XCX_SEG_N=%s: the block transform length must be a multiple of 4 and >= 4096", e);
     }
   }
-  p->seg->Kb = (int)(Np / 4);
+  p->seg->Kb = (int)(Np / 2);
   p->seg->Bk = (int)(Np / 2);
   p->seg->npr = p->seg->Bk + p->seg->Kb;
   const int npr = p->seg->npr;
-  int rc = xcx_plan_cc1d(ctx, npr, 0, npr - 1, npr - 1 + p->seg->Kb, XCX_F_STACK, &p->seg->sub);
+  // first operand = block (zero beyond Bk = idx_min samples), lags -(Kb-1) .. 0: no alias at N = npr
+  int rc = xcx_plan_cc1d(ctx, npr, 0, npr - p->seg->Kb, npr, XCX_F_STACK | kPlanShortOperand, &p->seg->sub);
   if (rc) { xcx_plan_destroy(p); return rc; }
   *out = p;
   return XCX_OK;
 }
 
 // all pointers are device pointers; out row r at out + r*ld_out, L floats
-static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys_h, int rows, float* out, long ld_out) {
+// conv_len > 0 (time shift of rows longer than one transform, timeshift.hip): ys are kernels of conv_len = 2n - 1 samples
+// (two periods), xs the rows of n samples; out[r][n - 1 - k] = sum_t ys[r][t + k] xs[r][t] for k in [0, n) -- ONE pass
+// with the kernel in the segment role, no statistics, no scaling: the n retained values are the circular convolution.
+static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys_h, int rows, float* out, long ld_out,
+                   long conv_len) {
   xcx_ctx* ctx = p->ctx;
   xcx_plan::Seg& sg = *p->seg;
   const Geom& g = p->g;
   const long n = g.n, L = p->L;
   const int Bk = sg.Bk, Kb = sg.Kb, npr = sg.npr;
   const int nb = (int)((n + Bk - 1) / Bk);
-  const long lmin = (long)g.idx_min - (n - 1), lmax = (long)g.idx_max - 1 - (n - 1);   // retained lags, inclusive
+  const bool conv = conv_len > 0;
+  const int flags = conv ? 0 : g.flags;
+  const long lmin = conv ? -(n - 1) : (long)g.idx_min - (n - 1);                        // retained lags, inclusive
+  const long lmax = conv ? 0 : (long)g.idx_max - 1 - (n - 1);
+  const long idx_min_eff = conv ? 0 : (long)g.idx_min, L_eff = conv ? n : L;
   int rc;
   // the distinct windows of the call: statistics and transforms belong to a window, not to a row
   std::vector<const float*> uptr;
@@ -1752,8 +1784,8 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
   double* su = (double*)sg.stats.ptr;
   HIP_TRY(hipMemsetAsync(su, 0, sizeof(double) * 2 * (size_t)nu, ctx->stream));
   double* part = su + 2 * (size_t)nu;
-  for (int phase = 0; phase < ((g.flags & XCX_F_NORMALIZE) ? 2 : 1); ++phase) {
-    hipLaunchKernelGGL(k_seg_stats, dim3(kSegParts, nu), dim3(256), 0, ctx->stream, dptr, n, g.flags, (const double*)su, part, phase);
+  for (int phase = 0; phase < (conv ? 0 : (flags & XCX_F_NORMALIZE) ? 2 : 1); ++phase) {
+    hipLaunchKernelGGL(k_seg_stats, dim3(kSegParts, nu), dim3(256), 0, ctx->stream, dptr, n, flags, (const double*)su, part, phase);
     hipLaunchKernelGGL(k_seg_stats_fin, dim3((nu + 63) / 64), dim3(64), 0, ctx->stream, (const double*)part, n, su, nu, phase);
   }
   HIP_TRY(hipGetLastError());
@@ -1765,11 +1797,15 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
     long k0, kend;            // lags [k0, kend) of C[k] = sum a[t+k] b[t]
     if (pass == 0) { k0 = std::max<long>(lmin, 0); kend = lmax + 1; }
     else { k0 = std::max<long>(1, -lmax); kend = -lmin + 1; }
+    if (conv) {                                   // lags 0 .. n-1 of (kernel, row), written at n - 1 - k
+      if (pass == 0) continue;
+      k0 = 0; kend = n;
+    }
     if (kend <= k0) continue;
     const int nchunks = (int)((kend - k0 + Kb - 1) / Kb);
     const std::vector<int>& ida = pass == 0 ? ix : iy;
     const std::vector<int>& idb = pass == 0 ? iy : ix;
-    const int NS = 2 * nb - 2 + nchunks;
+    const int NS = nb - 1 + nchunks;
     // bytes per distinct a-window (NS segments: samples + spectra), per distinct b-window (nb blocks), per row
     // (nchunks cross-spectra + Kb lags each)
     const size_t per_win = (size_t)npr * sizeof(float) + pitch * sizeof(cf);
@@ -1818,14 +1854,15 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
       float* segA = (float*)sg.segbuf.ptr;
       float* segB = segA + slotB * npr;
       const unsigned gx = (unsigned)std::min(64, (npr + 255) / 256);
-      hipLaunchKernelGGL(k_seg_gather, dim3(gx, NS, na), dim3(256), 0, ctx->stream, dptr, (const double*)su, d_ua, n, g.flags,
-                         npr, NS, k0, (long)Kb, npr, segA);
-      hipLaunchKernelGGL(k_seg_gather, dim3(gx, nb, nbw), dim3(256), 0, ctx->stream, dptr, (const double*)su, d_ub, n, g.flags,
+      hipLaunchKernelGGL(k_seg_gather, dim3(gx, NS, na), dim3(256), 0, ctx->stream, dptr, (const double*)su, d_ua,
+                         conv ? conv_len : n, flags, npr, NS, k0, (long)Kb, npr, segA);
+      hipLaunchKernelGGL(k_seg_gather, dim3(gx, nb, nbw), dim3(256), 0, ctx->stream, dptr, (const double*)su, d_ub, n, flags,
                          npr, nb, 0L, (long)Bk, Bk, segB);
       HIP_TRY(hipGetLastError());
       if ((rc = forward(sub, segA, (long)NS * npr, npr, NS, 0, 0, na * NS, 0))) return rc;
       if ((rc = forward(sub, segB, (long)nb * npr, npr, nb, 0, 0, nbw * nb, (int)slotB))) return rc;
-      hipLaunchKernelGGL(k_seg_gram, dim3((nfreq + 255) / 256, (nchunks + kSG - 1) / kSG, rr), dim3(256), 0, ctx->stream,
+      const SegGramVar& gv = seg_gram_pick(nchunks, nb);
+      hipLaunchKernelGGL(gv.fn, dim3((nfreq + 255) / 256, (nchunks + gv.sg - 1) / gv.sg, rr), dim3(256), 0, ctx->stream,
                          (const cf*)sub->spectra.ptr, pitch, nfreq, NS, nb, nchunks, slotB, d_ia, d_ib, (cf*)sub->gramC.ptr);
       HIP_TRY(hipGetLastError());
       // one inverse per (row, chunk): descriptor q reads row q of the cross-spectrum buffer, writes Kb lags at q Kb
@@ -1835,8 +1872,8 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
       if ((rc = upload(ctx, sub->descs, sub->hdescs.data(), (size_t)P * sizeof(PwDesc)))) return rc;
       if ((rc = stack_inverse(sub, P, (float*)sg.subout.ptr))) return rc;
       hipLaunchKernelGGL(k_seg_scatter, dim3(std::min(64, (Kb + 255) / 256), nchunks, rr), dim3(256), 0, ctx->stream,
-                         (const float*)sg.subout.ptr, (const double*)su, d_rx, d_ry, g.flags, n, Kb, nchunks, 0, k0, kend,
-                         pass == 0 ? 1 : -1, (long)g.idx_min, L, out + (size_t)r0 * ld_out, ld_out);
+                         (const float*)sg.subout.ptr, (const double*)su, d_rx, d_ry, flags, n, Kb, nchunks, 0, k0, kend,
+                         pass == 0 ? 1 : -1, idx_min_eff, L_eff, out + (size_t)r0 * ld_out, ld_out);
       HIP_TRY(hipGetLastError());
       r0 += rr;
     }
