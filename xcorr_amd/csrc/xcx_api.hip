@@ -1645,41 +1645,57 @@ __global__ __launch_bounds__(256) void k_seg_gather(const float* const* __restri
 // (512-byte runs per wave load), SG chunks per workgroup.  The SG segments a block meets are a WINDOW of the segment
 // axis that slides by one per block: it lives in registers and ONE load per block refills it (2 loads per block and
 // SG products; the first form loaded every operand of every product: 7 loads per 6 products).
-template <int SG>
+// R = 2: two rows that share the a-window (pairs of one station against two others, rows of one delay) ride the same
+// register window: 3 loads per block and 2 SG products.  grp[z R + i] = row i of group z.
+template <int SG, int R>
 __global__ __launch_bounds__(256) void k_seg_gram(const cf* __restrict__ X, size_t pitch, int nfreq, int NS, int nb, int nc,
                                                    size_t slotB, const int* __restrict__ ia, const int* __restrict__ ib,
-                                                   cf* __restrict__ C) {
+                                                   const int* __restrict__ grp, cf* __restrict__ C) {
   const int k = blockIdx.x * 256 + threadIdx.x;
   if (k >= nfreq) return;
-  const int c0 = blockIdx.y * SG, r = blockIdx.z;
-  const cf* __restrict__ Xa = X + ((size_t)ia[r] * NS + c0) * pitch + k;
-  const cf* __restrict__ Xb = X + (slotB + (size_t)ib[r] * nb) * pitch + k;
+  const int c0 = blockIdx.y * SG;
+  int r[R];
+  const cf* __restrict__ Xb[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    r[i] = grp[blockIdx.z * R + i];
+    Xb[i] = X + (slotB + (size_t)ib[r[i]] * nb) * pitch + k;
+  }
+  const cf* __restrict__ Xa = X + ((size_t)ia[r[0]] * NS + c0) * pitch + k;
   const int smax = NS - 1 - c0;                      // segments past the last one belong to chunks >= nc (not stored)
-  cf acc[SG], a[SG];
+  cf acc[R][SG], a[SG];
 #pragma unroll
   for (int j = 0; j < SG; ++j) {
-    acc[j] = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < R; ++i) acc[i][j] = make_float2(0.f, 0.f);
     a[j] = Xa[(size_t)min(j, smax) * pitch];
   }
   for (int beta = 0; beta < nb; ++beta) {
-    const cf b = Xb[(size_t)beta * pitch];
+    cf b[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) b[i] = Xb[i][(size_t)beta * pitch];
     const cf nx = Xa[(size_t)min(beta + SG, smax) * pitch];
 #pragma unroll
-    for (int j = 0; j < SG; ++j) {
-      acc[j].x += b.x * a[j].x + b.y * a[j].y;      // b conj(a)
-      acc[j].y += b.y * a[j].x - b.x * a[j].y;
-    }
+    for (int i = 0; i < R; ++i)
+#pragma unroll
+      for (int j = 0; j < SG; ++j) {
+        acc[i][j].x += b[i].x * a[j].x + b[i].y * a[j].y;      // b conj(a)
+        acc[i][j].y += b[i].y * a[j].x - b[i].x * a[j].y;
+      }
 #pragma unroll
     for (int j = 0; j + 1 < SG; ++j) a[j] = a[j + 1];
     a[SG - 1] = nx;
   }
 #pragma unroll
-  for (int j = 0; j < SG; ++j)
-    if (c0 + j < nc) C[((size_t)r * nc + c0 + j) * pitch + k] = acc[j];
+  for (int i = 0; i < R; ++i)
+#pragma unroll
+    for (int j = 0; j < SG; ++j)
+      if (c0 + j < nc) C[((size_t)r[i] * nc + c0 + j) * pitch + k] = acc[i][j];
 }
-using SegGramFn = void (*)(const cf*, size_t, int, int, int, int, size_t, const int*, const int*, cf*);
-struct SegGramVar { int sg; SegGramFn fn; };
-static const SegGramVar kSegGram[] = {{3, k_seg_gram<3>}, {6, k_seg_gram<6>}, {9, k_seg_gram<9>}, {12, k_seg_gram<12>}};
+using SegGramFn = void (*)(const cf*, size_t, int, int, int, int, size_t, const int*, const int*, const int*, cf*);
+struct SegGramVar { int sg; SegGramFn fn1, fn2; };
+static const SegGramVar kSegGram[] = {{3, k_seg_gram<3, 1>, k_seg_gram<3, 2>}, {6, k_seg_gram<6, 1>, k_seg_gram<6, 2>},
+                                      {9, k_seg_gram<9, 1>, k_seg_gram<9, 2>}, {12, k_seg_gram<12, 1>, k_seg_gram<12, 2>}};
 // fewest loads per row: groups x (SG + 2 nb); ties go to the wider window
 static const SegGramVar& seg_gram_pick(int nc, int nb) {
   const SegGramVar* best = &kSegGram[0];
@@ -1844,6 +1860,22 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
       ints.insert(ints.end(), ib.begin(), ib.end());
       ints.insert(ints.end(), ix.begin() + r0, ix.begin() + r0 + rr);
       ints.insert(ints.end(), iy.begin() + r0, iy.begin() + r0 + rr);
+      // rows of one a-window in twos (k_seg_gram<SG, 2>), the odd ones out alone; a-window order
+      const size_t g2_at = ints.size();
+      int n2 = 0, n1 = 0;
+      {
+        std::vector<int> cntv(na + 1, 0), ord(rr);
+        for (int i = 0; i < rr; ++i) cntv[ia[i] + 1]++;
+        for (int v = 0; v < na; ++v) cntv[v + 1] += cntv[v];
+        for (int i = 0; i < rr; ++i) ord[cntv[ia[i]]++] = i;          // stable counting sort by a-window
+        std::vector<int> single;
+        for (int i = 0; i < rr;) {
+          if (i + 1 < rr && ia[ord[i]] == ia[ord[i + 1]]) { ints.push_back(ord[i]); ints.push_back(ord[i + 1]); ++n2; i += 2; }
+          else { single.push_back(ord[i]); ++i; }
+        }
+        n1 = (int)single.size();
+        ints.insert(ints.end(), single.begin(), single.end());
+      }
       if ((rc = upload(ctx, sg.pairs, ints.data(), sizeof(int) * ints.size()))) return rc;
       const int* d_ua = (const int*)sg.pairs.ptr;
       const int* d_ub = d_ua + na;
@@ -1851,6 +1883,8 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
       const int* d_ib = d_ia + rr;
       const int* d_rx = d_ib + rr;
       const int* d_ry = d_rx + rr;
+      const int* d_g2 = (const int*)sg.pairs.ptr + g2_at;
+      const int* d_g1 = d_g2 + 2 * n2;
       float* segA = (float*)sg.segbuf.ptr;
       float* segB = segA + slotB * npr;
       const unsigned gx = (unsigned)std::min(64, (npr + 255) / 256);
@@ -1862,8 +1896,13 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
       if ((rc = forward(sub, segA, (long)NS * npr, npr, NS, 0, 0, na * NS, 0))) return rc;
       if ((rc = forward(sub, segB, (long)nb * npr, npr, nb, 0, 0, nbw * nb, (int)slotB))) return rc;
       const SegGramVar& gv = seg_gram_pick(nchunks, nb);
-      hipLaunchKernelGGL(gv.fn, dim3((nfreq + 255) / 256, (nchunks + gv.sg - 1) / gv.sg, rr), dim3(256), 0, ctx->stream,
-                         (const cf*)sub->spectra.ptr, pitch, nfreq, NS, nb, nchunks, slotB, d_ia, d_ib, (cf*)sub->gramC.ptr);
+      const dim3 gg((nfreq + 255) / 256, (nchunks + gv.sg - 1) / gv.sg, 1);
+      if (n2 > 0)
+        hipLaunchKernelGGL(gv.fn2, dim3(gg.x, gg.y, n2), dim3(256), 0, ctx->stream, (const cf*)sub->spectra.ptr, pitch, nfreq,
+                           NS, nb, nchunks, slotB, d_ia, d_ib, d_g2, (cf*)sub->gramC.ptr);
+      if (n1 > 0)
+        hipLaunchKernelGGL(gv.fn1, dim3(gg.x, gg.y, n1), dim3(256), 0, ctx->stream, (const cf*)sub->spectra.ptr, pitch, nfreq,
+                           NS, nb, nchunks, slotB, d_ia, d_ib, d_g1, (cf*)sub->gramC.ptr);
       HIP_TRY(hipGetLastError());
       // one inverse per (row, chunk): descriptor q reads row q of the cross-spectrum buffer, writes Kb lags at q Kb
       sub->hdescs.resize(P);
