@@ -1621,23 +1621,34 @@ __global__ void k_seg_stats_fin(const double* __restrict__ part, long n, double*
 //                  nb blocks of Bk samples (zero beyond) -- each transformed ONCE
 //   k_seg_gram   : G_c[k] = sum_beta B[ib(r)][beta][k] conj(A[ia(r)][beta + c][k])  for row r
 // windows: (ids, nwin) -> dst[(v nwin + w)][npr], sample base0 + w * wstride + i for i < len (zero beyond, and beyond n)
+constexpr int kSegU = 8;
 __global__ __launch_bounds__(256) void k_seg_gather(const float* const* __restrict__ ptrs, const double* __restrict__ su,
                                                      const int* __restrict__ ids, long n, int flags, int npr, int nwin,
                                                      long base0, long wstride, int len, float* __restrict__ dst) {
   const int w = blockIdx.y, v = blockIdx.z;
-  const int u = ids[v];
-  const float* __restrict__ src = ptrs[u];
-  const double m = su[2 * u];
+  const int win = ids[v];
+  const float* __restrict__ src = ptrs[win];
+  const double m = su[2 * win];
   const bool ob = flags & XCX_F_ONEBIT;
   float* __restrict__ d = dst + ((size_t)v * nwin + w) * (size_t)npr;
   const long base = base0 + (long)w * wstride;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < npr; i += gridDim.x * 256) {
+  // kSegU elements per thread, their loads issued together (a grid-stride loop here is one load and one wait per trip)
+  const int i0 = blockIdx.x * (256 * kSegU) + threadIdx.x;
+  float x[kSegU];
+  bool in[kSegU];
+#pragma unroll
+  for (int u = 0; u < kSegU; ++u) {
+    const int i = i0 + u * 256;
     const long j = base + i;
-    const bool in = i < len && j < n;
-    const float x = src[in ? j : 0];                 // unconditional load, then a select (no branch around the load)
-    const double uu = (double)x - m;
+    in[u] = i < len && j < n;
+    x[u] = src[in[u] ? j : 0];                       // unconditional load, then a select (no branch around the load)
+  }
+#pragma unroll
+  for (int u = 0; u < kSegU; ++u) {
+    const int i = i0 + u * 256;
+    const double uu = (double)x[u] - m;
     const float val = ob ? ((uu > 0.0) ? 1.f : ((uu < 0.0) ? -1.f : 0.f)) : (float)uu;
-    d[i] = in ? val : 0.f;
+    if (i < npr) d[i] = in[u] ? val : 0.f;
   }
 }
 
@@ -1717,12 +1728,18 @@ __global__ __launch_bounds__(256) void k_seg_scatter(const float* __restrict__ s
   double scale = 1.0;
   if (flags & XCX_F_NORMALIZE) scale = 1.0 / (sqrt(su[2 * rx[r] + 1]) * sqrt(su[2 * ry[r] + 1]));
   const float* __restrict__ srow = sub + ((size_t)r * nc + c) * (size_t)Kb;
-  for (int kk = blockIdx.x * 256 + threadIdx.x; kk < Kb; kk += gridDim.x * 256) {
+  const int kk0 = blockIdx.x * (256 * kSegU) + threadIdx.x;
+  float sv[kSegU];
+#pragma unroll
+  for (int u = 0; u < kSegU; ++u) sv[u] = srow[Kb - 1 - min(kk0 + u * 256, Kb - 1)];
+#pragma unroll
+  for (int u = 0; u < kSegU; ++u) {
+    const int kk = kk0 + u * 256;
     const long k = k0 + (long)(c0 + c) * Kb + kk;
-    if (k >= kend) continue;
+    if (kk >= Kb || k >= kend) continue;
     const long j = (n - 1) + sign * k - idx_min;
     if (j < 0 || j >= L) continue;
-    double v = (double)srow[Kb - 1 - kk] * scale;
+    double v = (double)sv[u] * scale;
     if (flags & XCX_F_UNBIAS) v *= (double)n / (double)(n - k);
     out[(size_t)r * ld_out + j] = (float)v;
   }
@@ -1887,7 +1904,7 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
       const int* d_g1 = d_g2 + 2 * n2;
       float* segA = (float*)sg.segbuf.ptr;
       float* segB = segA + slotB * npr;
-      const unsigned gx = (unsigned)std::min(64, (npr + 255) / 256);
+      const unsigned gx = (unsigned)((npr + 256 * kSegU - 1) / (256 * kSegU));
       hipLaunchKernelGGL(k_seg_gather, dim3(gx, NS, na), dim3(256), 0, ctx->stream, dptr, (const double*)su, d_ua,
                          conv ? conv_len : n, flags, npr, NS, k0, (long)Kb, npr, segA);
       hipLaunchKernelGGL(k_seg_gather, dim3(gx, nb, nbw), dim3(256), 0, ctx->stream, dptr, (const double*)su, d_ub, n, flags,
@@ -1910,7 +1927,7 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
       sub->desc_key = 0; sub->gram_key = 0;
       if ((rc = upload(ctx, sub->descs, sub->hdescs.data(), (size_t)P * sizeof(PwDesc)))) return rc;
       if ((rc = stack_inverse(sub, P, (float*)sg.subout.ptr))) return rc;
-      hipLaunchKernelGGL(k_seg_scatter, dim3(std::min(64, (Kb + 255) / 256), nchunks, rr), dim3(256), 0, ctx->stream,
+      hipLaunchKernelGGL(k_seg_scatter, dim3((Kb + 256 * kSegU - 1) / (256 * kSegU), nchunks, rr), dim3(256), 0, ctx->stream,
                          (const float*)sg.subout.ptr, (const double*)su, d_rx, d_ry, flags, n, Kb, nchunks, 0, k0, kend,
                          pass == 0 ? 1 : -1, idx_min_eff, L_eff, out + (size_t)r0 * ld_out, ld_out);
       HIP_TRY(hipGetLastError());
