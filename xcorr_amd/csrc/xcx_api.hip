@@ -1658,52 +1658,87 @@ __global__ __launch_bounds__(256) void k_seg_gather(const float* const* __restri
 // SG products; the first form loaded every operand of every product: 7 loads per 6 products).
 // R = 2: two rows that share the a-window (pairs of one station against two others, rows of one delay) ride the same
 // register window: 3 loads per block and 2 SG products.  grp[z R + i] = row i of group z.
+constexpr int kSegUB = 4;
+typedef float f2 __attribute__((ext_vector_type(2)));
 template <int SG, int R>
 __global__ __launch_bounds__(256) void k_seg_gram(const cf* __restrict__ X, size_t pitch, int nfreq, int NS, int nb, int nc,
                                                    size_t slotB, const int* __restrict__ ia, const int* __restrict__ ib,
-                                                   const int* __restrict__ grp, cf* __restrict__ C) {
-  const int k = blockIdx.x * 256 + threadIdx.x;
-  if (k >= nfreq) return;
-  const int c0 = blockIdx.y * SG;
+                                                   const int* __restrict__ grp, int G, int gy, cf* __restrict__ C) {
+  // One wave = 64 frequencies of one group of rows; the waves of a workgroup take four groups at the SAME frequencies,
+  // and the frequency tiles are dealt to the XCDs (tile f on XCD f mod 8, workgroup ids go round the XCDs): all groups
+  // of a tile run back to back on one XCD, so every window's 512 bytes of the tile are fetched into that L2 once and
+  // the other rows that meet the window hit there (with frequency tiles as the fast grid axis a window's lines were
+  // long gone when the next row asked for them: 60 MB per row from beyond the L2).
+  const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int per_tile = ((G + 3) >> 2) * gy;
+  const int t = q / per_tile, rem = q - t * per_tile;
+  const int f = x + 8 * t;
+  // everything but the lane's frequency is uniform over the wave: said so (readfirstlane), the row numbers, window
+  // indices and segment addresses are scalar work and the loads take a scalar base plus the lane's 32-bit offset
+  const int grp_i = (rem / gy) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned k = (unsigned)f * 64u + (threadIdx.x & 63);
+  if (k >= (unsigned)nfreq || grp_i >= G) return;
+  const int c0 = (rem % gy) * SG;
   int r[R];
   const cf* __restrict__ Xb[R];
 #pragma unroll
   for (int i = 0; i < R; ++i) {
-    r[i] = grp[blockIdx.z * R + i];
-    Xb[i] = X + (slotB + (size_t)ib[r[i]] * nb) * pitch + k;
+    r[i] = grp[grp_i * R + i];
+    Xb[i] = X + (slotB + (size_t)ib[r[i]] * nb) * pitch;
   }
-  const cf* __restrict__ Xa = X + ((size_t)ia[r[0]] * NS + c0) * pitch + k;
+  const cf* __restrict__ Xa = X + ((size_t)ia[r[0]] * NS + c0) * pitch;
   const int smax = NS - 1 - c0;                      // segments past the last one belong to chunks >= nc (not stored)
-  cf acc[R][SG], a[SG];
+  const unsigned koff = k * (unsigned)sizeof(cf);    // scalar row address + 32-bit lane offset: the load's own address mode
+  auto ld = [koff](const cf* row) { return *reinterpret_cast<const cf*>(reinterpret_cast<const char*>(row) + koff); };
+  f2 acc[R][SG];
+  // the window: w[0 .. SG-2] = segments beta .. beta+SG-2 at the start of a trip, the trip's loads append one segment
+  // per block, block u of the trip meets w[u .. u+SG-1] (static registers), one shift per trip
+  cf w[SG - 1 + kSegUB];
 #pragma unroll
-  for (int j = 0; j < SG; ++j) {
+  for (int j = 0; j < SG; ++j)
 #pragma unroll
-    for (int i = 0; i < R; ++i) acc[i][j] = make_float2(0.f, 0.f);
-    a[j] = Xa[(size_t)min(j, smax) * pitch];
-  }
-  for (int beta = 0; beta < nb; ++beta) {
-    cf b[R];
+    for (int i = 0; i < R; ++i) acc[i][j] = f2{0.f, 0.f};
 #pragma unroll
-    for (int i = 0; i < R; ++i) b[i] = Xb[i][(size_t)beta * pitch];
-    const cf nx = Xa[(size_t)min(beta + SG, smax) * pitch];
+  for (int j = 0; j + 1 < SG; ++j) w[j] = ld(Xa + (size_t)min(j, smax) * pitch);
+  // kSegUB blocks per trip, their loads issued together: with one block per trip (3 loads, then a full wait) the kernel
+  // ran on latency x occupancy, not on bandwidth
+  for (int beta = 0; beta < nb; beta += kSegUB) {
+    cf b[kSegUB][R];
 #pragma unroll
-    for (int i = 0; i < R; ++i)
+    for (int u = 0; u < kSegUB; ++u) {
+      const int bb = min(beta + u, nb - 1);
 #pragma unroll
-      for (int j = 0; j < SG; ++j) {
-        acc[i][j].x += b[i].x * a[j].x + b[i].y * a[j].y;      // b conj(a)
-        acc[i][j].y += b[i].y * a[j].x - b[i].x * a[j].y;
+      for (int i = 0; i < R; ++i) b[u][i] = ld(Xb[i] + (size_t)bb * pitch);
+      w[SG - 1 + u] = ld(Xa + (size_t)min(beta + u + SG - 1, smax) * pitch);
+    }
+#pragma unroll
+    for (int u = 0; u < kSegUB; ++u) {
+      if (beta + u < nb) {
+        f2 bv[R], bs[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) { bv[i] = f2{b[u][i].x, b[u][i].y}; bs[i] = f2{b[u][i].y, -b[u][i].x}; }
+#pragma unroll
+        for (int i = 0; i < R; ++i)
+#pragma unroll
+          for (int j = 0; j < SG; ++j)      // b conj(a) as two packed FMAs: (bx, by) ax + (by, -bx) ay
+            acc[i][j] = __builtin_elementwise_fma(bs[i], f2{w[u + j].y, w[u + j].y},
+                                                  __builtin_elementwise_fma(bv[i], f2{w[u + j].x, w[u + j].x}, acc[i][j]));
       }
+    }
 #pragma unroll
-    for (int j = 0; j + 1 < SG; ++j) a[j] = a[j + 1];
-    a[SG - 1] = nx;
+    for (int j = 0; j + 1 < SG; ++j) w[j] = w[j + kSegUB];
   }
 #pragma unroll
   for (int i = 0; i < R; ++i)
 #pragma unroll
     for (int j = 0; j < SG; ++j)
-      if (c0 + j < nc) C[((size_t)r[i] * nc + c0 + j) * pitch + k] = acc[i][j];
+      if (c0 + j < nc) {                             // streamed: nothing reads C before the inverse's column pass
+        float* dst = reinterpret_cast<float*>(C + ((size_t)r[i] * nc + c0 + j) * pitch + k);
+        __builtin_nontemporal_store(acc[i][j].x, dst);
+        __builtin_nontemporal_store(acc[i][j].y, dst + 1);
+      }
 }
-using SegGramFn = void (*)(const cf*, size_t, int, int, int, int, size_t, const int*, const int*, const int*, cf*);
+using SegGramFn = void (*)(const cf*, size_t, int, int, int, int, size_t, const int*, const int*, const int*, int, int, cf*);
 struct SegGramVar { int sg; SegGramFn fn1, fn2; };
 static const SegGramVar kSegGram[] = {{3, k_seg_gram<3, 1>, k_seg_gram<3, 2>}, {6, k_seg_gram<6, 1>, k_seg_gram<6, 2>},
                                       {9, k_seg_gram<9, 1>, k_seg_gram<9, 2>}, {12, k_seg_gram<12, 1>, k_seg_gram<12, 2>}};
@@ -1877,21 +1912,45 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
       ints.insert(ints.end(), ib.begin(), ib.end());
       ints.insert(ints.end(), ix.begin() + r0, ix.begin() + r0 + rr);
       ints.insert(ints.end(), iy.begin() + r0, iy.begin() + r0 + rr);
-      // rows of one a-window in twos (k_seg_gram<SG, 2>), the odd ones out alone; a-window order
+      // rows of one a-window in twos (k_seg_gram<SG, 2>), the odd ones out alone.  Twos are cut at even b-window
+      // numbers so that the twos of neighbouring a-windows meet the same b-windows, and the groups run in the order
+      // (block of kSegAB a-windows, b-window, a-window): while the b-windows sweep past, the block's a-windows stay in
+      // the Infinity Cache and each b-window is fetched from memory once per block, not once per a-window (the spectra
+      // of 64 stations are 5 GB: in row order every row fetched its 35 MB of b-blocks from HBM).
       const size_t g2_at = ints.size();
       int n2 = 0, n1 = 0;
       {
-        std::vector<int> cntv(na + 1, 0), ord(rr);
-        for (int i = 0; i < rr; ++i) cntv[ia[i] + 1]++;
-        for (int v = 0; v < na; ++v) cntv[v + 1] += cntv[v];
-        for (int i = 0; i < rr; ++i) ord[cntv[ia[i]]++] = i;          // stable counting sort by a-window
-        std::vector<int> single;
+        static const int kSegAB = getenv("XCX_SEG_ABLOCK") ? std::max(1, atoi(getenv("XCX_SEG_ABLOCK"))) : 2;
+        std::vector<int> ord(rr);
+        for (int i = 0; i < rr; ++i) ord[i] = i;
+        std::sort(ord.begin(), ord.end(), [&](int p, int q) {
+          return ia[p] != ia[q] ? ia[p] < ia[q] : (ib[p] != ib[q] ? ib[p] < ib[q] : p < q); });
+        struct Grp { int r0, r1; };
+        std::vector<Grp> twos, ones;
+        std::vector<int> left;
         for (int i = 0; i < rr;) {
-          if (i + 1 < rr && ia[ord[i]] == ia[ord[i + 1]]) { ints.push_back(ord[i]); ints.push_back(ord[i + 1]); ++n2; i += 2; }
-          else { single.push_back(ord[i]); ++i; }
+          int e = i;
+          while (e < rr && ia[ord[e]] == ia[ord[i]]) ++e;
+          left.clear();
+          for (int q = i; q < e;) {
+            if (q + 1 < e && (ib[ord[q]] >> 1) == (ib[ord[q + 1]] >> 1)) { twos.push_back({ord[q], ord[q + 1]}); q += 2; }
+            else { left.push_back(ord[q]); ++q; }
+          }
+          for (size_t q = 0; q + 1 < left.size(); q += 2) twos.push_back({left[q], left[q + 1]});
+          if (left.size() & 1) ones.push_back({left.back(), -1});
+          i = e;
         }
-        n1 = (int)single.size();
-        ints.insert(ints.end(), single.begin(), single.end());
+        auto before = [&](const Grp& p, const Grp& q) {
+          const int ap = ia[p.r0], aq = ia[q.r0];
+          if (ap / kSegAB != aq / kSegAB) return ap / kSegAB < aq / kSegAB;
+          if ((ib[p.r0] >> 1) != (ib[q.r0] >> 1)) return (ib[p.r0] >> 1) < (ib[q.r0] >> 1);
+          return ap != aq ? ap < aq : p.r0 < q.r0;
+        };
+        std::sort(twos.begin(), twos.end(), before);
+        std::sort(ones.begin(), ones.end(), before);
+        n2 = (int)twos.size(); n1 = (int)ones.size();
+        for (const Grp& t : twos) { ints.push_back(t.r0); ints.push_back(t.r1); }
+        for (const Grp& t : ones) ints.push_back(t.r0);
       }
       if ((rc = upload(ctx, sg.pairs, ints.data(), sizeof(int) * ints.size()))) return rc;
       const int* d_ua = (const int*)sg.pairs.ptr;
@@ -1913,13 +1972,14 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
       if ((rc = forward(sub, segA, (long)NS * npr, npr, NS, 0, 0, na * NS, 0))) return rc;
       if ((rc = forward(sub, segB, (long)nb * npr, npr, nb, 0, 0, nbw * nb, (int)slotB))) return rc;
       const SegGramVar& gv = seg_gram_pick(nchunks, nb);
-      const dim3 gg((nfreq + 255) / 256, (nchunks + gv.sg - 1) / gv.sg, 1);
+      const int gy = (nchunks + gv.sg - 1) / gv.sg, tiles8 = ((nfreq + 63) / 64 + 7) / 8;      // tiles per XCD
+      auto gram_grid = [&](int G) { return dim3((unsigned)(8 * (size_t)tiles8 * ((G + 3) / 4) * gy)); };
       if (n2 > 0)
-        hipLaunchKernelGGL(gv.fn2, dim3(gg.x, gg.y, n2), dim3(256), 0, ctx->stream, (const cf*)sub->spectra.ptr, pitch, nfreq,
-                           NS, nb, nchunks, slotB, d_ia, d_ib, d_g2, (cf*)sub->gramC.ptr);
+        hipLaunchKernelGGL(gv.fn2, gram_grid(n2), dim3(256), 0, ctx->stream, (const cf*)sub->spectra.ptr, pitch, nfreq,
+                           NS, nb, nchunks, slotB, d_ia, d_ib, d_g2, n2, gy, (cf*)sub->gramC.ptr);
       if (n1 > 0)
-        hipLaunchKernelGGL(gv.fn1, dim3(gg.x, gg.y, n1), dim3(256), 0, ctx->stream, (const cf*)sub->spectra.ptr, pitch, nfreq,
-                           NS, nb, nchunks, slotB, d_ia, d_ib, d_g1, (cf*)sub->gramC.ptr);
+        hipLaunchKernelGGL(gv.fn1, gram_grid(n1), dim3(256), 0, ctx->stream, (const cf*)sub->spectra.ptr, pitch, nfreq,
+                           NS, nb, nchunks, slotB, d_ia, d_ib, d_g1, n1, gy, (cf*)sub->gramC.ptr);
       HIP_TRY(hipGetLastError());
       // one inverse per (row, chunk): descriptor q reads row q of the cross-spectrum buffer, writes Kb lags at q Kb
       sub->hdescs.resize(P);
