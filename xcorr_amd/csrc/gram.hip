@@ -94,7 +94,9 @@ __global__ __launch_bounds__(256, 3) void k_gram_mfma(GramArgs a) {
   f32x16 gr00 = {0}, gr01 = {0}, gr11 = {0}, gi00 = {0}, gi01 = {0}, gi11 = {0};
   const int ls_s = tid >> 2, ls_f = tid & 3;                 // loader role: station, frequency of the quad
   const bool ld_ok = ls_s < S && f0 + ls_f < a.nfreq;
-  const cf* __restrict__ src = a.X + (size_t)ls_s * (a.ldw ? a.ldw : W) * a.spec_pitch + f0 + ls_f;
+  // the loader's address is clamped into the buffer and the value masked when it is stored: a load inside the bounds
+  // branch gets a wait of its own, and the sixteen loads of a chunk went out one round trip after the other
+  const cf* __restrict__ src = a.X + (size_t)min(ls_s, S - 1) * (a.ldw ? a.ldw : W) * a.spec_pitch + min(f0 + ls_f, a.nfreq - 1);
   const int part = lane >> 5, st = lane & 31;
   const float sgn = part ? -1.f : 1.f;
   // rows of C this thread will write (4 entries per 32x32 block), looked up before the main
@@ -106,13 +108,13 @@ __global__ __launch_bounds__(256, 3) void k_gram_mfma(GramArgs a) {
     for (int q = 0; q < 4; ++q) {
       const int e = tid + 256 * q;
       const int si = (blk == 2 ? 32 : 0) + (e >> 5), sj = (blk == 0 ? 0 : 32) + (e & 31);
-      prow[blk][q] = (si < S && sj < S) ? a.pidx[si * S + sj] : -1;
+      const int pv = a.pidx[min(si, S - 1) * S + min(sj, S - 1)];
+      prow[blk][q] = ((si < S) & (sj < S)) ? pv : -1;
     }
   cf stage[kGW];
   auto fetch = [&](int w0) {                                // one chunk of windows -> registers
 #pragma unroll
-    for (int w = 0; w < kGW; ++w)
-      stage[w] = (ld_ok && w0 + w < W) ? src[(size_t)(w0 + w) * a.spec_pitch] : make_float2(0.f, 0.f);
+    for (int w = 0; w < kGW; ++w) stage[w] = src[(size_t)min(w0 + w, W - 1) * a.spec_pitch];      // masked when stored
   };
   fetch(0);
   for (int w0 = 0; w0 < W; w0 += kGW) {
@@ -121,7 +123,8 @@ __global__ __launch_bounds__(256, 3) void k_gram_mfma(GramArgs a) {
 #pragma unroll
     for (int w = 0; w < kGW; ++w) {
       float* d = ls + (w * 64 + ls_s) * kGPitch + 2 * ls_f;
-      d[0] = stage[w].x; d[1] = stage[w].y;
+      const bool ok = ld_ok & (w0 + w < W);
+      d[0] = ok ? stage[w].x : 0.f; d[1] = ok ? stage[w].y : 0.f;
     }
     __syncthreads();
     if (w0 + kGW < W) fetch(w0 + kGW);                      // next chunk's loads fly under the MFMAs
