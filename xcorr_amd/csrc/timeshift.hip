@@ -58,7 +58,7 @@ namespace {
 // comes out below 1e-6 is re-evaluated exactly: next to the kernel's peak the quotient would amplify the
 // rounding of the recurrence.
 constexpr int kDK = 8;
-__global__ void k_dirichlet(float* __restrict__ hr, long n, long rows, const double* __restrict__ alpha, int ext) {
+__global__ void k_dirichlet(float* __restrict__ hr, long n, long rows, const double* __restrict__ alpha) {
   // grid (ceil(n / (256 kDK)), rows): no 64-bit division per sample
   // a wave owns 64 kDK consecutive samples; lane l takes t = first + l + 64 k, so every store instruction of the
   // wave writes 64 consecutive floats and a lane's samples are 64 apart: rotate by -64 pi/n per step
@@ -102,28 +102,12 @@ __global__ void k_dirichlet(float* __restrict__ hr, long n, long rows, const dou
       if (fabs(su) < 1e-12) h = ((double)(n - 1) + ca * sgn) * inv_n;
       else h = -sgn * sa * (cu / su) * inv_n;
     }
-    if (!ext) {
-      hr[r * n + t] = (float)h;
-    } else {
-      // two periods, g[j] = h[(n-1-j) mod n], j < 2n-1: with R[lag] = sum_j x[j+lag] g[j] (x zero beyond n samples)
-      // the lags -(n-1) .. 0 are y[m], m = n-1+lag.  h[m] = this sample's value (m = (-t) mod n).
-      float* g = hr + r * (2 * n - 1);
-      g[n - 1 - m] = (float)h;
-      if (m >= 1) g[2 * n - 1 - m] = (float)h;
-    }
+    // two periods, g[j] = h[(n-1-j) mod n], j < 2n-1: with R[lag] = sum_j x[j+lag] g[j] (x zero beyond n samples)
+    // the lags -(n-1) .. 0 are y[m], m = n-1+lag.  h[m] = this sample's value (m = (-t) mod n).
+    float* g = hr + r * (2 * n - 1);
+    g[n - 1 - m] = (float)h;
+    if (m >= 1) g[2 * n - 1 - m] = (float)h;
   }
-}
-
-// y[r][m] = R[r][m + n - 1] + (m >= 1 ? R[r][m - 1] : 0), times cos(2 pi m / n) when `modulate`
-__global__ void k_fold(const float* __restrict__ lin, long ld, float* __restrict__ y, long n, long rows, int modulate) {
-  const long r = blockIdx.y;
-  const long m = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= n || r >= rows) return;
-  const float* R = lin + r * ld;
-  float v = R[m + n - 1];
-  if (m >= 1) v += R[m - 1];
-  if (modulate) v = (float)((double)v * cospi(2.0 * (double)m / (double)n));
-  y[r * n + m] = v;
 }
 
 // y[r][m] *= cos(2 pi m / n)   (odd-length fft / ifft path of the reference, see xcx_timeshift_fft)
@@ -153,22 +137,26 @@ static int timeshift_rows(xcx_ctx* ctx, const float* x, float* y, long batch, lo
       ctx->ts_direct = !xcx_internal_segmented(ctx->ts_plan);
       if (!ctx->ts_direct) { xcx_plan_destroy(ctx->ts_plan); ctx->ts_plan = nullptr; }
     }
-    // longer than one transform: one period + fold, through the block decomposition
-    if (!ctx->ts_direct && (rc = xcx_plan_cc1d(ctx, (int)n, 0, 0, 0, 0, &ctx->ts_plan))) return rc;
+    // longer than one transform: the block decomposition (xcx_api.hip: seg_run) in its convolution mode
+    if (!ctx->ts_direct) {
+      if ((rc = xcx_plan_cc1d(ctx, (int)n, 0, 0, 0, 0, &ctx->ts_plan))) return rc;
+      if (!xcx_internal_segmented(ctx->ts_plan)) {       // cannot happen: 2n - 1 exceeds every single transform
+        xcx_plan_destroy(ctx->ts_plan); ctx->ts_plan = nullptr;
+        return set_err(XCX_EUNSUPPORTED, "time shift of %ld-sample rows: no plan", n);
+      }
+    }
     ctx->ts_n = n;
   }
   xcx_plan* plan = ctx->ts_plan;
   const bool direct = ctx->ts_direct;
   const long L = 2 * n - 1;
-  const long ld = (L + 31) / 32 * 32;
   const int kRows = n > 400000 ? 64 : 256;            // rows per launch group: bounded workspace for long rows; 128 -> 256 measured -5 % (launch tails)
-  DevBuf &hr = ctx->scratch[1], &lin = ctx->scratch[2], &dal = ctx->scratch[3], &dx = ctx->scratch[4],
+  DevBuf &hr = ctx->scratch[1], &dal = ctx->scratch[3], &dx = ctx->scratch[4],
          &dy = ctx->scratch[5];
   const int chunk = (int)std::min<long>(kRows, batch);
-  const bool seg = xcx_internal_segmented(plan);     // rows longer than one transform: block decomposition
-  const bool two = direct || seg;                    // kernels of two periods: the n retained lags are the convolution itself
-  if ((rc = hr.ensure(ctx, sizeof(float) * (two ? L : n) * chunk))) return rc;
-  if (!two && (rc = lin.ensure(ctx, sizeof(float) * ld * chunk))) return rc;
+  const bool seg = !direct;                          // rows longer than one transform: block decomposition
+  // kernels of two periods (2n - 1 samples): the n retained lags are the circular convolution itself
+  if ((rc = hr.ensure(ctx, sizeof(float) * L * chunk))) return rc;
   if ((rc = dal.ensure(ctx, sizeof(double) * batch))) return rc;
   HIP_TRY(hipMemcpyAsync(dal.ptr, alpha.data(), sizeof(double) * batch, hipMemcpyHostToDevice, ctx->stream));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -210,7 +198,7 @@ static int timeshift_rows(xcx_ctx* ctx, const float* x, float* y, long batch, lo
     const dim3 grid((unsigned)((n + 255) / 256), (unsigned)cnt);
     const dim3 kgrid((unsigned)((n + 256 * kDK - 1) / (256 * kDK)), (unsigned)nk);
     hipLaunchKernelGGL(k_dirichlet, kgrid, dim3(256), 0, ctx->stream, (float*)hr.ptr, n, (long)nk,
-                       (const double*)dal.ptr + r0, two ? 1 : 0);
+                       (const double*)dal.ptr + r0);
     HIP_TRY(hipGetLastError());
     if (direct) {
       if ((rc = xcx_internal_forward(plan, xd + r0 * size, size, 0, 1, 0, 0, cnt, 0, (int)n))) return rc;
@@ -223,26 +211,15 @@ static int timeshift_rows(xcx_ctx* ctx, const float* x, float* y, long batch, lo
       }
       continue;
     }
-    if (seg) {
-      // block-decomposed convolution with the two-period kernel in the segment role: one pass, the n values written
-      // in place (rows that share a delay share the kernel's segment transforms; before round 4: both lag signs
-      // against one period, 2n - 1 lags, then a fold)
-      for (int i = 0; i < cnt; ++i) { xs[i] = xd + (r0 + i) * size; ys[i] = (const float*)hr.ptr + (long)ukern[i] * L; }
-      if ((rc = xcx_internal_seg_conv(plan, xs.data(), ys.data(), cnt, yd + r0 * n, n))) return rc;
-      if (modulate) {
-        hipLaunchKernelGGL(k_modulate, grid, dim3(256), 0, ctx->stream, yd + r0 * n, n, (long)cnt);
-        HIP_TRY(hipGetLastError());
-      }
-      continue;
-    } else {
-      if ((rc = xcx_internal_forward(plan, xd + r0 * size, size, 0, 1, 0, 0, cnt, 0, 0))) return rc;
-      if ((rc = xcx_internal_forward(plan, (const float*)hr.ptr, n, 0, 1, 0, 0, nk, cnt, 0))) return rc;
-      for (int i = 0; i < cnt; ++i) d[i] = PwDesc{i, cnt + ukern[i], (long long)i * ld};
-      if ((rc = xcx_internal_pairs(plan, d.data(), cnt, (float*)lin.ptr))) return rc;
+    // block-decomposed convolution with the two-period kernel in the segment role: one pass, the n values written
+    // in place (rows that share a delay share the kernel's segment transforms; before round 4: both lag signs
+    // against one period, 2n - 1 lags, then a fold)
+    for (int i = 0; i < cnt; ++i) { xs[i] = xd + (r0 + i) * size; ys[i] = (const float*)hr.ptr + (long)ukern[i] * L; }
+    if ((rc = xcx_internal_seg_conv(plan, xs.data(), ys.data(), cnt, yd + r0 * n, n))) return rc;
+    if (modulate) {
+      hipLaunchKernelGGL(k_modulate, grid, dim3(256), 0, ctx->stream, yd + r0 * n, n, (long)cnt);
+      HIP_TRY(hipGetLastError());
     }
-    hipLaunchKernelGGL(k_fold, grid, dim3(256), 0, ctx->stream, (const float*)lin.ptr, ld, yd + r0 * n, n,
-                       (long)cnt, modulate);
-    HIP_TRY(hipGetLastError());
   }
   if (!on_device) {
     HIP_TRY(hipMemcpyAsync(y, yd, sizeof(float) * n * batch, hipMemcpyDeviceToHost, ctx->stream));

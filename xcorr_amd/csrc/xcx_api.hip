@@ -424,7 +424,8 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
   const long long maxlag = std::max<long long>((long long)n - 1 - idx_min, (long long)idx_max - n);
   // kPlanShortOperand (library-internal, fftn.hip): the caller guarantees that the first operand is zero
   // beyond its first idx_min + 1 samples and that only lags <= 0 are retained -- the aliases of the retained
-  // lags then fall outside the linear correlation's support as soon as N >= n (chirp convolutions).
+  // lags then fall outside the linear correlation's support as soon as N >= n (chirp convolutions, the blocks of the
+  // segmented plans).
   const long long need = (flags & kPlanShortOperand) ? (long long)n : (long long)n + maxlag;
   // choose N = 2*N1*N2h: smallest supported >= need (or == nfft)
   long long best = -1;
