@@ -106,7 +106,7 @@ def test_timeshift_of_long_rows(ctx):
 def test_timeshift_at_the_single_transform_boundary(ctx):
     """Rows up to 393 216 samples are shifted by ONE correlation against two periods of the Dirichlet kernel
     (2n - 1 <= 786 432, the longest transform; the pair pass writes the shifted row), longer ones by the
-    one-period correlation + fold through the block decomposition: both sides of the switch, odd sizes too."""
+    one-pass block convolution with that kernel (seg_run's convolution mode): both sides of the switch, odd sizes too."""
     from xcorr_amd import ops
     rng = np.random.default_rng(23)
     fs = 50.
@@ -136,6 +136,37 @@ def test_production_postprocess_chain(ctx):
     ref = R.postprocess_chain(rows.astype(np.float64), n, fs, i0, i1, delay)
     assert got.shape == ref.shape == (2, 1620000)
     assert _rel(got, ref) < 2 * TOL                 # six chained float32 stages
+
+
+def test_segmented_rows_in_several_chunks(ctx, monkeypatch):
+    """A call whose rows do not fit the workspace budget runs in chunks of rows, each transforming the windows its
+    rows meet (XCX_SEG_BUDGET_MB; by default half of the free device memory, 4-64 GB): all pairs of 7 stations and
+    a batch of unrelated rows, 1 MB at a time, give bit for bit what one chunk gives; rows that share a delay kernel
+    in the time shift too."""
+    from xcorr_amd import ops
+    rng = np.random.default_rng(31)
+    n, S = 10007, 7
+    monkeypatch.setenv('XCX_SEG_FORCE', '1')
+    monkeypatch.setenv('XCX_SEG_N', '4096')
+    seg = X.CCPlan(ctx, n, index_min=n - 1 - 300, index_max=n + 6000)
+    assert seg.N == 4096
+    tr = rng.standard_normal((S, n + 64)).astype(np.float32)
+    pr = np.array([(i, j) for i in range(S) for j in range(i, S)], np.int32)
+    x = rng.standard_normal((9, n)).astype(np.float32)
+    y = rng.standard_normal((9, n)).astype(np.float32)
+    t = (rng.standard_normal((11, 9107)) * np.hanning(9107)).astype(np.float32)
+    delay = np.array([0.003, -0.011, 0.02])[rng.integers(0, 3, 11)]
+    one = seg.pairs(tr, pr, 2, 64).copy(), seg.cc(x, y).copy(), ops.timeshift(ctx, t, delay, 50.).copy()
+    monkeypatch.setenv('XCX_SEG_BUDGET_MB', '1')
+    many = seg.pairs(tr, pr, 2, 64), seg.cc(x, y), ops.timeshift(ctx, t, delay, 50.)
+    for a, b in zip(one, many):
+        assert np.array_equal(a, b)
+    monkeypatch.delenv('XCX_SEG_FORCE'); monkeypatch.delenv('XCX_SEG_N'); monkeypatch.delenv('XCX_SEG_BUDGET_MB')
+    ref = X.CCPlan(ctx, n, index_min=n - 1 - 300, index_max=n + 6000)
+    b = ref.pairs(tr, pr, 2, 64)
+    assert np.abs(many[0] - b).max() / np.abs(b).max() < 2e-5
+    assert _rel(many[2], R.timeshift(t, delay, 50.)) < TOL
+    seg.close(); ref.close()
 
 
 def test_segmented_plan_random_sweep(ctx):

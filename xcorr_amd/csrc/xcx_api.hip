@@ -1880,15 +1880,27 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
     const size_t per_win = (size_t)npr * sizeof(float) + pitch * sizeof(cf);
     const size_t per_a = (size_t)NS * per_win, per_b = (size_t)nb * per_win;
     const size_t per_row = (size_t)nchunks * (pitch * sizeof(cf) + (size_t)Kb * sizeof(float));
-    const size_t budget = (size_t)16 << 30;
+    // workspace of one chunk of rows: half of what the device has free, between 4 and 64 GB (XCX_SEG_BUDGET_MB overrides);
+    // every chunk transforms the windows its rows meet, so three chunks of a 64-station day transformed every
+    // station's blocks three times
+    size_t budget = (size_t)16 << 30;
+    {
+      const char* eb = getenv("XCX_SEG_BUDGET_MB");           // read per call (tests)
+      const long env_mb = eb ? atol(eb) : 0;
+      size_t free_b = 0, total_b = 0;
+      if (env_mb > 0) budget = (size_t)env_mb << 20;
+      else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+        budget = std::min<size_t>((size_t)64 << 30, std::max<size_t>((size_t)4 << 30, free_b / 2));
+      else (void)hipGetLastError();
+    }
     std::vector<int> ua, ub, ia, ib, ints;
     std::unordered_map<int, int> posa, posb;
     for (int r0 = 0; r0 < rows;) {
-      // rows of the chunk: as many as fit the budget with their distinct windows (at most 1024: grid limit margin)
+      // rows of the chunk: as many as fit the budget with their distinct windows (at most 4096: grid z of the scatter)
       ua.clear(); ub.clear(); ia.clear(); ib.clear(); posa.clear(); posb.clear();
       int rr = 0;
       size_t bytes = 0;
-      while (r0 + rr < rows && rr < 1024) {
+      while (r0 + rr < rows && rr < 4096) {
         const int a = ida[r0 + rr], b = idb[r0 + rr];
         const size_t add = per_row + (posa.count(a) ? 0 : per_a) + (posb.count(b) ? 0 : per_b);
         if (rr > 0 && bytes + add > budget) break;
