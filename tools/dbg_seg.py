@@ -20,5 +20,5 @@ print('N', plan.N, 'max abs diff', d.max(), 'at lag', i, 'got', got[i], 'ref', r
 print('median abs diff', np.median(d), 'p99', np.percentile(d, 99), 'count > 1e-6:', int((d > 1e-6).sum()))
 bad = np.flatnonzero(d > 1e-6)
 print('bad lags (first 20):', bad[:20], ' ... last', bad[-5:] if len(bad) else None)
-Kb = plan.N // 4
+Kb = plan.N // 2
 print('bad lags mod Kb:', np.unique(bad % Kb)[:20], 'chunks', np.unique(bad // Kb))

@@ -31,6 +31,8 @@ struct Geom {
   int N1, N2, N2h;
   int idx_min, idx_max;   // retained lag slice of the 2n-1 lags
   int shift;    // (n-1-idx_min) mod N1 : output residue of row m1 = 0
+  int wrap;     // output positions o >= wrap belong to the negative lags (o - N): N - idx_min; N for a plan that keeps only
+                // lags >= 0 at N = n (the mirrored short-operand case of the segmented plans)
   int flags;
   int band_hi;  // whitened plans: spectra are EXACTLY zero at folded bins min(k, N-k) > band_hi (the whitening
                 // gain is 0 there), so the pair column pass never loads them; N = no band limit

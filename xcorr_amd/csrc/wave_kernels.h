@@ -792,6 +792,7 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
   const int idx_min = g.idx_min;
   const unsigned Lout = (unsigned)(g.idx_max - g.idx_min);
   const int shift = g.shift;
+  const int wrap_at = g.wrap;
   // Buffer stores through a resource that spans exactly the retained lags of this output
   // row: the hardware range check drops every out-of-range lag (negative indices wrap to
   // huge unsigned offsets), so a store needs a 32-bit offset and no compare / select /
@@ -833,7 +834,7 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
                 float v = h ? v1[it][t].y : v1[it][t].x;
                 if constexpr (UNBIAS) {
                   int o = res_l + N1 * (kk + wr + q0);
-                  if (o >= N - idx_min) o -= N;
+                  if (o >= wrap_at) o -= N;
                   int lag = o + idx_min - (n - 1);
                   lag = lag < 0 ? -lag : lag;
                   v *= (float)n / (float)(n - lag);
@@ -852,7 +853,7 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
         const float4 v = *reinterpret_cast<const float4*>(stg + sl * kTR + 4 * gq);
         const int r0 = res0 + 4 * gq;                          // residues r0 .. r0 + 3
         int o = r0 + N1 * (s + q0);
-        if (o >= N - idx_min) o -= N;                          // N, N1, r0 are multiples of 4: never splits a group
+        if (o >= wrap_at) o -= N;                          // N, N1, r0 are multiples of 4: never splits a group
         // element e is real data iff its row has kk = s - wr_e inside this pass, and retained iff
         // 0 <= o + e < Lout
         const int wr0 = (r0 < shift) ? 1 : 0, wr3 = (r0 + 3 < shift) ? 1 : 0;

@@ -306,7 +306,7 @@ struct xcx_plan {
   // windows too long for one transform (n + max|lag| beyond the planner's table, e.g. the reference's
   // production setting window_length = 86400 s, clip_lag = (0, 9 h): scripts/cc.py:25-29): the
   // correlation is assembled from blocks by a time-stacking sub-plan (see seg_run)
-  struct Seg { xcx_plan* sub = nullptr; int Bk = 0, Kb = 0, npr = 0; DevBuf segbuf, subout, stats, ptrs, pairs; };
+  struct Seg { xcx_plan* sub = nullptr; xcx_plan* subp = nullptr; int Bk = 0, Kb = 0, npr = 0; DevBuf segbuf, subout, stats, ptrs, pairs; };
   Seg* seg = nullptr;
   bool flow = false;                    // whole pair phase in one launch (k_wpair_flow), default when built
   DevBuf flow_sync;                     // cdone / rdone counters
@@ -425,7 +425,8 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
   // kPlanShortOperand (library-internal, fftn.hip): the caller guarantees that the first operand is zero
   // beyond its first idx_min + 1 samples and that only lags <= 0 are retained -- the aliases of the retained
   // lags then fall outside the linear correlation's support as soon as N >= n (chirp convolutions, the blocks of the
-  // segmented plans).
+  // segmented plans).  Mirror image (idx_min >= n - 1, segmented plans): the SECOND operand is the short one and only
+  // lags >= 0 are retained; Geom::wrap tells the row pass that no output position belongs to a negative lag.
   const long long need = (flags & kPlanShortOperand) ? (long long)n : (long long)n + maxlag;
   // choose N = 2*N1*N2h: smallest supported >= need (or == nfft)
   long long best = -1;
@@ -498,6 +499,7 @@ extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
   g.idx_max = idx_max;
   g.shift = (int)(((long long)n - 1 - idx_min) % g.N1);
   if (g.shift < 0) g.shift += g.N1;
+  g.wrap = ((flags & kPlanShortOperand) && idx_min >= n - 1) ? g.N : g.N - idx_min;
   g.flags = flags & 0xffff;
   g.band_hi = g.N;
   p->L = idx_max - idx_min;
@@ -542,6 +544,7 @@ extern "C" int xcx_plan_destroy(xcx_plan* p) {
   p->flow_sync.release();
   if (p->seg) {
     if (p->seg->sub) xcx_plan_destroy(p->seg->sub);
+    if (p->seg->subp) xcx_plan_destroy(p->seg->subp);
     DevBuf* sb[] = {&p->seg->segbuf, &p->seg->subout, &p->seg->stats, &p->seg->ptrs, &p->seg->pairs};
     for (DevBuf* b : sb) b->release();
     delete p->seg;
@@ -1068,18 +1071,18 @@ static int stack_flush(xcx_plan* p) {
   return XCX_OK;
 }
 
-static int stack_inverse(xcx_plan* p, int P, float* dout) {
+static int stack_inverse(xcx_plan* p, int P, float* dout, int first = 0, const cf* Csrc = nullptr) {
   xcx_ctx* ctx = p->ctx;
   const Geom& g = p->g;
   int rc;
   const int B = p->batch;
   const size_t tm_per = (size_t)g.N1 * (g.N2h + 1);
   if ((rc = p->T.ensure(ctx, sizeof(cf) * tm_per * B * 2 * (p->dual ? p->nchains : 1)))) return rc;
-  const cf* src = (const cf*)p->gramC.ptr;
-  if (p->flow) return flow_run(p, 0, (size_t)P, -1, dout, src);
-  if (p->dual) return dual_run(p, 0, (size_t)P, -1, dout, src);
+  const cf* src = Csrc ? Csrc : (const cf*)p->gramC.ptr;
+  if (p->flow) return flow_run(p, (size_t)first, (size_t)P, -1, dout, src);
+  if (p->dual) return dual_run(p, (size_t)first, (size_t)P, -1, dout, src);
   for (size_t d0 = 0; d0 < (size_t)P; d0 += B)
-    if ((rc = pair_batch(p, d0, (int)std::min((size_t)B, P - d0), dout, -1, src))) return rc;
+    if ((rc = pair_batch(p, first + d0, (int)std::min((size_t)B, P - d0), dout, -1, src))) return rc;
   return XCX_OK;
 }
 
@@ -1664,7 +1667,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 template <int SG, int R>
 __global__ __launch_bounds__(256) void k_seg_gram(const cf* __restrict__ X, size_t pitch, int nfreq, int NS, int nb, int nc,
                                                    size_t slotB, const int* __restrict__ ia, const int* __restrict__ ib,
-                                                   const int* __restrict__ grp, int G, int gy, cf* __restrict__ C) {
+                                                   const int* __restrict__ grp, int G, int gy, cf* __restrict__ C,
+                                                   const double* __restrict__ su, const int* __restrict__ rx,
+                                                   const int* __restrict__ ry, int scaled, int seg_first) {
   // One wave = 64 frequencies of one group of rows; the waves of a workgroup take four groups at the SAME frequencies,
   // and the frequency tiles are dealt to the XCDs (tile f on XCD f mod 8, workgroup ids go round the XCDs): all groups
   // of a tile run back to back on one XCD, so every window's 512 bytes of the tile are fetched into that L2 once and
@@ -1729,17 +1734,25 @@ __global__ __launch_bounds__(256) void k_seg_gram(const cf* __restrict__ X, size
 #pragma unroll
     for (int j = 0; j + 1 < SG; ++j) w[j] = w[j + kSegUB];
   }
+  // acc = B conj(A): the cross-spectrum of (block, segment), lags <= 0 of the sub-plan `sub`; its conjugate is the one of
+  // (segment, block), lags >= 0 of `subp` (seg_first).  scaled: 1 / (|x| |y|) of the row goes in here, and the inverse
+  // transforms write the row's lags in place.
 #pragma unroll
-  for (int i = 0; i < R; ++i)
+  for (int i = 0; i < R; ++i) {
+    float sx = 1.f;
+    if (scaled) sx = (float)(1.0 / (sqrt(su[2 * rx[r[i]] + 1]) * sqrt(su[2 * ry[r[i]] + 1])));
+    const float sy = seg_first ? -sx : sx;
 #pragma unroll
     for (int j = 0; j < SG; ++j)
       if (c0 + j < nc) {                             // streamed: nothing reads C before the inverse's column pass
         float* dst = reinterpret_cast<float*>(C + ((size_t)r[i] * nc + c0 + j) * pitch + k);
-        __builtin_nontemporal_store(acc[i][j].x, dst);
-        __builtin_nontemporal_store(acc[i][j].y, dst + 1);
+        __builtin_nontemporal_store(acc[i][j].x * sx, dst);
+        __builtin_nontemporal_store(acc[i][j].y * sy, dst + 1);
       }
+  }
 }
-using SegGramFn = void (*)(const cf*, size_t, int, int, int, int, size_t, const int*, const int*, const int*, int, int, cf*);
+using SegGramFn = void (*)(const cf*, size_t, int, int, int, int, size_t, const int*, const int*, const int*, int, int, cf*,
+                           const double*, const int*, const int*, int, int);
 struct SegGramVar { int sg; SegGramFn fn1, fn2; };
 static const SegGramVar kSegGram[] = {{3, k_seg_gram<3, 1>, k_seg_gram<3, 2>}, {6, k_seg_gram<6, 1>, k_seg_gram<6, 2>},
                                       {9, k_seg_gram<9, 1>, k_seg_gram<9, 2>}, {12, k_seg_gram<12, 1>, k_seg_gram<12, 2>}};
@@ -1754,12 +1767,13 @@ static const SegGramVar& seg_gram_pick(int nc, int nb) {
   return *best;
 }
 
-// sub[(r*nc + c)][Kb-1-k'] -> out[r][...]: lag k = k0 + (c0+c) Kb + k' (the sub-plan's lags run -(Kb-1) .. 0; sign -1 for
-// the exchanged roles)
+// sub[(r*nc + c)][rev ? Kb-1-k' : k'] -> out[r][...]: lag k = k0 + (c0+c) Kb + k' (rev: the lags of `sub` run -(Kb-1) .. 0;
+// sign -1 for the exchanged roles)
 __global__ __launch_bounds__(256) void k_seg_scatter(const float* __restrict__ sub, const double* __restrict__ su,
                                                       const int* __restrict__ rx, const int* __restrict__ ry, int flags,
                                                       long n, int Kb, int nc, int c0, long k0, long kend /*exclusive*/,
-                                                      int sign, long idx_min, long L, float* __restrict__ out, long ld_out) {
+                                                      int sign, int rev, long idx_min, long L, float* __restrict__ out,
+                                                      long ld_out) {
   const int r = blockIdx.z, c = blockIdx.y;
   double scale = 1.0;
   if (flags & XCX_F_NORMALIZE) scale = 1.0 / (sqrt(su[2 * rx[r] + 1]) * sqrt(su[2 * ry[r] + 1]));
@@ -1767,7 +1781,7 @@ __global__ __launch_bounds__(256) void k_seg_scatter(const float* __restrict__ s
   const int kk0 = blockIdx.x * (256 * kSegU) + threadIdx.x;
   float sv[kSegU];
 #pragma unroll
-  for (int u = 0; u < kSegU; ++u) sv[u] = srow[Kb - 1 - min(kk0 + u * 256, Kb - 1)];
+  for (int u = 0; u < kSegU; ++u) { const int kq = min(kk0 + u * 256, Kb - 1); sv[u] = srow[rev ? Kb - 1 - kq : kq]; }
 #pragma unroll
   for (int u = 0; u < kSegU; ++u) {
     const int kk = kk0 + u * 256;
@@ -1809,6 +1823,10 @@ static int seg_plan_create(xcx_ctx* ctx, int n, int idx_min, int idx_max, int fl
   const int npr = p->seg->npr;
   // first operand = block (zero beyond Bk = idx_min samples), lags -(Kb-1) .. 0: no alias at N = npr
   int rc = xcx_plan_cc1d(ctx, npr, 0, npr - p->seg->Kb, npr, XCX_F_STACK | kPlanShortOperand, &p->seg->sub);
+  if (rc) { xcx_plan_destroy(p); return rc; }
+  // the mirror image for the non-negative lags: (segment, block), the SECOND operand is the short one, lags 0 .. Kb-1 --
+  // alias-free at N = npr by the same argument; its inverse writes a chunk of lags in rising order
+  rc = xcx_plan_cc1d(ctx, npr, 0, npr - 1, npr - 1 + p->seg->Kb, XCX_F_STACK | kPlanShortOperand, &p->seg->subp);
   if (rc) { xcx_plan_destroy(p); return rc; }
   *out = p;
   return XCX_OK;
@@ -1914,9 +1932,7 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
       const int P = rr * nchunks;
       const size_t slotB = (size_t)na * NS, slots = slotB + (size_t)nbw * nb;
       if ((rc = sg.segbuf.ensure(ctx, sizeof(float) * slots * npr))) return rc;
-      if ((rc = sg.subout.ensure(ctx, sizeof(float) * (size_t)P * Kb))) return rc;
       if ((rc = sub->spectra.ensure(ctx, sizeof(cf) * pitch * slots))) return rc;
-      if ((rc = sub->gramC.ensure(ctx, sizeof(cf) * pitch * (size_t)P))) return rc;
       // int tables of the chunk in one upload: [ua | ub | ia | ib | rx | ry]
       ints.clear();
       ints.insert(ints.end(), ua.begin(), ua.end());
@@ -1984,26 +2000,59 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
       HIP_TRY(hipGetLastError());
       if ((rc = forward(sub, segA, (long)NS * npr, npr, NS, 0, 0, na * NS, 0))) return rc;
       if ((rc = forward(sub, segB, (long)nb * npr, npr, nb, 0, 0, nbw * nb, (int)slotB))) return rc;
+      // Orientation of the pass.  Non-negative lags of (a, b) (pass 0): the cross-spectra of (segment, block) through
+      // `subp`, whose inverse writes the Kb lags of a chunk in rising order; exchanged roles / convolution: (block,
+      // segment) through `sub`, whose lags -(Kb-1) .. 0 land in rising order of the output index as well.  Either way a
+      // FULL chunk is a run of Kb consecutive output samples of the row, and the inverse writes it in place (the row's
+      // 1 / (|x| |y|) went into the cross-spectrum); only the ragged last chunk -- its tail would run into the next
+      // row -- and rows that want the unbias weights go through the scatter kernel.
+      const bool seg_first = pass == 0;
+      xcx_plan* inv = seg_first ? sg.subp : sub;
+      const bool direct = !(flags & XCX_F_UNBIAS);
+      const int nfull = direct ? (int)((kend - k0) / Kb) : 0;          // chunks written in place
+      const int ne = nchunks - nfull;                                   // chunks through the staging rows
+      if ((rc = sub->gramC.ensure(ctx, sizeof(cf) * pitch * (size_t)P))) return rc;      // one buffer for both orientations
       const SegGramVar& gv = seg_gram_pick(nchunks, nb);
       const int gy = (nchunks + gv.sg - 1) / gv.sg, tiles8 = ((nfreq + 63) / 64 + 7) / 8;      // tiles per XCD
       auto gram_grid = [&](int G) { return dim3((unsigned)(8 * (size_t)tiles8 * ((G + 3) / 4) * gy)); };
+      const int scaled = direct && (flags & XCX_F_NORMALIZE) ? 1 : 0;
       if (n2 > 0)
         hipLaunchKernelGGL(gv.fn2, gram_grid(n2), dim3(256), 0, ctx->stream, (const cf*)sub->spectra.ptr, pitch, nfreq,
-                           NS, nb, nchunks, slotB, d_ia, d_ib, d_g2, n2, gy, (cf*)sub->gramC.ptr);
+                           NS, nb, nchunks, slotB, d_ia, d_ib, d_g2, n2, gy, (cf*)sub->gramC.ptr, (const double*)su, d_rx, d_ry,
+                           scaled, seg_first ? 1 : 0);
       if (n1 > 0)
         hipLaunchKernelGGL(gv.fn1, gram_grid(n1), dim3(256), 0, ctx->stream, (const cf*)sub->spectra.ptr, pitch, nfreq,
-                           NS, nb, nchunks, slotB, d_ia, d_ib, d_g1, n1, gy, (cf*)sub->gramC.ptr);
+                           NS, nb, nchunks, slotB, d_ia, d_ib, d_g1, n1, gy, (cf*)sub->gramC.ptr, (const double*)su, d_rx, d_ry,
+                           scaled, seg_first ? 1 : 0);
       HIP_TRY(hipGetLastError());
-      // one inverse per (row, chunk): descriptor q reads row q of the cross-spectrum buffer, writes Kb lags at q Kb
-      sub->hdescs.resize(P);
-      for (int q = 0; q < P; ++q) sub->hdescs[q] = PwDesc{q, q, (long long)q * Kb};
-      sub->desc_key = 0; sub->gram_key = 0;
-      if ((rc = upload(ctx, sub->descs, sub->hdescs.data(), (size_t)P * sizeof(PwDesc)))) return rc;
-      if ((rc = stack_inverse(sub, P, (float*)sg.subout.ptr))) return rc;
-      hipLaunchKernelGGL(k_seg_scatter, dim3((Kb + 256 * kSegU - 1) / (256 * kSegU), nchunks, rr), dim3(256), 0, ctx->stream,
-                         (const float*)sg.subout.ptr, (const double*)su, d_rx, d_ry, flags, n, Kb, nchunks, 0, k0, kend,
-                         pass == 0 ? 1 : -1, idx_min_eff, L_eff, out + (size_t)r0 * ld_out, ld_out);
-      HIP_TRY(hipGetLastError());
+      // one inverse per (row, chunk): descriptor (slot q = row of the cross-spectrum buffer, output offset).  First the
+      // chunks written in place (offsets into `out`), then the staged ones ([row][edge chunk][Kb])
+      inv->hdescs.resize(P);
+      {
+        int d = 0;
+        for (int r = 0; r < rr; ++r)
+          for (int c = 0; c < nfull; ++c) {
+            const long kc = k0 + (long)c * Kb;                          // first lag of the chunk
+            const long j0 = seg_first ? (n - 1) + kc - idx_min_eff : (n - 1) - (kc + Kb - 1) - idx_min_eff;
+            inv->hdescs[d++] = PwDesc{r * nchunks + c, r * nchunks + c, (long long)(r0 + r) * ld_out + j0};
+          }
+        for (int r = 0; r < rr; ++r)
+          for (int c = nfull; c < nchunks; ++c)
+            inv->hdescs[d++] = PwDesc{r * nchunks + c, r * nchunks + c, ((long long)r * ne + (c - nfull)) * Kb};
+      }
+      inv->desc_key = 0; inv->gram_key = 0;
+      if ((rc = upload(ctx, inv->descs, inv->hdescs.data(), (size_t)P * sizeof(PwDesc)))) return rc;
+      const int Pd = rr * nfull;
+      if (Pd > 0 && (rc = stack_inverse(inv, Pd, out, 0, (const cf*)sub->gramC.ptr))) return rc;
+      if (ne > 0) {
+        if ((rc = sg.subout.ensure(ctx, sizeof(float) * (size_t)rr * ne * Kb))) return rc;
+        if ((rc = stack_inverse(inv, rr * ne, (float*)sg.subout.ptr, Pd, (const cf*)sub->gramC.ptr))) return rc;
+        hipLaunchKernelGGL(k_seg_scatter, dim3((Kb + 256 * kSegU - 1) / (256 * kSegU), ne, rr), dim3(256), 0, ctx->stream,
+                           (const float*)sg.subout.ptr, (const double*)su, d_rx, d_ry, scaled ? (flags & ~XCX_F_NORMALIZE) : flags,
+                           n, Kb, ne, nfull, k0, kend, pass == 0 ? 1 : -1, seg_first ? 0 : 1, idx_min_eff, L_eff,
+                           out + (size_t)r0 * ld_out, ld_out);
+        HIP_TRY(hipGetLastError());
+      }
       r0 += rr;
     }
   }
