@@ -165,6 +165,32 @@ def test_split_transform_boundaries(ctx):
     assert relerr(ops.fft(ctx, c), np.fft.fft(c.astype(np.complex128), axis=-1)) < TOL
 
 
+def test_transforms_beyond_every_single_transform(ctx):
+    """Axes whose chirp convolution exceeds the longest transform (2 max(nin, nout) - 1 > 786 432) run as block-decomposed
+    convolutions (fftn.hip: bluestein_seg over seg_run's convolution mode): day-long rows (rfft of 4 320 000 samples = a
+    complex transform of 2 160 000 points), odd and prime-ish lengths, complex transforms, hilbert / envelope; the
+    stretch in between (np > 737 280 but one transform still fits 2n - 1) keeps the partial-transform route."""
+    rng = np.random.default_rng(19)
+    for n in (1000002, 1000003, 4320000, 760000):
+        x = rng.standard_normal((2, n)).astype(np.float32)
+        x[:, n // 3: n // 3 + 500] += 5.0
+        m = n - (n & 1)
+        X = ops.rfft(ctx, x)
+        ref = np.fft.rfft(x[:, :m].astype(np.float64), axis=-1)
+        assert X.shape == ref.shape and relerr(X, ref) < TOL, n
+        back = ops.irfft(ctx, X)
+        assert back.shape == (2, m) and relerr(back, x[:, :m]) < 2 * TOL, n
+    n = 400001                                             # complex, odd: nin = nout = n, 2n - 1 = 800 001
+    c = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))).astype(np.complex64)
+    assert relerr(ops.fft(ctx, c), np.fft.fft(c.astype(np.complex128), axis=-1)) < TOL
+    assert relerr(ops.ifft(ctx, c), np.fft.ifft(c.astype(np.complex128), axis=-1)) < TOL
+    n = 800001
+    x = (rng.standard_normal((1, n)) * np.hanning(n)).astype(np.float32)
+    zr = R.hilbert(x)
+    assert relerr(ops.hilbert(ctx, x), zr) < TOL
+    assert relerr(ops.hilbert(ctx, x, envelope=True), np.abs(zr)) < TOL
+
+
 def test_device_resident_transforms(ctx):
     """DeviceArray in -> DeviceArray out (complex rows as interleaved float32 pairs): the same values as the host
     path, nothing staged through the host."""

@@ -35,6 +35,9 @@ using namespace xcx;
                      __FILE__, __LINE__);                                 \
   } while (0)
 
+int xcx_internal_seg_conv(xcx_plan* p, const float* const* xs, const float* const* ks, int count, float* out, long ld);
+bool xcx_internal_segmented(xcx_plan* p);
+
 namespace {
 
 struct BsGeom {
@@ -116,12 +119,19 @@ __global__ void k_bs_pre(const float* __restrict__ in, BsGeom g, long B, float* 
 
 // out[b][k] = c[k] (R[2b][k] + i R[2b+1][k]) scale ; real_only keeps the real part
 // out_mode 0: complex, 1: real part, 2: modulus.   grid (ceil(nout / 256), B)
+// quad: four real convolutions per row (segmented path): re = R[4b] - R[4b+1], im = R[4b+2] + R[4b+3]
 __global__ void k_bs_post(const float* __restrict__ R, long ld, BsGeom g, long B, double scale, int real_only,
-                          float* __restrict__ out, const double2* __restrict__ tab) {
+                          float* __restrict__ out, const double2* __restrict__ tab, int quad = 0) {
   const long b = blockIdx.y;
   const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= g.nout || b >= B) return;
-  const double re = R[(2 * b) * ld + k], im = R[(2 * b + 1) * ld + k];
+  double re, im;
+  if (quad) {
+    const float r0 = R[(4 * b) * ld + k], r1 = R[(4 * b + 1) * ld + k], r2 = R[(4 * b + 2) * ld + k], r3 = R[(4 * b + 3) * ld + k];
+    re = (double)r0 - (double)r1; im = (double)r2 + (double)r3;
+  } else {
+    re = R[(2 * b) * ld + k]; im = R[(2 * b + 1) * ld + k];
+  }
   const double2 c = chirp_tab(tab, g.k0 + k, g.n, g.sign);
   double orr = (re * c.x - im * c.y) * scale, oi = (re * c.y + im * c.x) * scale;
   const long o = b * (g.out_pitch ? g.out_pitch : g.nout) + g.k0 + k;
@@ -213,6 +223,122 @@ int bluestein_core(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom
   return XCX_OK;
 }
 
+// Axes whose chirp convolution exceeds every single transform (day-long rows: rfft of 4.32 M samples = a complex
+// transform of 2.16 M points) as ONE block-decomposed convolution per real product (xcx_api.hip: seg_run's convolution
+// mode, the machinery of the long time shifts): rows a = in * c as (Re, Im) of nn = max(nin, nout) samples, the chirp
+// kernel over TWO spans, g[j] = conj(c)[nn - 1 - j + k0 - m0] for j < 2 nn - 1, as (Re, Im) -- shared by every row and
+// transformed once per call; the four real convolutions (Re a, Im a) x (Re g, Im g) of a row share its block
+// transforms.  Before (round 1-3): si x so partial transforms of <= 737 280 points, each two full correlations --
+// 36 of them for a day-long rfft, 848 us per row.
+// rows: tr[b][2][nn];  kernels: kr[2][2 nn - 1].   grid (ceil((2 nn - 1) / 256), B + 1): row B writes the kernels
+__global__ void k_bs_pre_seg(const float* __restrict__ in, BsGeom g, long nn, long B, float* __restrict__ tr,
+                             float* __restrict__ kr, const double2* __restrict__ tab) {
+  const long b = blockIdx.y;
+  const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) {
+    if (t >= nn) return;
+    float ar = 0.f, ai = 0.f;
+    if (t < g.nin) {
+      const long m = g.m0 + t;
+      double vr, vi = 0.0;
+      if (g.in_complex == 2) {
+        vr = in[b * g.in_pitch + 2 * m];
+        vi = in[b * g.in_pitch + 2 * m + 1];
+      } else if (g.in_complex) {
+        const float2 v = reinterpret_cast<const float2*>(in)[b * g.in_pitch + m];
+        vr = v.x; vi = v.y;
+      } else {
+        vr = in[b * g.in_pitch + m];
+      }
+      if (g.half_weights && m != 0 && 2 * m != g.n) { vr *= 2.0; vi *= 2.0; }
+      const double2 c = chirp_tab(tab, m, g.n, g.sign);
+      ar = (float)(vr * c.x - vi * c.y);
+      ai = (float)(vr * c.y + vi * c.x);
+    }
+    tr[(b * 2 + 0) * nn + t] = ar;
+    tr[(b * 2 + 1) * nn + t] = ai;
+  } else {
+    const long L = 2 * nn - 1;
+    if (t >= L) return;
+    const double2 c = chirp_tab(tab, nn - 1 - t + (g.k0 - g.m0), g.n, -g.sign);
+    kr[t] = (float)c.x;
+    kr[L + t] = (float)c.y;
+  }
+}
+
+int bluestein_seg(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom g, double scale, int real_only,
+                  int in_dev, int out_dev) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  int rc;
+  const long nn = std::max(g.nin, g.nout), L = 2 * nn - 1;
+  if (nn > 0x7fffffffL / 2) return set_err(XCX_EUNSUPPORTED, "transform length %ld too long", g.n);
+  int slot = -1;
+  for (int i = 0; i < 2; ++i) if (ctx->bs_seg_plan[i] && ctx->bs_seg_n[i] == nn) slot = i;
+  if (slot < 0) {                                   // two cached plans, replaced in turn
+    slot = ctx->bs_seg_next;
+    ctx->bs_seg_next ^= 1;
+    if (ctx->bs_seg_plan[slot]) { xcx_plan_destroy(ctx->bs_seg_plan[slot]); ctx->bs_seg_plan[slot] = nullptr; }
+    ctx->bs_seg_n[slot] = 0;
+    if ((rc = xcx_plan_cc1d(ctx, (int)nn, 0, 0, 0, 0, &ctx->bs_seg_plan[slot]))) return rc;
+    ctx->bs_seg_n[slot] = nn;
+  }
+  xcx_plan* plan = ctx->bs_seg_plan[slot];
+  if (!xcx_internal_segmented(plan)) return set_err(XCX_EUNSUPPORTED, "bluestein_seg: %ld points fit one transform", nn);
+  if (ctx->bs_tab_n != g.n || !ctx->bs_tab.ptr) {
+    ctx->bs_tab_n = 0;
+    if ((rc = ctx->bs_tab.ensure(ctx, sizeof(double2) * (size_t)(g.n + 1)))) return rc;
+    hipLaunchKernelGGL(k_chirp_table, dim3((unsigned)((g.n + 256) / 256)), dim3(256), 0, ctx->stream, (double2*)ctx->bs_tab.ptr, g.n);
+    HIP_TRY(hipGetLastError());
+    ctx->bs_tab_n = g.n;
+  }
+  const double2* tab = (const double2*)ctx->bs_tab.ptr;
+  const long chunk = std::max<long>(1, std::min<long>(batch, ((long)2048 << 20) / (24 * nn)));     // 6 nn floats per row
+  DevBuf &tr = ctx->scratch[1], &lin = ctx->scratch[2], &din = ctx->scratch[4], &dout = ctx->scratch[5];
+  if ((rc = tr.ensure(ctx, sizeof(float) * (2 * nn * chunk + 2 * L)))) return rc;          // rows, then the two kernel rows
+  if ((rc = lin.ensure(ctx, sizeof(float) * 4 * nn * chunk))) return rc;
+  float* krp = (float*)tr.ptr + 2 * nn * chunk;
+  const size_t in_row = (size_t)g.in_pitch * (g.in_complex == 1 ? 8 : 4);
+  const size_t out_row = (size_t)(g.out_pitch ? g.out_pitch : g.nout) * (real_only ? 4 : 8);
+  HostPin pin_in(in_dev ? nullptr : in, in_row * (size_t)batch);
+  HostPin pin_out(out_dev ? nullptr : out, out_row * (size_t)batch);
+  const float* ind = in;
+  float* outd = out;
+  if (!in_dev) {
+    if ((rc = din.ensure(ctx, in_row * batch))) return rc;
+    HIP_TRY(hipMemcpyAsync(din.ptr, in, in_row * batch, hipMemcpyHostToDevice, ctx->stream));
+    ind = (const float*)din.ptr;
+  }
+  if (!out_dev) {
+    if ((rc = dout.ensure(ctx, out_row * batch))) return rc;
+    outd = (float*)dout.ptr;
+  }
+  std::vector<const float*> xs, ks;
+  const float* gr = krp;
+  const float* gi = gr + L;
+  for (long r0 = 0; r0 < batch; r0 += chunk) {
+    const long cnt = std::min(chunk, batch - r0);
+    hipLaunchKernelGGL(k_bs_pre_seg, dim3((unsigned)((L + 255) / 256), (unsigned)(cnt + 1)), dim3(256), 0, ctx->stream,
+                       (const float*)((const char*)ind + in_row * r0), g, nn, cnt, (float*)tr.ptr, krp, tab);
+    HIP_TRY(hipGetLastError());
+    xs.resize(4 * cnt); ks.resize(4 * cnt);
+    for (long b = 0; b < cnt; ++b) {
+      const float* ar = (const float*)tr.ptr + (2 * b) * nn;
+      const float* ai = ar + nn;
+      xs[4 * b + 0] = ar; ks[4 * b + 0] = gr;           // Re = ar*gr - ai*gi
+      xs[4 * b + 1] = ai; ks[4 * b + 1] = gi;
+      xs[4 * b + 2] = ar; ks[4 * b + 2] = gi;           // Im = ar*gi + ai*gr
+      xs[4 * b + 3] = ai; ks[4 * b + 3] = gr;
+    }
+    if ((rc = xcx_internal_seg_conv(plan, xs.data(), ks.data(), (int)(4 * cnt), (float*)lin.ptr, nn))) return rc;
+    hipLaunchKernelGGL(k_bs_post, dim3((unsigned)((g.nout + 255) / 256), (unsigned)cnt), dim3(256), 0, ctx->stream,
+                       (const float*)lin.ptr, nn, g, cnt, scale, real_only, (float*)((char*)outd + out_row * r0), tab, 1);
+    HIP_TRY(hipGetLastError());
+  }
+  if (!out_dev) HIP_TRY(hipMemcpyAsync(out, outd, out_row * batch, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return XCX_OK;
+}
+
 // Any length: an axis whose chirp convolution (nin + nout - 1 points) exceeds the longest
 // correlation plan is split into si input blocks x so output blocks,
 //     out[k0 + u] = sum over input blocks of  c[k] sum_t (in[m0+t] c[m0+t]) conj(c)[(k0+u) - (m0+t)],
@@ -223,6 +349,8 @@ int bluestein(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom g, d
   if (!ctx || !in || !out) return set_err(XCX_EINVAL, "null argument");
   if (batch < 1 || g.n < 2) return set_err(XCX_EINVAL, "batch >= 1 and n >= 2 required");
   if (g.nin + g.nout - 1 <= kBsMaxNp) return bluestein_core(ctx, in, out, batch, g, scale, real_only, in_dev, out_dev);
+  if (2 * std::max(g.nin, g.nout) - 1 > kMaxTransformN)      // beyond every single transform: block convolution
+    return bluestein_seg(ctx, in, out, batch, g, scale, real_only, in_dev, out_dev);
   if (real_only == 2) return set_err(XCX_EINVAL, "modulus output of a split transform goes through a complex buffer");
   long si = 1, so = 1;
   auto np_of = [&](long a, long b) { return (g.nin + a - 1) / a + (g.nout + b - 1) / b - 1; };
@@ -437,13 +565,20 @@ extern "C" int xcx_resample(xcx_ctx* ctx, const float* x, float* y, long batch, 
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     dw = (const float*)dwin.ptr;
   }
-  BsGeom gf{npts, nh, npts, 0, -1, 0, 0, npts};                // rfft of all npts samples
-  if ((rc = bluestein(ctx, x, (float*)sx.ptr, batch, gf, 1.0, 0, on_device, 1))) return rc;
+  // rfft of all npts samples: even lengths as ONE complex transform of half the length (rfft_even)
+  if (npts % 2 == 0 && npts >= 4) {
+    if ((rc = rfft_even(ctx, x, npts, (float*)sx.ptr, batch, npts, on_device, 1))) return rc;
+  } else {
+    BsGeom gf{npts, nh, npts, 0, -1, 0, 0, npts};
+    if ((rc = bluestein(ctx, x, (float*)sx.ptr, batch, gf, 1.0, 0, on_device, 1))) return rc;
+  }
   const long total = batch * mh;
   hipLaunchKernelGGL(k_resample_spec, dim3((unsigned)std::min<long>((total + 255) / 256, 256L * 16)), dim3(256), 0,
                      ctx->stream, (const float2*)sx.ptr, nh, dw, (float2*)sy.ptr, mh, ratio, batch);
   HIP_TRY(hipGetLastError());
-  BsGeom gi{mh, num, num, 0, +1, 1, 1, mh};                    // irfft to num samples (odd or even)
+  // irfft to num samples, times num / npts: even num through the packed form as well
+  if (num % 2 == 0 && num >= 4) return irfft_even(ctx, (const float*)sy.ptr, mh, y, batch, num, 1.0 / (double)npts, 1, on_device);
+  BsGeom gi{mh, num, num, 0, +1, 1, 1, mh};
   return bluestein(ctx, (const float*)sy.ptr, y, batch, gi, 1.0 / (double)npts, 1, 1, on_device);
 }
 

@@ -148,6 +148,7 @@ extern "C" int xcx_destroy(xcx_ctx* ctx) {
   xcx_comm_destroy(ctx);
   if (ctx->ts_plan) xcx_plan_destroy(ctx->ts_plan);
   for (auto* bp : ctx->bs_plan) if (bp) xcx_plan_destroy(bp);
+  for (auto* bp : ctx->bs_seg_plan) if (bp) xcx_plan_destroy(bp);
   ctx->sg_tab.release();
   for (auto& t : ctx->sos_tab) t.release();
   ctx->bs_tab.release();

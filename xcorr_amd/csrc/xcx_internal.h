@@ -57,6 +57,8 @@ struct xcx_ctx {
   long ts_n = 0;
   bool ts_direct = false;               // ts_plan correlates against the period-extended kernel (timeshift.hip)
   struct xcx_plan* bs_plan[2] = {nullptr, nullptr};   // cached plans of the Bluestein FFTs (fftn.hip)
+  struct xcx_plan* bs_seg_plan[2] = {nullptr, nullptr}; long bs_seg_n[2] = {0, 0}; int bs_seg_next = 0;   // ... and the segmented plans of
+                                        // the long axes (chirp convolution in blocks); two: a resample alternates between two lengths
   long bs_key[2][3] = {{0, 0, 0}, {0, 0, 0}};
   int bs_next = 0;
   xcx::DevBuf bs_tab;                    // chirp exp(i pi j^2 / n), j <= n, of the last transform length (fftn.hip)
