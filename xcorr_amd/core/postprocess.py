@@ -14,6 +14,7 @@ import numpy as np
 from .. import ops
 from ..engine import default_context
 from .init import CCDataset
+from ..signal.ops1d import butter_design
 
 __all__ = ['postprocess', 'postprocess_rows']
 
@@ -40,7 +41,7 @@ def postprocess_rows(rows, delay, sampling_rate, npts, index_min, index_max, fil
     ops.post_prep(ctx, d, npts, index_min, index_max, unbiased=True,
                   taper_nmax=int(round(5. * fs)))                   # taper: timeshift phase wrapping
     y = ops.timeshift(ctx, d, np.asarray(delay, np.float64).reshape(-1), fs)
-    sos = scipy.signal.butter(N=fk['order'], Wn=fk['frequency'], btype=fk['btype'], output='sos', fs=fs)
+    sos = butter_design(fk['order'], fk['frequency'], fk['btype'], fs)
     ops.sosfiltfilt(ctx, y, sos)
     ops.taper(ctx, y, int(round(1.5 * fs)))                         # filter artefacts
     if host:

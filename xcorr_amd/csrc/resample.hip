@@ -29,6 +29,9 @@ using namespace xcx;
                      __FILE__, __LINE__);                                 \
   } while (0)
 
+int xcx_internal_sosfilt_decimate(xcx_ctx* ctx, const float* x, long batch, long n, const double* sos, int K, float* dst,
+                                  long nout, long factor);
+
 namespace {
 
 constexpr int NT = 256;
@@ -154,6 +157,10 @@ extern "C" int xcx_decimate(xcx_ctx* ctx, const float* x, float* y, long batch, 
   int rc = io.begin(ctx, x, in_bytes, y, sizeof(float) * (size_t)batch * nout, on_device);
   if (rc) return io.end(rc);
   const float* src = io.in_d;
+  if (n_sections > 0 && factor <= 64) {
+    // the filter's last pass stores only the samples that are kept (sos.hip: Decim)
+    return io.end(xcx_internal_sosfilt_decimate(ctx, io.in_d, batch, n, sos, n_sections, io.out_d, nout, factor));
+  }
   if (n_sections > 0) {
     DevBuf& work = ctx->scratch[7];                        // the filter runs in place on a copy
     if ((rc = work.ensure(ctx, in_bytes))) return io.end(rc);

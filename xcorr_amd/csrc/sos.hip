@@ -42,6 +42,9 @@ constexpr int kMaxK = 8;          // sections
 constexpr int kTile = 64;
 
 struct SosCoef { double b0, b1, b2, a1, a2; };
+// decimating output of a forward pass (xcx_decimate): the filtered samples t = 0, factor, 2 factor, ... of row r go to
+// dst[r * stride + t / factor] and x is left as it is (factor <= 64)
+struct Decim { float* dst = nullptr; long stride = 0; int factor = 1; };
 struct SosParams { int K; SosCoef c[kMaxK]; };
 
 template <int K>
@@ -77,7 +80,7 @@ template <int K, bool REVERSE, bool WRITE>
 __global__ __launch_bounds__(64) void k_sos_tiles(
     float* __restrict__ x, long row_stride, long n, long Lc, int nchunks,
     long nseq, SosParams P, const double* __restrict__ s0,
-    double* __restrict__ send) {
+    double* __restrict__ send, Decim dc = Decim{}) {
   __shared__ float tile[kTile][kTile + 1];
   const int lane = threadIdx.x;
   const long q0 = (long)blockIdx.x * 64;
@@ -102,33 +105,103 @@ __global__ __launch_bounds__(64) void k_sos_tiles(
   // sequence i's address and length from lane i (no 64-bit divisions in the loop)
   long mybase = 0;
   if (live) mybase = (q / nchunks) * row_stride + (q % nchunks) * Lc;
-  for (long t0 = 0; t0 < Lc; t0 += kTile) {
-    // coalesced load: 64 consecutive samples of sequence i per instruction
-    // 16 loads in flight at a time (a rolled load -> LDS-store loop would wait out one
-    // memory round trip per sequence); lanes beyond nact hold mylen = 0 and load nothing
-    for (int i0 = 0; i0 < 64; i0 += 16) {
-      float v[16];
+  // coalesced load: 64 consecutive samples of sequence i per instruction, all 64 sequences of a tile issued together
+  // into registers (lanes beyond nact hold mylen = 0 and load nothing).  The NEXT tile is fetched while this one is
+  // filtered and written back: with ~2.3 waves per SIMD (the LDS tile) the kernel otherwise sat out four memory round
+  // trips per tile with nothing to do (skewing the sections alone, K independent chains, changed nothing).
+  float nx[kTile];
+  auto fetch = [&](long t0) {
 #pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        const long base = lane_bcast(mybase, i0 + k);
-        const long len = lane_bcast(mylen, i0 + k);
-        const long u = t0 + lane;               // step index within the sequence
-        const long t = REVERSE ? (len - 1 - u) : u;
-        v[k] = (u < len) ? x[base + t] : 0.f;
-      }
-#pragma unroll
-      for (int k = 0; k < 16; ++k) tile[i0 + k][lane] = v[k];
+    for (int k = 0; k < kTile; ++k) {
+      const long base = lane_bcast(mybase, k);
+      const long len = lane_bcast(mylen, k);
+      const long u = t0 + lane;               // step index within the sequence
+      const long t = REVERSE ? (len - 1 - u) : u;
+      nx[k] = (u < len) ? x[base + t] : 0.f;
     }
+  };
+  fetch(0);
+  for (long t0 = 0; t0 < Lc; t0 += kTile) {
+#pragma unroll
+    for (int k = 0; k < kTile; ++k) tile[k][lane] = nx[k];
     __syncthreads();
-    if (live) {
-      const int steps = (int)std::min((long)kTile, mylen - t0);
+    if (t0 + kTile < Lc) fetch(t0 + kTile);
+    const int steps = live ? (int)std::max(0L, std::min((long)kTile, mylen - t0)) : 0;
+    if (K > 1 && __builtin_amdgcn_ballot_w64(live && steps != kTile) == 0) {
+      // Whole tiles (all but the ragged end of a short last chunk), the sections SKEWED in time: in step s section k
+      // works on sample s - k, taking what section k-1 produced one step earlier (pipe[k]).  Every section still sees
+      // its inputs in order and performs the same operations -- the results are bit for bit those of the sample-by-
+      // sample cascade -- but the K section updates of a step do not depend on each other: K chains of three dependent
+      // float64 operations in flight instead of one chain of 3 K (the kernel runs at ~2.3 waves per SIMD on its LDS
+      // tile; it was bound by that latency chain, not by the float64 issue rate).  Lanes without a sequence run on zeros.
+      double pipe[K];
+#pragma unroll
+      for (int k = 0; k < K; ++k) pipe[k] = 0.0;
+      auto section = [&](int k, double v) {
+        const SosCoef c = P.c[k];
+        const double y = fma(c.b0, v, z[k][0]);
+        z[k][0] = fma(c.b1, v, fma(-c.a1, y, z[k][1]));
+        z[k][1] = fma(c.b2, v, -c.a2 * y);
+        return y;
+      };
+      // prologue: steps 0 .. K-2, sections 0 .. s
+#pragma unroll
+      for (int st = 0; st < K - 1; ++st) {
+#pragma unroll
+        for (int k = K - 2; k >= 0; --k)
+          if (k <= st) pipe[k + 1] = section(k, k == 0 ? (double)tile[lane][st] : pipe[k]);
+      }
+      // steady state: every section busy
+      for (int st = K - 1; st < kTile; ++st) {
+        const double yl = section(K - 1, pipe[K - 1]);
+#pragma unroll
+        for (int k = K - 2; k >= 0; --k) pipe[k + 1] = section(k, k == 0 ? (double)tile[lane][st] : pipe[k]);
+        if (WRITE) tile[lane][st - (K - 1)] = (float)yl;
+      }
+      // epilogue: steps kTile .. kTile + K - 2, sections s - kTile + 1 .. K - 1
+#pragma unroll
+      for (int e = 0; e < K - 1; ++e) {
+        const double yl = section(K - 1, pipe[K - 1]);
+#pragma unroll
+        for (int k = K - 2; k >= 1; --k)
+          if (k > e) pipe[k + 1] = section(k, pipe[k]);
+        if (WRITE) tile[lane][kTile - (K - 1) + e] = (float)yl;
+      }
+    } else if (live) {
       for (int u = 0; u < steps; ++u) {
         const double y = sos_step<K>(P, z, (double)tile[lane][u]);
         if (WRITE) tile[lane][u] = (float)y;
       }
     }
     __syncthreads();
-    if (WRITE) {
+    if (WRITE && !REVERSE && dc.dst) {
+      // every factor-th sample of the ROW: the tile of sequence i starts at row sample g0 = chunk Lc + t0 = factor qd + rd
+      // (one division per lane and tile, for its own sequence); lane l holds sample g0 + l, kept iff (rd + l) % factor == 0.
+      // (rd + l) / factor by a 16-bit reciprocal: exact for (rd + l) factor < 65536
+      long dbase = 0;
+      int rd = 0;
+      if (live) {
+        const long g0 = (q % nchunks) * Lc + t0;
+        const long qd = g0 / dc.factor;
+        rd = (int)(g0 - qd * dc.factor);
+        dbase = (q / nchunks) * dc.stride + qd;
+      }
+      const unsigned M = (65536u + (unsigned)dc.factor - 1u) / (unsigned)dc.factor;
+      for (int i0 = 0; i0 < 64; i0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = tile[i0 + k][lane];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const long base = lane_bcast(dbase, i0 + k);
+          const long len = lane_bcast(mylen, i0 + k);
+          const unsigned e = (unsigned)__builtin_amdgcn_readlane(rd, i0 + k) + (unsigned)lane;
+          const unsigned ed = (e * M) >> 16;
+          if (t0 + lane < len && ed * (unsigned)dc.factor == e) dc.dst[base + ed] = v[k];
+        }
+      }
+      __syncthreads();
+    } else if (WRITE) {
       // 16 sequences per trip: the LDS reads of a trip are issued together (lanes beyond nact have len = 0)
       for (int i0 = 0; i0 < 64; i0 += 16) {
         float v[16];
@@ -397,10 +470,10 @@ void sosfilt_zi(const SosParams& P, std::vector<double>& zi) {
 
 template <int K, bool REV, bool WR>
 hipError_t launch_tiles(xcx_ctx* ctx, float* x, long row_stride, long n, long Lc, int nchunks,
-                        long nseq, const SosParams& P, const double* s0, double* send) {
+                        long nseq, const SosParams& P, const double* s0, double* send, Decim dc = Decim{}) {
   const unsigned grid = (unsigned)((nseq + 63) / 64);
   hipLaunchKernelGGL((k_sos_tiles<K, REV, WR>), dim3(grid), dim3(64), 0, ctx->stream, x, row_stride,
-                     n, Lc, nchunks, nseq, P, s0, send);
+                     n, Lc, nchunks, nseq, P, s0, send, dc);
   return hipGetLastError();
 }
 
@@ -410,19 +483,23 @@ hipError_t launch_tiles(xcx_ctx* ctx, float* x, long row_stride, long n, long Lc
 template <int K, bool REV>
 int run_pass(xcx_ctx* ctx, float* x, long rows, long n, const SosParams& P,
              const double* init, double* fend, DevBuf& zbuf, DevBuf& /*unused: matrices live in ctx->sos_tab*/,
-             long row_stride = 0) {
+             long row_stride = 0, Decim dc = Decim{}) {
   if (row_stride == 0) row_stride = n;                 // dense rows; > n: a column range of wider rows
   const int D = 2 * K;
   long Lc = n;
   int nchunks = 1;
   if (rows < 8192 && n > 4096) {          // few long rows: chunked scan
     Lc = 1024;
+    // a wave walks 64 chunks; a handful of day-long rows at 1024 samples per chunk is ~1 000 waves, one per SIMD, and the
+    // kernel then waits out every memory round trip and dependent operation alone (SQ counters: 34 % of a wave's cycles
+    // issue VALU, the CUs hold 1-2 waves of the 9 their LDS allows): shorter chunks until there are ~8 waves per CU
+    while (Lc > 128 && rows * ((n + Lc - 1) / Lc) < 131072) Lc /= 2;
     while ((n + Lc - 1) / Lc > 65536) Lc *= 2;
     nchunks = (int)((n + Lc - 1) / Lc);
   }
   const long nseq = rows * nchunks;
   if (nchunks == 1) {
-    HIP_TRY((launch_tiles<K, REV, true>(ctx, x, row_stride, n, Lc, 1, nseq, P, init, fend)));
+    HIP_TRY((launch_tiles<K, REV, true>(ctx, x, row_stride, n, Lc, 1, nseq, P, init, fend, dc)));
     return XCX_OK;
   }
   int rc;
@@ -482,7 +559,7 @@ int run_pass(xcx_ctx* ctx, float* x, long rows, long n, const SosParams& P,
                      ctx->stream, Z, (const double*)E, PW, PWs, D, nchunks, G, rows, (int)REV);
   HIP_TRY(hipGetLastError());
   // re-run from the true start states; end states land back in Z
-  HIP_TRY((launch_tiles<K, REV, true>(ctx, x, row_stride, n, Lc, nchunks, nseq, P, Z, fend ? Z : nullptr)));
+  HIP_TRY((launch_tiles<K, REV, true>(ctx, x, row_stride, n, Lc, nchunks, nseq, P, Z, fend ? Z : nullptr, dc)));
   if (fend) {
     // the row's end state is that of its last-processed chunk
     const int endc = REV ? 0 : nchunks - 1;
@@ -579,6 +656,31 @@ int filt_entry(xcx_ctx* ctx, float* x, long batch, long n, const double* sos, in
 }
 
 }  // namespace
+
+// xcx_decimate (resample.hip): the causal filter from rest, every factor-th output sample written to dst rows of `nout`
+// samples, x untouched (device pointers): the zero-state pass reads x, the pass from the true chunk states reads it again
+// and stores only what is kept -- no working copy, no in-place rewrite, no gather pass
+int xcx_internal_sosfilt_decimate(xcx_ctx* ctx, const float* x, long batch, long n, const double* sos, int K, float* dst,
+                                  long nout, long factor) {
+  if (factor < 1 || factor > 64) return set_err(XCX_EINVAL, "decimating filter pass: factor %ld outside [1, 64]", factor);
+  SosParams P;
+  int rc = parse_sos(sos, K, P);
+  if (rc) return rc;
+  HIP_TRY(hipSetDevice(ctx->device));
+  DevBuf &zbuf = ctx->scratch[1], &mbuf = ctx->scratch[2];
+  float* xx = const_cast<float*>(x);                  // never written: every writing pass has a destination of its own
+  const Decim dc{dst, nout, (int)factor};
+  switch (K) {
+    case 1: return run_pass<1, false>(ctx, xx, batch, n, P, nullptr, nullptr, zbuf, mbuf, 0, dc);
+    case 2: return run_pass<2, false>(ctx, xx, batch, n, P, nullptr, nullptr, zbuf, mbuf, 0, dc);
+    case 3: return run_pass<3, false>(ctx, xx, batch, n, P, nullptr, nullptr, zbuf, mbuf, 0, dc);
+    case 4: return run_pass<4, false>(ctx, xx, batch, n, P, nullptr, nullptr, zbuf, mbuf, 0, dc);
+    case 5: return run_pass<5, false>(ctx, xx, batch, n, P, nullptr, nullptr, zbuf, mbuf, 0, dc);
+    case 6: return run_pass<6, false>(ctx, xx, batch, n, P, nullptr, nullptr, zbuf, mbuf, 0, dc);
+    case 7: return run_pass<7, false>(ctx, xx, batch, n, P, nullptr, nullptr, zbuf, mbuf, 0, dc);
+    default: return run_pass<8, false>(ctx, xx, batch, n, P, nullptr, nullptr, zbuf, mbuf, 0, dc);
+  }
+}
 
 extern "C" int xcx_sosfiltfilt(xcx_ctx* ctx, float* x, long batch, long n, const double* sos,
                                int n_sections, int on_device) {

@@ -1,4 +1,6 @@
 """numpy-level + DataArray-level implementations (see package docstring)."""
+import functools
+
 import numpy as np
 
 from .. import ops as _ops
@@ -202,6 +204,19 @@ def taper(x, wtype=None, max_percentage=None, max_length=None, side=None,
 
 
 # -- a9: signal/filter.py:27-120 -------------------------------------------------
+def butter_design(order, frequency, btype, sampling_rate):
+    """``scipy.signal.butter(N, Wn, btype, output='sos', fs)`` (signal/filter.py:86-92), cached per argument set: a design
+    costs 0.3 ms of host time, every call of the post-correlation chain asked for the same one."""
+    wn = tuple(float(f) for f in frequency) if isinstance(frequency, (tuple, list, np.ndarray)) else float(frequency)
+    return _butter_design(int(order), wn, str(btype), float(sampling_rate)).copy()
+
+
+@functools.lru_cache(maxsize=64)
+def _butter_design(order, wn, btype, fs):
+    import scipy.signal
+    return scipy.signal.butter(N=order, Wn=list(wn) if isinstance(wn, tuple) else wn, btype=btype, output='sos', fs=fs)
+
+
 def filter(x, frequency, btype=None, order=2, dim=None, sampling_rate=None):
     """Zero-phase Butterworth: ``butter(order, frequency, btype, 'sos', fs)``
     designed on the host (scipy, microseconds), ``sosfiltfilt`` on the GPU
@@ -220,8 +235,7 @@ def filter(x, frequency, btype=None, order=2, dim=None, sampling_rate=None):
         sampling_rate = x[dim].attrs['sampling_rate']
     elif sampling_rate is None:
         raise ValueError('sampling_rate is required for array input')
-    sos = scipy.signal.butter(N=order, Wn=frequency, btype=btype,
-                              output='sos', fs=sampling_rate)
+    sos = butter_design(order, frequency, btype, sampling_rate)
     if _is_da(x):
         return _apply_da(x, dim, lambda v: _ops.sosfiltfilt(None, v, sos))
     return _ops.sosfiltfilt(None, x, sos)

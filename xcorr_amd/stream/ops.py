@@ -11,7 +11,15 @@ from . import segments as _seg
 # -- filter design (host side, scipy) -----------------------------------------
 def butter_sos(ftype, sampling_rate, corners=4, freq=None, freqmin=None, freqmax=None):
     """ObsPy ``Trace.filter('highpass'|'lowpass'|'bandpass', ...)`` design: Butterworth
-    ``iirfilter(corners, Wn, btype, ftype='butter', output='zpk')`` -> ``zpk2sos``."""
+    ``iirfilter(corners, Wn, btype, ftype='butter', output='zpk')`` -> ``zpk2sos``.  Designs are cached: a list of
+    ops runs the same few filters for every station-day, and a design costs as much host time as filtering a day."""
+    key = tuple(None if v is None else float(v) for v in (sampling_rate, freq, freqmin, freqmax))
+    return _butter_design(str(ftype), int(corners), key).copy()
+
+
+@functools.lru_cache(maxsize=64)
+def _butter_design(ftype, corners, key):
+    sampling_rate, freq, freqmin, freqmax = key
     fe = 0.5 * sampling_rate
     if ftype == 'bandpass':
         wn, btype = [freqmin / fe, freqmax / fe], 'band'
@@ -26,7 +34,13 @@ def butter_sos(ftype, sampling_rate, corners=4, freq=None, freqmin=None, freqmax
 def cheby2_lowpass_sos(freq, sampling_rate, maxorder=12):
     """ObsPy ``lowpass_cheby_2`` design (the anti-alias filter of ``Trace.decimate``):
     stop band at `freq` with 96 dB attenuation, pass band lowered by 1 % steps until the
-    order given by ``cheb2ord`` is <= maxorder."""
+    order given by ``cheb2ord`` is <= maxorder.  Cached (2.6 ms of scipy per design: more than the decimation of a
+    station-day on the device)."""
+    return _cheby2_design(float(freq), float(sampling_rate), int(maxorder)).copy()
+
+
+@functools.lru_cache(maxsize=64)
+def _cheby2_design(freq, sampling_rate, maxorder):
     nyquist = sampling_rate * 0.5
     rp, rs, order = 1, 96, 1e99
     ws = freq / nyquist
