@@ -71,6 +71,27 @@ def test_lanczos_positions_next_to_a_sample(ctx, raw):
         assert relerr(got, ref) < TOL, (step, off, a)
 
 
+def test_lanczos_rational_steps_take_the_polyphase_kernel(ctx, raw):
+    """Steps P / Q with Q <= 64 (every resampling between round rates: 40 -> 50 Hz = 4/5, 50 -> 20 Hz = 5/2) repeat the
+    fractional position with period Q: the weights come from a per-call table and the kernel is a polyphase FIR
+    (resample.hip: k_lanczos_table / k_lanczos_poly).  Against the oracle, which evaluates every weight from its own
+    position: offsets, odd numbers of outputs, phases that land on samples, taps clipped at both ends of the row, a
+    kernel wider than the four-sample loads' stride, too few outputs for a table."""
+    x = raw[:, :40001]
+    n = x.shape[1]
+    for step, off, a in ((0.8, 0.0, 20), (2.5, 0.0, 20), (10.0 / 3.0, 1.25, 7), (1.0, 0.5, 3), (0.8, 2.0 - 1e-13, 20),
+                         (1.25, 0.0, 1), (64.0 / 63.0, 0.3, 5), (0.5, 0.0, 13)):
+        nout = int((n - 1 - off) / step) + 1
+        for m in (nout, nout - 1, 3):
+            got = ops.lanczos(ctx, x, m, off, step, a)
+            ref = R.lanczos_interpolation(x, off, step, m, a)
+            assert got.shape == ref.shape and relerr(got, ref) < TOL, (step, off, a, m)
+    d = ctx.array(x)                                     # device rows, many rows (grid z)
+    y = ops.lanczos(ctx, d, 30000, 0.0, 0.8, 20)
+    assert relerr(y.to_host(), R.lanczos_interpolation(x, 0.0, 0.8, 30000, 20)) < TOL
+    y.free(); d.free()
+
+
 def test_lanczos_bandlimited_signal_is_recovered(ctx):
     t = np.arange(20000) / 250.
     x = np.sin(2 * np.pi * 2.3 * t).astype(np.float32)[None]

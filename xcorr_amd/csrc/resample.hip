@@ -94,6 +94,67 @@ __global__ __launch_bounds__(NT) void k_lanczos(const float* __restrict__ x, flo
   }
 }
 
+// Rational steps (40 -> 50 Hz: step 4/5; 50 -> 20 Hz: 5/2 -- every resampling between round rates): the positions
+// p_k = offset + k step repeat their fractional part with period Q (step = P / Q), so the 2a weights of an output
+// depend on k mod Q only.  k_lanczos_table evaluates them once per call, directly (sinpi of the tap distance, float64:
+// the reference's own expression), and k_lanczos_poly (below) is a polyphase FIR: 2a multiply-adds per output instead of
+// 2a rotations, divisions and range tests (the general kernel above ran at 40 % of the float64 issue rate; it remains for
+// irrational steps).  W[q][j]: weight of tap m = c - a + 1 + j for phase q; cq[q] = floor(offset + q step).
+__global__ void k_lanczos_table(double* __restrict__ W, long* __restrict__ cq, int Q, int a, double offset, double step) {
+  const int q = blockIdx.y;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= Q || j >= 2 * a) return;
+  const double p = offset + (double)q * step;
+  const long c = (long)floor(p);
+  if (j == 0) cq[q] = c;
+  const double u = p - (double)(c - a + 1 + j);
+  double w = 0.0;
+  if (u > -(double)a && u < (double)a) {
+    if (u == 0.0) w = 1.0;
+    else {
+      const double pu = M_PI * u;
+      w = sinpi(u) * sinpi(u / (double)a) / (pu * pu / (double)a);
+    }
+  }
+  W[(size_t)q * 2 * a + j] = w;
+}
+
+// One phase per workgroup row (blockIdx.y = q): the outputs k = q + Q r of consecutive lanes use the SAME weights -- a
+// uniform address, so they arrive through the scalar cache and sit in SGPRs -- and their first taps are P samples apart,
+// so the four-sample loads of a wave are (nearly) contiguous.  2a multiply-adds, a/2 vector loads per output.
+struct __attribute__((packed, aligned(4))) F4u { float v[4]; };       // four samples at a 4-byte aligned address
+__global__ __launch_bounds__(NT) void k_lanczos_poly(const float* __restrict__ x, float* __restrict__ y, long n, long nout,
+                                                     const double* __restrict__ W, const long* __restrict__ cq, int Q, long P,
+                                                     int a) {
+  const int q = blockIdx.y;
+  const long b = blockIdx.z;
+  const long r = (long)blockIdx.x * NT + threadIdx.x;
+  const long k = q + (long)Q * r;
+  if (k >= nout) return;
+  const long m0 = cq[q] + r * P - a + 1;            // first tap
+  const float* __restrict__ row = x + b * n;
+  const double* __restrict__ w = W + (size_t)q * 2 * a;
+  double acc = 0.0;
+  const int ntap = 2 * a;
+  if (m0 >= 0 && m0 + ntap <= n) {
+    int j = 0;
+    for (; j + 8 <= ntap; j += 8) {                  // taps in order, eight samples (two loads) in flight
+      const F4u v0 = *reinterpret_cast<const F4u*>(row + m0 + j), v1 = *reinterpret_cast<const F4u*>(row + m0 + j + 4);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc = fma((double)v0.v[t], w[j + t], acc);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc = fma((double)v1.v[t], w[j + 4 + t], acc);
+    }
+    for (; j < ntap; ++j) acc = fma((double)row[m0 + j], w[j], acc);
+  } else {
+    for (int j = 0; j < ntap; ++j) {
+      const long m = m0 + j;
+      if (m >= 0 && m < n) acc = fma((double)row[m], w[j], acc);
+    }
+  }
+  y[b * nout + k] = (float)acc;
+}
+
 // one wave per output block
 __global__ __launch_bounds__(NT) void k_block_rms(const float* __restrict__ x, float* __restrict__ y, long batch, long n,
                                                   long nwin, long win, long step) {
@@ -184,8 +245,31 @@ extern "C" int xcx_lanczos(xcx_ctx* ctx, const float* x, float* y, long batch, l
   IO io;
   int rc = io.begin(ctx, x, sizeof(float) * (size_t)batch * n, y, sizeof(float) * (size_t)batch * n_out, on_device);
   if (rc) return io.end(rc);
-  hipLaunchKernelGGL(k_lanczos, dim3(grid_for(batch * n_out)), dim3(NT), 0, ctx->stream, io.in_d, io.out_d, batch, n,
-                     n_out, offset, step, a);
+  // step = P / Q with a small Q?  (exact in float64 for the ratios of round sampling rates)
+  int Q = 0;
+  long P = 0;
+  for (int q = 1; q <= 64 && !Q; ++q) {
+    const double pq = step * (double)q, pr = std::round(pq);
+    if (pr >= 1.0 && std::fabs(pq - pr) <= 4e-16 * pr) { Q = q; P = (long)pr; }
+  }
+  if (Q && n_out >= 4 * Q) {
+    DevBuf& tab = ctx->scratch[6];
+    const size_t wbytes = sizeof(double) * (size_t)Q * 2 * a;
+    if ((rc = tab.ensure(ctx, wbytes + sizeof(long) * Q))) return io.end(rc);
+    double* W = (double*)tab.ptr;
+    long* cq = (long*)((char*)tab.ptr + wbytes);
+    hipLaunchKernelGGL(k_lanczos_table, dim3((unsigned)((2 * a + 63) / 64), (unsigned)Q), dim3(64), 0, ctx->stream, W, cq, Q, a,
+                       offset, step);
+    const long per_phase = (n_out + Q - 1) / Q;
+    for (long b0 = 0; b0 < batch; b0 += 65535) {       // grid z limit
+      const long nb = std::min<long>(65535, batch - b0);
+      hipLaunchKernelGGL(k_lanczos_poly, dim3((unsigned)((per_phase + NT - 1) / NT), (unsigned)Q, (unsigned)nb), dim3(NT), 0,
+                         ctx->stream, io.in_d + b0 * n, io.out_d + b0 * n_out, n, n_out, (const double*)W, (const long*)cq, Q, P, a);
+    }
+  } else {
+    hipLaunchKernelGGL(k_lanczos, dim3(grid_for(batch * n_out)), dim3(NT), 0, ctx->stream, io.in_d, io.out_d, batch, n,
+                       n_out, offset, step, a);
+  }
   if (hipGetLastError() != hipSuccess) rc = set_err(XCX_EHIP, "k_lanczos launch failed");
   return io.end(rc);
 }
