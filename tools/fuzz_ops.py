@@ -20,7 +20,7 @@ def run(budget=60.0, seed=0, ctx=None):
     worst, cases = {}, 0
     while time.time() < t_end:
         kind = rng.choice(['sos', 'rowops', 'fft', 'hilbert', 'ram', 'cc2d', 'lanczos', 'timeshift', 'timeshift_fft',
-                           'specseg', 'resample', 'bigfft', 'zerophase', 'postprep'])
+                           'specseg', 'resample', 'bigfft', 'zerophase', 'postprep', 'decimate', 'polyphase', 'longfft'])
         if kind == 'sos':
             n = int(rng.choice([rng.integers(40, 300), rng.integers(300, 20000), rng.integers(20000, 400000)]))
             b = int(rng.integers(1, 5)) if n > 20000 else int(rng.integers(1, 200))
@@ -117,6 +117,37 @@ def run(budget=60.0, seed=0, ctx=None):
             n = int(rng.integers(200, 300000)); x = (rng.standard_normal((2, n)) + 1.0).astype(np.float32)
             sos = stream.butter_sos('bandpass', 50., int(rng.integers(1, 5)), freqmin=float(rng.uniform(0.05, 2.)), freqmax=float(rng.uniform(4., 20.)))
             e = rel(ops.sosfilt_zerophase(ctx, x, sos), R.sosfilt_zerophase(sos, x)); tol = 2e-5
+        elif kind == 'decimate':                 # the filter's last pass stores every factor-th sample (sos.hip: Decim)
+            from xcorr_amd import stream
+            n = int(rng.choice([rng.integers(40, 5000), rng.integers(5000, 300000), rng.integers(300000, 3000000)]))
+            b = int(rng.integers(1, 5)) if n > 20000 else int(rng.integers(1, 40))
+            factor = int(rng.integers(2, 17)); fs = float(rng.choice([100., 250., 40.]))
+            x = (rng.standard_normal((b, n)) + 0.3).astype(np.float32)
+            if rng.random() < 0.5:
+                y, _ = stream.decimate(ctx.array(x), fs, factor, ctx=ctx)
+                got = y.to_host(); y.free()
+            else:
+                got, _ = stream.decimate(x, fs, factor, ctx=ctx)
+            e = rel(got, R.decimate(x, fs, factor)); tol = 1e-5
+        elif kind == 'polyphase':                # rational steps: per-call weight table + polyphase FIR (resample.hip)
+            n = int(rng.integers(200, 200000)); a_ = int(rng.integers(1, 33))
+            P_, Q_ = int(rng.integers(1, 40)), int(rng.integers(1, 65))
+            step = P_ / Q_
+            if step < 0.05: step = 1.0
+            off = float(rng.choice([0.0, 0.5, float(rng.uniform(0, 3)), 2.0 - 1e-13]))
+            nout = max(1, int((n - 1 - off) / step) + int(rng.integers(0, 2)))
+            if off + (nout - 1) * step > n - 1: nout -= 1
+            x = rng.standard_normal((int(rng.integers(1, 4)), n)).astype(np.float32)
+            e = rel(ops.lanczos(ctx, x, nout, off, step, a_), R.lanczos_interpolation(x, off, step, nout, a_)); tol = 1e-5
+        elif kind == 'longfft':                  # beyond every single transform: block-decomposed chirp convolution
+            if rng.random() < 0.8:               # (expensive on the host: a fifth of the draws)
+                continue
+            n = int(rng.integers(790000, 2600000)); x = rng.standard_normal((1, n)).astype(np.float32)
+            m = n - (n & 1)
+            X = ops.rfft(ctx, x)
+            e = rel(X, np.fft.rfft(x[:, :m].astype(np.float64), axis=-1))
+            e = max(e, rel(ops.irfft(ctx, X), x[:, :m]) / 2)
+            tol = 1e-5
         elif kind == 'postprep':
             npts = int(rng.integers(200, 100000)); full = 2 * npts - 1
             i0 = int(rng.integers(0, full - 64)); i1 = int(rng.integers(i0 + 64, full + 1))
