@@ -559,3 +559,32 @@ def test_fftlib_host_rules(monkeypatch):
     with pytest.raises(ValueError):
         fftlib.fft(z, norm='bogus')
     assert fftlib.fftshift is np.fft.fftshift and fftlib.rfftfreq is np.fft.rfftfreq
+
+
+def test_filter_designs_are_cached_copies():
+    """stream.butter_sos / cheby2_lowpass_sos and signal's butter_design keep their scipy designs per argument set (a
+    Chebyshev anti-alias design costs more host time than decimating a station-day on the device): the cached design
+    equals a fresh one bit for bit, and what a caller does to the array it got does not reach the next caller."""
+    import scipy.signal
+    from xcorr_amd import stream
+    from xcorr_amd.signal.ops1d import butter_design
+    a = stream.cheby2_lowpass_sos(25., 250.)
+    assert np.array_equal(a, R.cheby2_lowpass_sos(25., 250.))
+    a[:] = 0.0
+    assert np.array_equal(stream.cheby2_lowpass_sos(25., 250.), R.cheby2_lowpass_sos(25., 250.))
+    for ftype, kw in (('highpass', dict(freq=0.05)), ('lowpass', dict(freq=20.)), ('bandpass', dict(freqmin=0.1, freqmax=10.))):
+        b = stream.butter_sos(ftype, 50., 4, **kw)
+        fe = 25.
+        wn = [kw['freqmin'] / fe, kw['freqmax'] / fe] if ftype == 'bandpass' else kw['freq'] / fe
+        z, p, k = scipy.signal.iirfilter(4, wn, btype='band' if ftype == 'bandpass' else ftype[:-4], ftype='butter', output='zpk')
+        assert np.array_equal(b, scipy.signal.zpk2sos(z, p, k))
+        b[:] = 1.0
+        assert not np.array_equal(stream.butter_sos(ftype, 50., 4, **kw), b)
+    with pytest.raises(NotImplementedError):
+        stream.butter_sos('bandstop', 50., 4, freqmin=1., freqmax=2.)
+    for order, wn, bt in ((2, 3.0, 'highpass'), (4, (0.1, 10.), 'bandpass'), (4, [1.5, 10.], 'bandpass')):
+        c = butter_design(order, wn, bt, 50.)
+        ref = scipy.signal.butter(N=order, Wn=list(wn) if not isinstance(wn, float) else wn, btype=bt, output='sos', fs=50.)
+        assert np.array_equal(c, ref)
+        c[:] = 0.0
+        assert np.array_equal(butter_design(order, wn, bt, 50.), ref)
