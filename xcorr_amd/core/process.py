@@ -115,7 +115,7 @@ def process(dataset, client, inventory=None, retry_missing=False,
         out = plan.pairs(buf, pairs, 1, npts)[:, 0]                  # :155-162, batched
         del buf
         for k, (ip, it) in enumerate(todo):
-            dataset.cc[ip, it] = out[k].astype(dataset.cc.dtype)
+            np.copyto(dataset.cc[ip, it], out[k], casting='same_kind')      # one pass (astype + assign were two)
             dataset.status[ip, it] = 1                       # :165
     if dataset.cc_attrs['bias_correct'] == 1 and dataset.cc_attrs['unbiased'] == 0:
         from .. import ops
