@@ -35,7 +35,8 @@ using namespace xcx;
                      __FILE__, __LINE__);                                 \
   } while (0)
 
-int xcx_internal_seg_conv(xcx_plan* p, const float* const* xs, const float* const* ks, int count, float* out, long ld);
+int xcx_internal_seg_conv_sum(xcx_plan* p, const float* const* xs, const float* const* ks, int count, const int* signs,
+                              float* out, long ld);
 bool xcx_internal_segmented(xcx_plan* p);
 
 namespace {
@@ -119,19 +120,12 @@ __global__ void k_bs_pre(const float* __restrict__ in, BsGeom g, long B, float* 
 
 // out[b][k] = c[k] (R[2b][k] + i R[2b+1][k]) scale ; real_only keeps the real part
 // out_mode 0: complex, 1: real part, 2: modulus.   grid (ceil(nout / 256), B)
-// quad: four real convolutions per row (segmented path): re = R[4b] - R[4b+1], im = R[4b+2] + R[4b+3]
 __global__ void k_bs_post(const float* __restrict__ R, long ld, BsGeom g, long B, double scale, int real_only,
-                          float* __restrict__ out, const double2* __restrict__ tab, int quad = 0) {
+                          float* __restrict__ out, const double2* __restrict__ tab) {
   const long b = blockIdx.y;
   const long k = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= g.nout || b >= B) return;
-  double re, im;
-  if (quad) {
-    const float r0 = R[(4 * b) * ld + k], r1 = R[(4 * b + 1) * ld + k], r2 = R[(4 * b + 2) * ld + k], r3 = R[(4 * b + 3) * ld + k];
-    re = (double)r0 - (double)r1; im = (double)r2 + (double)r3;
-  } else {
-    re = R[(2 * b) * ld + k]; im = R[(2 * b + 1) * ld + k];
-  }
+  const double re = R[(2 * b) * ld + k], im = R[(2 * b + 1) * ld + k];
   const double2 c = chirp_tab(tab, g.k0 + k, g.n, g.sign);
   double orr = (re * c.x - im * c.y) * scale, oi = (re * c.y + im * c.x) * scale;
   const long o = b * (g.out_pitch ? g.out_pitch : g.nout) + g.k0 + k;
@@ -228,7 +222,8 @@ int bluestein_core(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom
 // mode, the machinery of the long time shifts): rows a = in * c as (Re, Im) of nn = max(nin, nout) samples, the chirp
 // kernel over TWO spans, g[j] = conj(c)[nn - 1 - j + k0 - m0] for j < 2 nn - 1, as (Re, Im) -- shared by every row and
 // transformed once per call; the four real convolutions (Re a, Im a) x (Re g, Im g) of a row share its block
-// transforms.  Before (round 1-3): si x so partial transforms of <= 737 280 points, each two full correlations --
+// transforms and are summed in twos in the frequency domain (Re = ar*gr - ai*gi, Im = ar*gi + ai*gr: k_seg_gram_sum,
+// one inverse transform per chunk and part).  Before (round 1-3): si x so partial transforms of <= 737 280 points, each two full correlations --
 // 36 of them for a day-long rfft, 848 us per row.
 // rows: tr[b][2][nn];  kernels: kr[2][2 nn - 1].   grid (ceil((2 nn - 1) / 256), B + 1): row B writes the kernels
 __global__ void k_bs_pre_seg(const float* __restrict__ in, BsGeom g, long nn, long B, float* __restrict__ tr,
@@ -292,10 +287,10 @@ int bluestein_seg(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom 
     ctx->bs_tab_n = g.n;
   }
   const double2* tab = (const double2*)ctx->bs_tab.ptr;
-  const long chunk = std::max<long>(1, std::min<long>(batch, ((long)2048 << 20) / (24 * nn)));     // 6 nn floats per row
+  const long chunk = std::max<long>(1, std::min<long>(batch, ((long)2048 << 20) / (16 * nn)));     // 4 nn floats per row
   DevBuf &tr = ctx->scratch[1], &lin = ctx->scratch[2], &din = ctx->scratch[4], &dout = ctx->scratch[5];
   if ((rc = tr.ensure(ctx, sizeof(float) * (2 * nn * chunk + 2 * L)))) return rc;          // rows, then the two kernel rows
-  if ((rc = lin.ensure(ctx, sizeof(float) * 4 * nn * chunk))) return rc;
+  if ((rc = lin.ensure(ctx, sizeof(float) * 2 * nn * chunk))) return rc;
   float* krp = (float*)tr.ptr + 2 * nn * chunk;
   const size_t in_row = (size_t)g.in_pitch * (g.in_complex == 1 ? 8 : 4);
   const size_t out_row = (size_t)(g.out_pitch ? g.out_pitch : g.nout) * (real_only ? 4 : 8);
@@ -313,6 +308,7 @@ int bluestein_seg(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom 
     outd = (float*)dout.ptr;
   }
   std::vector<const float*> xs, ks;
+  std::vector<int> signs;
   const float* gr = krp;
   const float* gi = gr + L;
   for (long r0 = 0; r0 < batch; r0 += chunk) {
@@ -329,9 +325,12 @@ int bluestein_seg(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom 
       xs[4 * b + 2] = ar; ks[4 * b + 2] = gi;           // Im = ar*gi + ai*gr
       xs[4 * b + 3] = ai; ks[4 * b + 3] = gr;
     }
-    if ((rc = xcx_internal_seg_conv(plan, xs.data(), ks.data(), (int)(4 * cnt), (float*)lin.ptr, nn))) return rc;
+    // the two products of a real (imaginary) part are summed in the frequency domain: one inverse per chunk and part
+    signs.resize(2 * cnt);
+    for (long b = 0; b < cnt; ++b) { signs[2 * b] = -1; signs[2 * b + 1] = +1; }
+    if ((rc = xcx_internal_seg_conv_sum(plan, xs.data(), ks.data(), (int)(4 * cnt), signs.data(), (float*)lin.ptr, nn))) return rc;
     hipLaunchKernelGGL(k_bs_post, dim3((unsigned)((g.nout + 255) / 256), (unsigned)cnt), dim3(256), 0, ctx->stream,
-                       (const float*)lin.ptr, nn, g, cnt, scale, real_only, (float*)((char*)outd + out_row * r0), tab, 1);
+                       (const float*)lin.ptr, nn, g, cnt, scale, real_only, (float*)((char*)outd + out_row * r0), tab);
     HIP_TRY(hipGetLastError());
   }
   if (!out_dev) HIP_TRY(hipMemcpyAsync(out, outd, out_row * batch, hipMemcpyDeviceToHost, ctx->stream));

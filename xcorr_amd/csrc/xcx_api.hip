@@ -407,7 +407,7 @@ static int upload(xcx_ctx* ctx, DevBuf& b, const void* src, size_t bytes) {
 
 static int seg_plan_create(xcx_ctx* ctx, int n, int idx_min, int idx_max, int flags, xcx_plan** out);
 static int seg_run(xcx_plan* p, const float* const* xs, const float* const* ys, int rows, float* out, long ld_out,
-                   long conv_len = 0);
+                   long conv_len = 0, const int* psign = nullptr);
 
 extern "C" int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min,
                              int idx_max, int flags, xcx_plan** out) {
@@ -1533,6 +1533,12 @@ bool xcx_internal_segmented(xcx_plan* p) { return p->seg != nullptr; }
 int xcx_internal_seg_conv(xcx_plan* p, const float* const* xs, const float* const* ks, int count, float* out, long ld) {
   return seg_run(p, xs, ks, count, out, ld, 2L * p->g.n - 1);
 }
+// ... with the rows in twos summed in the frequency domain: out row t = conv(row 2t) + signs[t] conv(row 2t + 1), count / 2 rows
+int xcx_internal_seg_conv_sum(xcx_plan* p, const float* const* xs, const float* const* ks, int count, const int* signs,
+                              float* out, long ld) {
+  if (count < 2 || (count & 1) || !signs) return set_err(XCX_EINVAL, "xcx_internal_seg_conv_sum: rows come in twos");
+  return seg_run(p, xs, ks, count, out, ld, 2L * p->g.n - 1, signs);
+}
 
 #ifdef XCX_STAMPS
 // diagnostic build only (not part of include/xcx.h): copy the recorded phase stamps to the host
@@ -1752,11 +1758,89 @@ __global__ __launch_bounds__(256) void k_seg_gram(const cf* __restrict__ X, size
       }
   }
 }
+// Sum of two products per output row (convolution mode, complex chirp convolutions of fftn.hip): row z of C is
+// B[r0] conj(A[r0]) + sign[z] B[r1] conj(A[r1]) for the rows (r0, r1) = grp[2z], grp[2z+1] -- the real (or imaginary) part
+// of a complex convolution needs ONE inverse transform per chunk instead of two.  Two register windows, same walk.
+template <int SG>
+__global__ __launch_bounds__(256) void k_seg_gram_sum(const cf* __restrict__ X, size_t pitch, int nfreq, int NS, int nb, int nc,
+                                                       size_t slotB, const int* __restrict__ ia, const int* __restrict__ ib,
+                                                       const int* __restrict__ grp, const int* __restrict__ sign, int G, int gy,
+                                                       cf* __restrict__ C) {
+  const int x = blockIdx.x & 7, q = blockIdx.x >> 3;
+  const int per_tile = ((G + 3) >> 2) * gy;
+  const int t = q / per_tile, rem = q - t * per_tile;
+  const int f = x + 8 * t;
+  const int grp_i = (rem / gy) * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned k = (unsigned)f * 64u + (threadIdx.x & 63);
+  if (k >= (unsigned)nfreq || grp_i >= G) return;
+  const int c0 = (rem % gy) * SG;
+  const cf* __restrict__ Xb[2];
+  const cf* __restrict__ Xa[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = grp[grp_i * 2 + i];
+    Xb[i] = X + (slotB + (size_t)ib[r] * nb) * pitch;
+    Xa[i] = X + ((size_t)ia[r] * NS + c0) * pitch;
+  }
+  const float sg1 = sign[grp_i] < 0 ? -1.f : 1.f;
+  const int smax = NS - 1 - c0;
+  const unsigned koff = k * (unsigned)sizeof(cf);
+  auto ld = [koff](const cf* row) { return *reinterpret_cast<const cf*>(reinterpret_cast<const char*>(row) + koff); };
+  f2 acc[SG];
+  cf w[2][SG - 1 + kSegUB];
+#pragma unroll
+  for (int j = 0; j < SG; ++j) acc[j] = f2{0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j + 1 < SG; ++j) w[i][j] = ld(Xa[i] + (size_t)min(j, smax) * pitch);
+  for (int beta = 0; beta < nb; beta += kSegUB) {
+    cf b[kSegUB][2];
+#pragma unroll
+    for (int u = 0; u < kSegUB; ++u) {
+      const int bb = min(beta + u, nb - 1);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        b[u][i] = ld(Xb[i] + (size_t)bb * pitch);
+        w[i][SG - 1 + u] = ld(Xa[i] + (size_t)min(beta + u + SG - 1, smax) * pitch);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < kSegUB; ++u) {
+      if (beta + u < nb) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const float sgi = i ? sg1 : 1.f;
+          const f2 bv = f2{b[u][i].x * sgi, b[u][i].y * sgi}, bs = f2{b[u][i].y * sgi, -b[u][i].x * sgi};
+#pragma unroll
+          for (int j = 0; j < SG; ++j)
+            acc[j] = __builtin_elementwise_fma(bs, f2{w[i][u + j].y, w[i][u + j].y},
+                                               __builtin_elementwise_fma(bv, f2{w[i][u + j].x, w[i][u + j].x}, acc[j]));
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j + 1 < SG; ++j) w[i][j] = w[i][j + kSegUB];
+  }
+#pragma unroll
+  for (int j = 0; j < SG; ++j)
+    if (c0 + j < nc) {
+      float* dst = reinterpret_cast<float*>(C + ((size_t)grp_i * nc + c0 + j) * pitch + k);
+      __builtin_nontemporal_store(acc[j].x, dst);
+      __builtin_nontemporal_store(acc[j].y, dst + 1);
+    }
+}
+using SegGramSumFn = void (*)(const cf*, size_t, int, int, int, int, size_t, const int*, const int*, const int*, const int*, int,
+                              int, cf*);
 using SegGramFn = void (*)(const cf*, size_t, int, int, int, int, size_t, const int*, const int*, const int*, int, int, cf*,
                            const double*, const int*, const int*, int, int);
-struct SegGramVar { int sg; SegGramFn fn1, fn2; };
-static const SegGramVar kSegGram[] = {{3, k_seg_gram<3, 1>, k_seg_gram<3, 2>}, {6, k_seg_gram<6, 1>, k_seg_gram<6, 2>},
-                                      {9, k_seg_gram<9, 1>, k_seg_gram<9, 2>}, {12, k_seg_gram<12, 1>, k_seg_gram<12, 2>}};
+struct SegGramVar { int sg; SegGramFn fn1, fn2; SegGramSumFn fsum; };
+static const SegGramVar kSegGram[] = {{3, k_seg_gram<3, 1>, k_seg_gram<3, 2>, k_seg_gram_sum<3>},
+                                      {6, k_seg_gram<6, 1>, k_seg_gram<6, 2>, k_seg_gram_sum<6>},
+                                      {9, k_seg_gram<9, 1>, k_seg_gram<9, 2>, k_seg_gram_sum<9>},
+                                      {12, k_seg_gram<12, 1>, k_seg_gram<12, 2>, k_seg_gram_sum<12>}};
 // fewest loads per row: groups x (SG + 2 nb); ties go to the wider window
 static const SegGramVar& seg_gram_pick(int nc, int nb) {
   const SegGramVar* best = &kSegGram[0];
@@ -1837,8 +1921,10 @@ static int seg_plan_create(xcx_ctx* ctx, int n, int idx_min, int idx_max, int fl
 // conv_len > 0 (time shift of rows longer than one transform, timeshift.hip): ys are kernels of conv_len = 2n - 1 samples
 // (two periods), xs the rows of n samples; out[r][n - 1 - k] = sum_t ys[r][t + k] xs[r][t] for k in [0, n) -- ONE pass
 // with the kernel in the segment role, no statistics, no scaling: the n retained values are the circular convolution.
+// psign (convolution mode): the rows come in twos and output row t = conv(row 2t) + psign[t] conv(row 2t + 1), summed in
+// the frequency domain (k_seg_gram_sum): rows / 2 output rows.
 static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys_h, int rows, float* out, long ld_out,
-                   long conv_len) {
+                   long conv_len, const int* psign) {
   xcx_ctx* ctx = p->ctx;
   xcx_plan::Seg& sg = *p->seg;
   const Geom& g = p->g;
@@ -1922,7 +2008,7 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
       while (r0 + rr < rows && rr < 4096) {
         const int a = ida[r0 + rr], b = idb[r0 + rr];
         const size_t add = per_row + (posa.count(a) ? 0 : per_a) + (posb.count(b) ? 0 : per_b);
-        if (rr > 0 && bytes + add > budget) break;
+        if (rr > 0 && !(psign && (rr & 1)) && bytes + add > budget) break;
         bytes += add;
         if (!posa.count(a)) { posa.emplace(a, (int)ua.size()); ua.push_back(a); }
         if (!posb.count(b)) { posb.emplace(b, (int)ub.size()); ub.push_back(b); }
@@ -1930,7 +2016,8 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
         ++rr;
       }
       const int na = (int)ua.size(), nbw = (int)ub.size();
-      const int P = rr * nchunks;
+      const int orr = psign ? rr / 2 : rr, or0 = psign ? r0 / 2 : r0;      // output rows of the chunk
+      const int P = orr * nchunks;
       const size_t slotB = (size_t)na * NS, slots = slotB + (size_t)nbw * nb;
       if ((rc = sg.segbuf.ensure(ctx, sizeof(float) * slots * npr))) return rc;
       if ((rc = sub->spectra.ensure(ctx, sizeof(cf) * pitch * slots))) return rc;
@@ -1949,7 +2036,11 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
       // of 64 stations are 5 GB: in row order every row fetched its 35 MB of b-blocks from HBM).
       const size_t g2_at = ints.size();
       int n2 = 0, n1 = 0;
-      {
+      if (psign) {                                   // pair sums: group t = rows (2t, 2t + 1), then the signs
+        n2 = orr;
+        for (int t = 0; t < orr; ++t) { ints.push_back(2 * t); ints.push_back(2 * t + 1); }
+        for (int t = 0; t < orr; ++t) ints.push_back(psign[or0 + t]);
+      } else {
         static const int kSegAB = getenv("XCX_SEG_ABLOCK") ? std::max(1, atoi(getenv("XCX_SEG_ABLOCK"))) : 2;
         std::vector<int> ord(rr);
         for (int i = 0; i < rr; ++i) ord[i] = i;
@@ -1990,7 +2081,7 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
       const int* d_rx = d_ib + rr;
       const int* d_ry = d_rx + rr;
       const int* d_g2 = (const int*)sg.pairs.ptr + g2_at;
-      const int* d_g1 = d_g2 + 2 * n2;
+      const int* d_g1 = d_g2 + 2 * n2;                              // pair sums: the signs
       float* segA = (float*)sg.segbuf.ptr;
       float* segB = segA + slotB * npr;
       const unsigned gx = (unsigned)((npr + 256 * kSegU - 1) / (256 * kSegU));
@@ -2017,11 +2108,14 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
       const int gy = (nchunks + gv.sg - 1) / gv.sg, tiles8 = ((nfreq + 63) / 64 + 7) / 8;      // tiles per XCD
       auto gram_grid = [&](int G) { return dim3((unsigned)(8 * (size_t)tiles8 * ((G + 3) / 4) * gy)); };
       const int scaled = direct && (flags & XCX_F_NORMALIZE) ? 1 : 0;
-      if (n2 > 0)
+      if (psign)
+        hipLaunchKernelGGL(gv.fsum, gram_grid(n2), dim3(256), 0, ctx->stream, (const cf*)sub->spectra.ptr, pitch, nfreq, NS, nb,
+                           nchunks, slotB, d_ia, d_ib, d_g2, d_g1, n2, gy, (cf*)sub->gramC.ptr);
+      else if (n2 > 0)
         hipLaunchKernelGGL(gv.fn2, gram_grid(n2), dim3(256), 0, ctx->stream, (const cf*)sub->spectra.ptr, pitch, nfreq,
                            NS, nb, nchunks, slotB, d_ia, d_ib, d_g2, n2, gy, (cf*)sub->gramC.ptr, (const double*)su, d_rx, d_ry,
                            scaled, seg_first ? 1 : 0);
-      if (n1 > 0)
+      if (!psign && n1 > 0)
         hipLaunchKernelGGL(gv.fn1, gram_grid(n1), dim3(256), 0, ctx->stream, (const cf*)sub->spectra.ptr, pitch, nfreq,
                            NS, nb, nchunks, slotB, d_ia, d_ib, d_g1, n1, gy, (cf*)sub->gramC.ptr, (const double*)su, d_rx, d_ry,
                            scaled, seg_first ? 1 : 0);
@@ -2031,27 +2125,27 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
       inv->hdescs.resize(P);
       {
         int d = 0;
-        for (int r = 0; r < rr; ++r)
+        for (int r = 0; r < orr; ++r)
           for (int c = 0; c < nfull; ++c) {
             const long kc = k0 + (long)c * Kb;                          // first lag of the chunk
             const long j0 = seg_first ? (n - 1) + kc - idx_min_eff : (n - 1) - (kc + Kb - 1) - idx_min_eff;
-            inv->hdescs[d++] = PwDesc{r * nchunks + c, r * nchunks + c, (long long)(r0 + r) * ld_out + j0};
+            inv->hdescs[d++] = PwDesc{r * nchunks + c, r * nchunks + c, (long long)(or0 + r) * ld_out + j0};
           }
-        for (int r = 0; r < rr; ++r)
+        for (int r = 0; r < orr; ++r)
           for (int c = nfull; c < nchunks; ++c)
             inv->hdescs[d++] = PwDesc{r * nchunks + c, r * nchunks + c, ((long long)r * ne + (c - nfull)) * Kb};
       }
       inv->desc_key = 0; inv->gram_key = 0;
       if ((rc = upload(ctx, inv->descs, inv->hdescs.data(), (size_t)P * sizeof(PwDesc)))) return rc;
-      const int Pd = rr * nfull;
+      const int Pd = orr * nfull;
       if (Pd > 0 && (rc = stack_inverse(inv, Pd, out, 0, (const cf*)sub->gramC.ptr))) return rc;
       if (ne > 0) {
-        if ((rc = sg.subout.ensure(ctx, sizeof(float) * (size_t)rr * ne * Kb))) return rc;
-        if ((rc = stack_inverse(inv, rr * ne, (float*)sg.subout.ptr, Pd, (const cf*)sub->gramC.ptr))) return rc;
-        hipLaunchKernelGGL(k_seg_scatter, dim3((Kb + 256 * kSegU - 1) / (256 * kSegU), ne, rr), dim3(256), 0, ctx->stream,
+        if ((rc = sg.subout.ensure(ctx, sizeof(float) * (size_t)orr * ne * Kb))) return rc;
+        if ((rc = stack_inverse(inv, orr * ne, (float*)sg.subout.ptr, Pd, (const cf*)sub->gramC.ptr))) return rc;
+        hipLaunchKernelGGL(k_seg_scatter, dim3((Kb + 256 * kSegU - 1) / (256 * kSegU), ne, orr), dim3(256), 0, ctx->stream,
                            (const float*)sg.subout.ptr, (const double*)su, d_rx, d_ry, scaled ? (flags & ~XCX_F_NORMALIZE) : flags,
                            n, Kb, ne, nfull, k0, kend, pass == 0 ? 1 : -1, seg_first ? 0 : 1, idx_min_eff, L_eff,
-                           out + (size_t)r0 * ld_out, ld_out);
+                           out + (size_t)or0 * ld_out, ld_out);
         HIP_TRY(hipGetLastError());
       }
       r0 += rr;
