@@ -3,6 +3,7 @@
 bench.py -- pair-windows/s of the MI355X cross-correlation engine.
 
     python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py --gpus N ...             (starts its own N rank processes, xcorr_amd/launch.py)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
@@ -67,6 +68,8 @@ def parse():
     ap.add_argument('--stack', action='store_true', help='time-stack mode (configs[3])')
     ap.add_argument('--days', type=int, default=0,
                     help='--stack: station-days per step, dealt to the ranks (default: one per rank)')
+    ap.add_argument('--oversubscribe', action='store_true',
+                    help='rehearsal: allow more ranks than visible GPUs (ranks share devices; RCCL will refuse)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-seconds', type=float, default=12.0)
     ap.add_argument('--no-kernel-timing', action='store_true')
@@ -179,12 +182,35 @@ def src_sha256():
     return h.hexdigest()
 
 
+def _launch_module():
+    """xcorr_amd/launch.py loaded by path: the launching parent imports nothing of the package."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_xcx_launch', os.path.join(ROOT, 'xcorr_amd', 'launch.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def main():
     a = parse()
+    # `python bench.py --gpus N` without a launcher: this process becomes the launcher -- before any GPU call and
+    # before xcorr_amd is imported -- and starts N fresh rank processes (xcorr_amd/launch.py); with a launcher
+    # (torch.distributed.run, mpirun, ...) WORLD_SIZE must equal --gpus.  Never a silent one-rank run.
+    launch = _launch_module()
+    if launch.needs_launch(a.gpus) == 'spawn':
+        if not a.oversubscribe:
+            try:
+                ndev = launch.visible_devices()
+            except Exception as e:
+                raise SystemExit(f'--gpus {a.gpus}: cannot count the visible GPUs ({e})')
+            if a.gpus > ndev:
+                raise SystemExit(f'--gpus {a.gpus} but {ndev} GPU(s) visible; --oversubscribe lets ranks share '
+                                 'devices (rehearsal only)')
+        sys.exit(launch.spawn_ranks(a.gpus, [os.path.abspath(__file__)] + sys.argv[1:]))
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f'--gpus {a.gpus} but WORLD_SIZE={world}')
     from xcorr_amd import rendezvous
     rdzv = rendezvous.from_env()
@@ -195,7 +221,9 @@ def main():
     import ctypes as _C
     ndev = _C.c_int(0)
     _ffi.check(_ffi.lib().xcx_device_count(_C.byref(ndev)))
-    # one rank per GPU; the modulo only matters when rehearsing N ranks on a smaller box
+    # one rank per GPU; the modulo only matters when rehearsing N ranks on a smaller box (--oversubscribe)
+    if local >= max(ndev.value, 1) and not a.oversubscribe:
+        raise SystemExit(f'rank {rank}: LOCAL_RANK={local} but {ndev.value} GPU(s) visible (--oversubscribe to share devices)')
     ctx = X.Context(local % max(ndev.value, 1))
 
     S = a.stations

@@ -53,6 +53,32 @@ enum {
   XCX_DEMEAN = 32      /* subtract the window mean (signal/detrend.py:110)    */
 };
 
+/* ---- numeric limits of this build ---------------------------------------
+ * Every size limit this header speaks of is one of these constants; the library enforces exactly them (static
+ * assertions tie them to its kernels) and reports them at run time: xcx_limits(out, XCX_LIM_COUNT) fills
+ * out[XCX_LIM_...] (no GPU needed).  tests/test_abi.py compares the two. */
+#define XCX_MAX_SINGLE_TRANSFORM 786432L   /* longest transform ONE plan holds (2 x 3072 x 128 points); correlations,
+                                              time shifts and DFTs beyond it run block-decomposed ("segmented") */
+#define XCX_MAX_CHIRP_POINTS     737280L   /* longest chirp convolution (nin + nout - 1 points) done as one transform */
+#define XCX_MAX_ROW_SAMPLES  1073741823L   /* rows of the segmented paths: 2n fits a 32-bit int */
+#define XCX_MAX_SPLIT_PARTS        4096L   /* partial transforms of a split DFT (input blocks x output blocks) */
+#define XCX_CC2D_MAX_F              256L   /* xcx_cc2d tile rows */
+#define XCX_CC2D_MAX_L             4096L   /* xcx_cc2d tile columns */
+#define XCX_RAM_MAX_HALF_WIDTH     3072L   /* xcx_ram_normalize */
+#define XCX_SOS_MAX_SECTIONS          8L   /* second-order sections of one filter call */
+#define XCX_SPECTROGRAM_MAX_WIN     256L   /* window length of the MFMA spectrogram kernels */
+#define XCX_SPECTROGRAM_MAX_NFFT   8192L   /* nfft of the MFMA spectrogram kernels */
+#define XCX_SPECTROGRAM_SEG_MAX_NFFT 4194304L  /* nfft of xcx_spectrogram_seg's DFT route (2^22) */
+#define XCX_ROWS_MAX_BATCH        65535L   /* rows per call of xcx_scale_rows / xcx_absmax_rows (grid y) */
+#define XCX_SEG_WORKSPACE_MAX_GB     64L   /* segmented plans: workspace = half of the free device memory, at most this */
+enum {
+  XCX_LIM_MAX_SINGLE_TRANSFORM = 0, XCX_LIM_MAX_CHIRP_POINTS, XCX_LIM_MAX_ROW_SAMPLES, XCX_LIM_MAX_SPLIT_PARTS,
+  XCX_LIM_CC2D_MAX_F, XCX_LIM_CC2D_MAX_L, XCX_LIM_RAM_MAX_HALF_WIDTH, XCX_LIM_SOS_MAX_SECTIONS,
+  XCX_LIM_SPECTROGRAM_MAX_WIN, XCX_LIM_SPECTROGRAM_MAX_NFFT, XCX_LIM_SPECTROGRAM_SEG_MAX_NFFT,
+  XCX_LIM_ROWS_MAX_BATCH, XCX_LIM_SEG_WORKSPACE_MAX_GB, XCX_LIM_COUNT
+};
+int xcx_limits(long* out, int count);
+
 /* ---- context / memory / timing ---------------------------------------- */
 int xcx_device_count(int* count);
 int xcx_init(int device, xcx_ctx** ctx);
@@ -62,6 +88,11 @@ int xcx_last_error(char* buf, size_t len);
 int xcx_device_name(xcx_ctx* ctx, char* buf, size_t len);
 int xcx_malloc(xcx_ctx* ctx, size_t bytes, void** dptr);
 int xcx_free(xcx_ctx* ctx, void* dptr);
+/* A caller that keeps freed device buffers in a pool of its own registers a callback that returns them (through
+ * xcx_free) and reports the bytes released.  The library calls it once before an allocation of its own fails with
+ * XCX_ENOMEM (plan workspaces, staged host rows, xcx_malloc itself) and before a segmented plan sizes its workspace
+ * from the free device memory.  cb = NULL removes it.  Not re-entered from the xcx_free calls it makes. */
+int xcx_set_reclaim(xcx_ctx* ctx, size_t (*cb)(void* user), void* user);
 /* page-locked host memory (hipHostMalloc): device-to-host copies into it run at PCIe speed; the
  * Python mirrors return their result arrays in it (xcorr_amd.Context.pinned_empty) */
 int xcx_host_alloc(xcx_ctx* ctx, size_t bytes, void** hptr);
@@ -95,6 +126,12 @@ int xcx_timer_stop(xcx_ctx* ctx, float* ms);
  * idx_min, idx_max : retained slice of the 2n-1 lags, end exclusive
  *            (core/process.py:155-162 `[index_min:index_max]`,
  *            util/time.py:104-108); idx_max = 0 means 2n-1.
+ * Windows for which no single transform holds n + max|lag| points (beyond XCX_MAX_SINGLE_TRANSFORM: the
+ * reference's production setting window_length = 86400 s, clip_lag = (0, 9 h), scripts/cc.py:25-29) get a
+ * SEGMENTED plan behind the same entry points (not with XCX_WHITEN / XCX_STACK): y is cut into blocks and the
+ * lags into chunks of 184 320 samples each (half of the tuned 368 640-point block transform), every distinct window of a call is transformed
+ * once, and the rows go through in chunks whose workspace is half of the free device memory, at most
+ * XCX_SEG_WORKSPACE_MAX_GB (XCX_SEG_BUDGET_MB overrides; a registered xcx_set_reclaim callback is asked first).
  */
 int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min, int idx_max,
                   int flags, xcx_plan** plan);
@@ -190,7 +227,8 @@ int xcx_plan_profile_read(xcx_plan* plan, int kernel_id, char* name,
  * onebit  : sign(x)                           (self-defined)
  * sosfiltfilt : zero-phase Butterworth, scipy semantics (odd padding of
  *           3*ntaps samples, sosfilt_zi initial state) given `sos`
- *           [n_sections][6] float64           (signal/filter.py:86-96)
+ *           [n_sections][6] float64           (signal/filter.py:86-96); n_sections <= XCX_SOS_MAX_SECTIONS
+ *           in every SOS entry point (an order-16 band-pass)
  * sosfilt : forward-only cascade from rest (ObsPy Trace.filter,
  *           stream/process.py:279-282; unverified vs obspy)
  */
@@ -229,12 +267,17 @@ int xcx_onebit(xcx_ctx* ctx, float* x, long batch, long n, int on_device);
 /* Row scaling and row maxima for the ObsPy-named preprocess ops that are a division by one number per trace
  * (stream/process.py:29-94: `remove_sensitivity` = Trace.remove_sensitivity, `normalize` = Trace.normalize):
  * x[r][:] *= factor[r] (factor: `batch` host doubles; the product is formed in float64 and rounded once), and
- * out[r] = max |x[r][:]| (out: `batch` host floats). */
+ * out[r] = max |x[r][:]| (out: `batch` host floats).  batch <= XCX_ROWS_MAX_BATCH per call. */
 int xcx_scale_rows(xcx_ctx* ctx, float* x, long batch, long n, const double* factor, int on_device);
 int xcx_absmax_rows(xcx_ctx* ctx, const float* x, long batch, long n, float* out, int on_device);
+/* Rotation of two components in place (stream/process.py:70-73 `rotate` = obspy Stream.rotate; 'NE->RT' as used by
+ * scripts/cc.py:83-84): (a, b) <- (c4[0] a + c4[1] b, c4[2] a + c4[3] b) on two arrays [batch][n] (both host or both
+ * device); products in float64, rounded once.  out[r] of xcx_absmax_rows is NaN when the row holds a NaN
+ * (np.abs(x).max() semantics). */
+int xcx_rotate2(xcx_ctx* ctx, float* a, float* b, long batch, long n, const double* c4, int on_device);
 /* Running-absolute-mean temporal normalisation (Bensen et al. 2007 eq. 1; self-defined,
  * the reference has none): x[t] /= mean(|x[t-h .. t+h]|), the window truncated at the
- * row ends and averaged over the samples it holds; 0 where the mean is 0.  h <= 3072. */
+ * row ends and averaged over the samples it holds; 0 where the mean is 0.  h <= XCX_RAM_MAX_HALF_WIDTH. */
 int xcx_ram_normalize(xcx_ctx* ctx, float* x, long batch, long n, long half_width,
                       int on_device);
 int xcx_sosfiltfilt(xcx_ctx* ctx, float* x, long batch, long n,
@@ -273,8 +316,13 @@ int xcx_snr(xcx_ctx* ctx, const float* x, long batch, long n,
  * fN = round(n/2 / ((n-1)/sampling_rate)) (signal/fft.py:358).
  * x: [batch][size], y: [batch][n], delay: [batch] seconds (host pointer).
  * Computed as a period-n circular convolution with the analytic Dirichlet
- * kernel on the cross-correlation engine (no length-n FFT is needed);
- * supported for 2n-1 <= the largest transform length (n <= 393216). */
+ * kernel on the cross-correlation engine (no length-n FFT is needed), any n >= 2 up to
+ * XCX_MAX_ROW_SAMPLES: rows with 2n-1 <= XCX_MAX_SINGLE_TRANSFORM (n <= 393 216) take three
+ * transforms of >= 2n-1 points (9.0 us per 359 998-sample row; rows of a call that share a delay
+ * share the kernel's transform: 5.3 us); longer rows (the 1.62 M-lag rows of the production
+ * container) run the same convolution as ONE pass of the block decomposition of the segmented
+ * plans (blocks of 184 320 samples, cost ~ n * ceil(n / 184 320): 66 us per
+ * 1.62 M-sample row, 34 us with shared delays; workspace: see xcx_plan_cc1d, segmented plans). */
 int xcx_timeshift(xcx_ctx* ctx, const float* x, float* y, long batch, long size,
                   const double* delay, double sampling_rate, int on_device);
 
@@ -299,7 +347,7 @@ int xcx_timeshift_fft(xcx_ctx* ctx, const float* x, float* y, long batch, long s
  * its (i, j), first occurrence in row-major order (numpy.argmax).  full, when
  * non-NULL, receives all [P][2F-1][2L-1] values (host or device per on_device).
  * Computed at the padded size P1 x P2 >= (2F-1) x (2L-1) with P1, P2 powers of
- * two; F <= 256, L <= 4096 (XCX_EUNSUPPORTED beyond). */
+ * two; F <= XCX_CC2D_MAX_F, L <= XCX_CC2D_MAX_L (XCX_EUNSUPPORTED beyond). */
 int xcx_cc2d(xcx_ctx* ctx, const float* tiles, int T, int F, int L,
              const int* pairs, int P, int normalize, float* peak_val,
              int* peak_idx, float* full, int on_device);
@@ -312,10 +360,16 @@ int xcx_cc2d(xcx_ctx* ctx, const float* tiles, int T, int F, int L,
  *   xcx_rfft           : x [batch][size] real  -> out [batch][n/2+1] complex with
  *                        n = size - (size & 1)  (fft.py:357 drops an odd last sample)
  *   xcx_irfft          : in [batch][m] complex -> x [batch][2(m-1)] real  (fft.py:475)
- * Bluestein's chirp convolution on the cross-correlation engine: one convolution while
- * 2 (nin + nout - 1) - 1 <= 737280 (n <= 184320 complex, n <= 245760 real); longer axes
- * (the 359 998-sample lag axis) are split into partial transforms over blocks of inputs
- * and outputs that are accumulated (cost grows with the square of n / 184320). */
+ * Bluestein's chirp convolution on the cross-correlation engine, any n >= 2 up to XCX_MAX_ROW_SAMPLES,
+ * three regimes (even-length real transforms are packed into one complex transform of n/2 points first):
+ *   nin + nout - 1 <= XCX_MAX_CHIRP_POINTS : ONE convolution (complex n <= 368 640; packed real n <= 737 280 --
+ *       the 359 998-sample lag axis: rfft / irfft 8.8 / 8.3 us per row, hilbert 18 us);
+ *   beyond that while 2 max(nin, nout) - 1 <= XCX_MAX_SINGLE_TRANSFORM : the DFT sum split over si input x so output
+ *       blocks, si * so <= XCX_MAX_SPLIT_PARTS partial transforms accumulated into the output (cost ~ si * so);
+ *   beyond every single transform (day-long rows: rfft of 4.32 M samples = 2.16 M complex points) : the chirp
+ *       convolution block-decomposed on the segmented plans, cost ~ n * ceil(n / 368 640) (rfft 159 us, hilbert
+ *       326 us per 4.32 M-sample row); workspace = half of the free device memory, at most
+ *       XCX_SEG_WORKSPACE_MAX_GB (XCX_SEG_BUDGET_MB overrides), rows beyond it go through in several chunks. */
 int xcx_fft(xcx_ctx* ctx, const float* in, float* out, long batch, long n, int on_device);
 int xcx_ifft(xcx_ctx* ctx, const float* in, float* out, long batch, long n, int on_device);
 int xcx_rfft(xcx_ctx* ctx, const float* x, float* out, long batch, long size, int on_device);
@@ -326,14 +380,16 @@ int xcx_irfft(xcx_ctx* ctx, const float* in, float* x, long batch, long m, int o
  *   y = irfft(interp(rfft(x) * window_half), num) * num / npts,   x [batch][npts] -> y [batch][num],
  * the spectrum linearly interpolated at bin positions j * ratio (ratio = npts * new_rate /
  * (num * old_rate)), clamped at the last bin like numpy.interp.  window_half: HOST float32
- * [npts/2 + 1] (ifftshift(get_window(w, npts))[:npts/2+1]) or NULL.  Long rows are transformed in blocks (see xcx_fft). */
+ * [npts/2 + 1] (ifftshift(get_window(w, npts))[:npts/2+1]) or NULL.  Any npts, num >= 2 up to XCX_MAX_ROW_SAMPLES:
+ * both transforms follow the three regimes of xcx_fft (a day-long row 50 -> 20 Hz: 0.22 ms). */
 int xcx_resample(xcx_ctx* ctx, const float* x, float* y, long batch, long npts, long num,
                  double ratio, const float* window_half, int on_device);
 
 /* Analytic signal of every row, scipy.signal.hilbert semantics (xcorr/signal/hilbert.py:69):
  * x [batch][n] real -> out [batch][n] complex, or with envelope != 0 its modulus
  * [batch][n] real (hilbert.py:120; the `envelope=True` branch of signal/snr.py:109).
- * Any n >= 2 with 3n <= 737280. */
+ * Any n >= 2 up to XCX_MAX_ROW_SAMPLES; even n as two packed real transforms, every length through the three
+ * regimes of xcx_fft (18 us per 359 998-sample row, 326 us per 4.32 M-sample row). */
 int xcx_hilbert(xcx_ctx* ctx, const float* x, float* out, long batch, long n, int envelope,
                 int on_device);
 
@@ -363,7 +419,8 @@ int xcx_block_rms(xcx_ctx* ctx, const float* x, float* y, long batch, long n, lo
  * window: win_len float64 values (host); scale: 1/(fs sum w^2) ('density') or
  * 1/(sum w)^2 ('spectrum') -- the one-sided doubling of all bins but DC / Nyquist is
  * applied here; detrend: 0 none, 1 'constant' (scipy default).
- * Sliding-window DFT as a Hankel GEMM on fp32 MFMA; 2 <= win_len <= 256, nfft <= 8192. */
+ * Sliding-window DFT as a Hankel GEMM on fp32 MFMA; 2 <= win_len <= XCX_SPECTROGRAM_MAX_WIN,
+ * nfft <= XCX_SPECTROGRAM_MAX_NFFT. */
 int xcx_spectrogram(xcx_ctx* ctx, const float* x, float* S, long batch, long n,
                     int win_len, int nfft, const double* window, double scale,
                     int detrend, int on_device);
@@ -372,8 +429,9 @@ int xcx_spectrogram(xcx_ctx* ctx, const float* x, float* S, long batch, long n,
  * noverlap=win_len-hop, nfft, window, detrend, mode='psd') as called by
  * spectrogram_mtc, xcorr/signal/spectrogram.py:266-276.  x [batch][n] ->
  * S [batch][nfft/2+1][nseg], nseg = (n - win_len)/hop + 1, segment s starts at
- * sample s*hop.  window / scale / detrend as for xcx_spectrogram.  Segments are
- * framed on the device and transformed by the any-length DFT (nfft <= 2^22). */
+ * sample s*hop.  window / scale / detrend as for xcx_spectrogram.  Segments within the limits of xcx_spectrogram
+ * take its MFMA kernel with a column stride; longer ones are framed on the device and transformed by the
+ * any-length DFT (nfft <= XCX_SPECTROGRAM_SEG_MAX_NFFT). */
 int xcx_spectrogram_seg(xcx_ctx* ctx, const float* x, float* S, long batch, long n,
                         int win_len, long hop, int nfft, const double* window,
                         double scale, int detrend, int on_device);

@@ -90,3 +90,60 @@ def test_header_is_plain_c(tmp_path):
     subprocess.run([gcc, '-std=c99', '-Wall', '-O1', '-I', os.path.join(root, 'include'),
                     os.path.join(root, 'examples', 'abi_demo.c'), '-L', lib, '-lxcx', f'-Wl,-rpath,{lib}', '-lm',
                     '-o', str(tmp_path / 'abi_demo')], check=True)
+
+
+def test_header_limits_are_what_the_library_enforces():
+    """Every numeric limit the header quotes is a named constant, the library reports the values it was built with
+    (xcx_limits, no GPU needed), and the prose refers to the names -- a binder reading include/xcx.h reads the
+    contract of THIS build."""
+    from xcorr_amd import _ffi
+    src = open(os.path.join(ROOT, 'include', 'xcx.h')).read()
+    macros = dict(re.findall(r'#define\s+(XCX_[A-Z0-9_]+)\s+(\d+)L\b', src))
+    order = re.search(r'enum\s*\{\s*(XCX_LIM_MAX_SINGLE_TRANSFORM.*?)XCX_LIM_COUNT\s*\}', src, flags=re.S).group(1)
+    names = [n.split('=')[0].strip() for n in order.replace('\n', ' ').split(',') if n.strip()]
+    assert len(names) >= 12 and len(names) == len(macros)
+    out = (C.c_long * len(names))()
+    assert _ffi.lib().xcx_limits(out, len(names)) == 0
+    for i, lim in enumerate(names):
+        macro = 'XCX_' + lim[len('XCX_LIM_'):]
+        assert macro in macros, f'{lim} has no #define {macro}'
+        assert out[i] == int(macros[macro]), f'{macro}: header {macros[macro]}, library {out[i]}'
+    # the entry-point comments quote limits by name, not by stale numbers
+    prose = ' '.join(re.findall(r'/\*.*?\*/', src, flags=re.S))
+    for stale in ('n <= 393216)', '3n <= 737280', 'square of n / 184320', 'F <= 256, L <= 4096', 'h <= 3072'):
+        assert stale not in prose, f'stale limit text in include/xcx.h: {stale!r}'
+    for macro in macros:
+        assert prose.count(macro) >= 1, f'{macro} is defined but no entry point documents it'
+    assert _ffi.lib().xcx_limits(None, 1) == _ffi.XCX_EINVAL
+
+
+def test_reclaim_hook_is_part_of_the_context(monkeypatch):
+    """freed device buffers wait in a pool of the Python binding; the library must be able to get them
+    back (xcx_set_reclaim) -- the pool gives everything up when asked, oldest blocks first when it is full."""
+    from xcorr_amd import engine
+    calls = []
+
+    class FakeLib:
+        def xcx_free(self, h, p):
+            calls.append(p.value)
+            return 0
+
+        def xcx_sync(self, h):
+            return 0
+
+    monkeypatch.setattr(engine._ffi, 'lib', lambda: FakeLib())
+    ctx = engine.Context.__new__(engine.Context)
+    ctx.handle = 1
+    ctx._dev_pool, ctx._dev_pool_bytes = {}, 0
+    ctx._dev_pool_cap, ctx._dev_pool_age = 8 << 20, 30.0
+    assert not ctx._pool_give(0x1000, 100)                  # small blocks are not pooled
+    assert not ctx._pool_give(0x1000, 5 << 20)              # nor blocks above half the cap
+    assert ctx._pool_give(0x1000, 3 << 20) and ctx._pool_give(0x2000, 3 << 20)
+    assert ctx._pool_give(0x3000, 4 << 20)                  # over the cap: the OLDEST block makes room
+    assert calls == [0x1000] and ctx._dev_pool_bytes == 7 << 20
+    assert ctx._pool_take(3 << 20) == 0x2000 and ctx._pool_take(3 << 20) is None
+    assert ctx._reclaim() == 4 << 20 and calls == [0x1000, 0x3000] and ctx._dev_pool_bytes == 0
+    ctx._pool_give(0x4000, 2 << 20)
+    ctx._dev_pool[2 << 20][0] = (0x4000, -1e9)              # idle since long ago: expires at the next take / give
+    assert ctx._pool_take(1 << 20) is None and calls[-1] == 0x4000 and not ctx._dev_pool
+    ctx.handle = None                                       # no __del__ work on the fake

@@ -163,3 +163,92 @@ def test_rendezvous_directory_must_be_ours_and_private(tmp_path, monkeypatch):
     blocker.write_text('x')
     with pytest.raises(OSError):
         FileRendezvous(0, 1, 'k4', root=str(blocker))
+
+
+# ---------------------------------------------------------------------------
+# bench.py --gpus N without a launcher: xcorr_amd/launch.py starts the ranks
+# (reference analogue: the Dask fan-out of core/lazy.py:352-361)
+# ---------------------------------------------------------------------------
+_RANK_SCRIPT = '''
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"]
+assert os.environ["XCX_RDZV_KEY"].startswith("self_")
+mode = sys.argv[1]
+if mode == "fail" and rank == 1:
+    sys.exit(7)
+if mode == "fail" and rank != 1:
+    time.sleep(60)          # would wait for rank 1 in a rendezvous: the launcher must stop us
+if rank == 0:
+    print(json.dumps({"n_gpus": world, "key": os.environ["XCX_RDZV_KEY"]}), flush=True)
+else:
+    print("noise from rank", rank, flush=True)
+'''
+
+
+def _load_launch():
+    import importlib.util
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('_xcx_launch_t', os.path.join(here, 'xcorr_amd', 'launch.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_launcher_starts_ranks_and_relays_rank0_only(tmp_path):
+    import io
+    import json
+    launch = _load_launch()
+    script = tmp_path / 'rank.py'
+    script.write_text(_RANK_SCRIPT)
+    out = io.StringIO()
+    with open(tmp_path / 'err.txt', 'w') as err:
+        rc = launch.spawn_ranks(3, [str(script), 'ok'], out=out, err=err)
+    assert rc == 0
+    lines = out.getvalue().strip().splitlines()
+    assert len(lines) == 1                                   # the bench's ONE JSON line stays alone on stdout
+    assert json.loads(lines[0])['n_gpus'] == 3
+    assert 'noise from rank' in (tmp_path / 'err.txt').read_text()
+    # two launches never share a rendezvous key
+    out2 = io.StringIO()
+    with open(tmp_path / 'err2.txt', 'w') as err:
+        assert launch.spawn_ranks(2, [str(script), 'ok'], out=out2, err=err) == 0
+    assert json.loads(out2.getvalue())['key'] != json.loads(lines[0])['key']
+
+
+def test_launcher_fails_when_a_rank_fails_and_stops_the_rest(tmp_path):
+    import io
+    import time
+    launch = _load_launch()
+    script = tmp_path / 'rank.py'
+    script.write_text(_RANK_SCRIPT)
+    t0 = time.monotonic()
+    with open(tmp_path / 'err.txt', 'w') as err:
+        rc = launch.spawn_ranks(3, [str(script), 'fail'], out=io.StringIO(), err=err, grace=5.0)
+    assert rc == 7
+    assert time.monotonic() - t0 < 30                        # the sleeping ranks were terminated, not waited for
+    assert 'rank 1 exited with status 7' in (tmp_path / 'err.txt').read_text()
+
+
+def test_gpus_flag_never_runs_a_silent_single_rank():
+    launch = _load_launch()
+    assert launch.needs_launch(1, {}) == 'run'
+    assert launch.needs_launch(8, {}) == 'spawn'             # no launcher: start the ranks ourselves
+    assert launch.needs_launch(8, {'WORLD_SIZE': '8'}) == 'run'
+    with pytest.raises(SystemExit):
+        launch.needs_launch(8, {'WORLD_SIZE': '1'})          # never n_gpus: 1 for --gpus 8
+    with pytest.raises(SystemExit):
+        launch.needs_launch(1, {'WORLD_SIZE': '2'})
+
+
+def test_bench_refuses_more_ranks_than_devices_without_oversubscribe():
+    """On a box without a GPU (this container) the device probe fails or reports 0: `bench.py --gpus 2` must
+    refuse loudly before starting any rank; on a GPU box with >= 2 devices this test does not apply."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(here, 'bench.py'), '--gpus', '64', '--steps', '1'],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert '--gpus 64' in r.stderr and 'n_gpus' not in r.stdout

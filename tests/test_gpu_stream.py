@@ -138,6 +138,75 @@ def test_operation_list_like_scripts_cc(ctx, raw):
         stream.apply_operations(raw, 250., [('remove_response', {})], ctx=ctx)
 
 
+def test_bhr_operation_list_of_scripts_cc(ctx):
+    """The BHR list of xcorr/scripts/cc.py:70-90 minus `remove_response` (needs an ObsPy inventory), on a component
+    set {BHZ, BHN, BHE} at 40 Hz: merge -> demean -> highpass -> rotate(->ZNE) -> rotate(NE->RT, 250.39 deg) ->
+    select(BHR) -> Lanczos to 50 Hz -> lowpass -> trim -> demean -> cosine taper, host rows and device-resident
+    rows, against the oracle restatement.  Unverified against obspy (no obspy here), like every a13 op."""
+    rng = np.random.default_rng(31)
+    npts = 40 * 900
+    comps = {c: (rng.standard_normal(npts).cumsum() * 0.01 + rng.standard_normal(npts)).astype(np.float32)
+             for c in ('BHZ', 'BHN', 'BHE')}
+    baz = 250.39
+    ops_list = [
+        ('merge', {'method': 1, 'fill_value': 'interpolate', 'interpolation_samples': 0}),
+        ('detrend', {'type': 'demean'}),
+        ('filter', {'type': 'highpass', 'freq': .05}),
+        ('rotate', {'method': '->ZNE'}),
+        ('rotate', {'method': 'NE->RT', 'back_azimuth': baz}),
+        ('select', {'channel': 'BHR'}),
+        ('interpolate', {'sampling_rate': 50, 'method': 'lanczos', 'a': 20}),
+        ('filter', {'type': 'lowpass', 'freq': 20.}),
+        ('trim', {}),
+        ('detrend', {'type': 'demean'}),
+        ('taper', {'type': 'cosine', 'max_percentage': 0.05, 'max_length': 30.}),
+    ]
+    t0, t1 = 100.0, 100.0 + 800.0
+    y, fs, ts = stream.apply_operations(comps, 40., ops_list, ctx=ctx, starttime=t0 + 20., endtime=t1,
+                                        t0=t0, return_t0=True)
+    # oracle: the same list in float64
+    hp = stream.butter_sos('highpass', 40., 4, freq=.05)
+    pre = {c: R.sosfilt(hp, R.demean(v.astype(np.float64)[None]))[0] for c, v in comps.items()}
+    ba = np.radians(baz)
+    r = -pre['BHE'] * np.sin(ba) - pre['BHN'] * np.cos(ba)
+    span = (npts - 1) / 40.
+    nnew = int(np.floor(span * 50.)) + 1
+    r = R.lanczos_interpolation(r[None], 0.0, 40. / 50., nnew, 20)[0]
+    r = R.sosfilt(stream.butter_sos('lowpass', 50., 4, freq=20.), r[None])[0]
+    i0 = int(round((t0 + 20. - t0) * 50.))
+    i1 = int(round((t1 - t0) * 50.))
+    r = r[i0:i1 + 1]
+    r = R.demean(r[None])[0]
+    r = r * R.cosine_taper_obspy(r.size, 50., 0.05, 30.)
+    assert fs == 50. and abs(ts - (t0 + 20.)) < 1e-9 and y.shape == r.shape
+    assert relerr(y, r) < 5 * TOL
+    # device-resident components: same numbers, the result stays on the device
+    dcomps = {c: ctx.array(v[None]) for c, v in comps.items()}
+    yd, fsd = stream.apply_operations(dcomps, 40., ops_list[1:], ctx=ctx, starttime=t0 + 20., endtime=t1, t0=t0)
+    assert hasattr(yd, 'to_host') and fsd == 50.
+    assert relerr(yd.to_host()[0], r) < 5 * TOL
+    # the rotation alone, both directions of storage, against the defining formula
+    n32, e32 = comps['BHN'], comps['BHE']
+    rr, tt = stream.rotate_ne_rt(n32, e32, 33.0, ctx=ctx)
+    b = np.radians(33.0)
+    assert relerr(rr, -e32.astype(np.float64) * np.sin(b) - n32.astype(np.float64) * np.cos(b)) < 1e-7
+    assert relerr(tt, -e32.astype(np.float64) * np.cos(b) + n32.astype(np.float64) * np.sin(b)) < 1e-7
+    assert np.array_equal(n32, comps['BHN'])                  # host inputs are not modified
+
+
+def test_normalize_propagates_nan_on_device_rows_like_the_host_path(ctx):
+    """a gappy row (NaN sample) normalises to NaN on the host path (np.abs(x).max()); device rows agree."""
+    x = np.random.default_rng(5).standard_normal((3, 70000)).astype(np.float32)
+    x[1, 12345] = np.nan
+    m = ops.absmax_rows(ctx, ctx.array(x))
+    assert np.isnan(m[1]) and m[0] == np.abs(x[0]).max() and m[2] == np.abs(x[2]).max()
+    assert np.isnan(ops.absmax_rows(ctx, x)[1])
+    yd = stream.normalize(ctx.array(x)).to_host()
+    yh = stream.normalize(x)
+    assert np.isnan(yd[1]).all() and np.isnan(yh[1]).all()
+    assert np.allclose(yd[0], yh[0], rtol=1e-6) and np.allclose(yd[2], yh[2], rtol=1e-6)
+
+
 def test_device_resident_rows(ctx, raw):
     d = ctx.array(raw)
     y = ops.decimate(ctx, d, 5, stream.cheby2_lowpass_sos(25., 250.))

@@ -311,12 +311,11 @@ def test_trim_rules():
 def test_rotate_and_sensitivity():
     from xcorr_amd.stream import rotate_ne_rt, remove_sensitivity
     n, e = np.array([1., 0.]), np.array([0., 1.])
-    r, t = rotate_ne_rt(n, e, 0.)           # source due north: radial points south
-    assert np.allclose(r, [-1, 0]) and np.allclose(t, [0, -1])
-    r, t = rotate_ne_rt(n, e, 90.)
-    assert np.allclose(r, [0, -1]) and np.allclose(t, [1, 0])
+    # the arithmetic of the rotation runs in the library (tests/test_gpu_stream.py); argument checks come first
     with pytest.raises(ValueError):
         rotate_ne_rt(n, e, 400.)
+    with pytest.raises(TypeError):
+        rotate_ne_rt(n, e[:1], 10.)
     x = np.array([2., 4.], np.float32)
     y = remove_sensitivity(x, 2.0)
     assert y.dtype == np.float32 and np.array_equal(y, [1, 2])
@@ -324,6 +323,38 @@ def test_rotate_and_sensitivity():
     z = normalize(np.array([[1., -4., 2.], [0., 0., 0.]], np.float32))
     assert z.dtype == np.float32 and np.array_equal(z, [[.25, -1., .5], [0., 0., 0.]])
     assert np.array_equal(normalize(np.array([2., 4.]), norm=-2.), [1., 2.])
+
+
+def test_rotate_and_select_act_on_component_sets():
+    """stream/process.py:70-77 `rotate` / `select` through the registry: bookkeeping and refusals (no GPU)."""
+    from xcorr_amd import stream
+    from xcorr_amd.stream import ops as sops
+    z, n, e = (np.zeros(4, np.float32) + i for i in range(3))
+    comps = {'BHZ': z, 'BHN': n, 'BHE': e}
+    assert sops.rotate(comps, '->ZNE') is comps                     # already ZNE: untouched
+    with pytest.raises(NotImplementedError, match='inventory'):
+        sops.rotate({'BHZ': z, 'BH1': n, 'BH2': e}, '->ZNE')
+    with pytest.raises(ValueError, match='back_azimuth'):
+        sops.rotate(comps, 'NE->RT')
+    with pytest.raises(NotImplementedError):
+        sops.rotate(comps, 'ZNE->LQT', back_azimuth=10., inclination=5.)
+    with pytest.raises(ValueError, match='no pair'):
+        sops.rotate({'BHZ': z, 'BHN': n}, 'NE->RT', back_azimuth=10.)
+    assert list(sops.select(comps, channel='BH[NE]')) == ['BHN', 'BHE']
+    assert list(sops.select(comps, component='Z')) == ['BHZ']
+    with pytest.raises(ValueError, match='matches none'):
+        sops.select(comps, channel='BHR')
+    with pytest.raises(NotImplementedError):
+        sops.select(comps, station='ANMO')
+    # single traces: set operations and inventory operations are refused by name
+    with pytest.raises(TypeError, match='component set'):
+        stream.apply_operations(z, 50., [('select', {'channel': 'BHZ'})])
+    for name in ('remove_response', 'attach_response', 'simulate'):
+        with pytest.raises(NotImplementedError, match='inventory'):
+            stream.apply_operations(z, 50., [(name, {})])
+    # a set that only goes through set operations needs no GPU: select down to one component -> that array
+    y, fs = stream.apply_operations(comps, 50., [('rotate', {'method': '->ZNE'}), ('select', {'channel': 'BHZ'})])
+    assert y is z and fs == 50.
 
 
 def test_hasher_restates_reference_serialisation():

@@ -28,18 +28,21 @@ class XcxError(RuntimeError):
 
 
 _vp, _i, _l, _sz = C.c_void_p, C.c_int, C.c_long, C.c_size_t
+RECLAIM_CB = C.CFUNCTYPE(C.c_size_t, C.c_void_p)        # xcx_set_reclaim callback: size_t cb(void* user)
 _pf, _pi, _pd = C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_double)
 
 # name -> argtypes; every function returns int.  Kept in one table so that
 # tests can check the library exports exactly what include/xcx.h declares.
 SIGNATURES = {
     'xcx_device_count': [_pi],
+    'xcx_limits': [C.POINTER(C.c_long), _i],
     'xcx_init': [_i, C.POINTER(_vp)],
     'xcx_destroy': [_vp],
     'xcx_last_error': [C.c_char_p, _sz],
     'xcx_device_name': [_vp, C.c_char_p, _sz],
     'xcx_malloc': [_vp, _sz, C.POINTER(_vp)],
     'xcx_free': [_vp, _vp],
+    'xcx_set_reclaim': [_vp, _vp, _vp],
     'xcx_host_alloc': [_vp, _sz, C.POINTER(_vp)],
     'xcx_host_free': [_vp, _vp],
     'xcx_memset': [_vp, _vp, _i, _sz],
@@ -75,6 +78,7 @@ SIGNATURES = {
     'xcx_unbias': [_vp, _vp, _l, _l, _l, _l, _i],
     'xcx_onebit': [_vp, _vp, _l, _l, _i],
     'xcx_scale_rows': [_vp, _vp, _l, _l, _vp, _i],
+    'xcx_rotate2': [_vp, _vp, _vp, _l, _l, _vp, _i],
     'xcx_absmax_rows': [_vp, _vp, _l, _l, _vp, _i],
     'xcx_detrend_nan': [_vp, _vp, _l, _l, _i, _i],
     'xcx_taper_table': [_vp, _vp, _l, _l, _vp, _l, _i],

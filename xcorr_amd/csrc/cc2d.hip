@@ -514,8 +514,9 @@ extern "C" int xcx_cc2d(xcx_ctx* ctx, const float* tiles, int T, int F, int L, c
   int P1 = 0, R = 0;
   for (int v : kP1) if (v >= 2 * F - 1) { P1 = v; break; }
   for (int v : kR) if (2 * v >= 2 * L - 1) { R = v; break; }
-  if (!P1 || !R)
-    return set_err(XCX_EUNSUPPORTED, "tile %d x %d too large (max 256 x 4096)", F, L);
+  static_assert(2 * XCX_CC2D_MAX_F == 512 && XCX_CC2D_MAX_L == 4096, "include/xcx.h: the padded sizes instantiated above");
+  if (!P1 || !R || F > XCX_CC2D_MAX_F || L > XCX_CC2D_MAX_L)
+    return set_err(XCX_EUNSUPPORTED, "tile %d x %d too large (max %ld x %ld)", F, L, XCX_CC2D_MAX_F, XCX_CC2D_MAX_L);
   HIP_TRY(hipSetDevice(ctx->device));
   G2 g{F, L, P1, R, (R + 1 + 15) / 16 * 16};
   std::vector<float2> tr, tu, tc;

@@ -138,7 +138,7 @@ __global__ void k_bs_post(const float* __restrict__ R, long ld, BsGeom g, long B
   }
 }
 
-constexpr long kBsMaxNp = 737280;                    // np <= N of the longest tuned correlation plan (kPlanShortOperand)
+constexpr long kBsMaxNp = XCX_MAX_CHIRP_POINTS;                    // np <= N of the longest tuned correlation plan (kPlanShortOperand)
 
 int bluestein_core(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom g, double scale, int real_only,
                    int in_dev, int out_dev) {
@@ -266,7 +266,7 @@ int bluestein_seg(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom 
   HIP_TRY(hipSetDevice(ctx->device));
   int rc;
   const long nn = std::max(g.nin, g.nout), L = 2 * nn - 1;
-  if (nn > 0x7fffffffL / 2) return set_err(XCX_EUNSUPPORTED, "transform length %ld too long", g.n);
+  if (nn > XCX_MAX_ROW_SAMPLES) return set_err(XCX_EUNSUPPORTED, "transform length %ld too long", g.n);
   int slot = -1;
   for (int i = 0; i < 2; ++i) if (ctx->bs_seg_plan[i] && ctx->bs_seg_n[i] == nn) slot = i;
   if (slot < 0) {                                   // two cached plans, replaced in turn
@@ -355,7 +355,7 @@ int bluestein(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom g, d
   auto np_of = [&](long a, long b) { return (g.nin + a - 1) / a + (g.nout + b - 1) / b - 1; };
   while (np_of(si, so) > kBsMaxNp) {
     if ((g.nin + si - 1) / si >= (g.nout + so - 1) / so) ++si; else ++so;
-    if (si * so > 4096) return set_err(XCX_EUNSUPPORTED, "transform length %ld needs more than 4096 partial transforms", g.n);
+    if (si * so > XCX_MAX_SPLIT_PARTS) return set_err(XCX_EUNSUPPORTED, "transform length %ld needs more than %ld partial transforms", g.n, XCX_MAX_SPLIT_PARTS);
   }
   HIP_TRY(hipSetDevice(ctx->device));
   int rc;
@@ -365,12 +365,12 @@ int bluestein(xcx_ctx* ctx, const float* in, float* out, long batch, BsGeom g, d
   auto done = [&](int r) { (void)hipFree(din); (void)hipFree(dout); return r; };
   const float* ind = in; float* outd = out;
   if (!in_dev) {
-    if (hipMalloc(&din, in_row * batch) != hipSuccess) return done(set_err(XCX_ENOMEM, "split transform input"));
+    if (ctx_malloc(ctx, &din, in_row * batch) != hipSuccess) return done(set_err(XCX_ENOMEM, "split transform input"));
     if (hipMemcpyAsync(din, in, in_row * batch, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return done(set_err(XCX_EHIP, "H2D"));
     ind = (const float*)din;
   }
   if (!out_dev) {
-    if (hipMalloc(&dout, out_row * batch) != hipSuccess) return done(set_err(XCX_ENOMEM, "split transform output"));
+    if (ctx_malloc(ctx, &dout, out_row * batch) != hipSuccess) return done(set_err(XCX_ENOMEM, "split transform output"));
     outd = (float*)dout;
   }
   const long ci = (g.nin + si - 1) / si, co = (g.nout + so - 1) / so;
@@ -660,11 +660,11 @@ extern "C" int xcx_hilbert(xcx_ctx* ctx, const float* x, float* out, long batch,
       // split transform: the partial sums are complex, the modulus comes last
       void *dz = nullptr, *dm = nullptr;
       auto done = [&](int r) { (void)hipFree(dz); (void)hipFree(dm); return r; };
-      if (hipMalloc(&dz, sizeof(float2) * n * cnt) != hipSuccess) return done(set_err(XCX_ENOMEM, "analytic signal buffer"));
+      if (ctx_malloc(ctx, &dz, sizeof(float2) * n * cnt) != hipSuccess) return done(set_err(XCX_ENOMEM, "analytic signal buffer"));
       if ((rc = bluestein(ctx, (const float*)spec.ptr, (float*)dz, cnt, b, 1.0 / (double)n, 0, 1, 1))) return done(rc);
       float* dst = (float*)((char*)out + orow * r0);
       if (!on_device) {
-        if (hipMalloc(&dm, sizeof(float) * n * cnt) != hipSuccess) return done(set_err(XCX_ENOMEM, "envelope buffer"));
+        if (ctx_malloc(ctx, &dm, sizeof(float) * n * cnt) != hipSuccess) return done(set_err(XCX_ENOMEM, "envelope buffer"));
         dst = (float*)dm;
       }
       const long tot = n * cnt;

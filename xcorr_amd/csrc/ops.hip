@@ -411,11 +411,26 @@ __global__ __launch_bounds__(NT) void k_snr(const float* __restrict__ x, long n,
 
 // stage host data on the device when on_device == 0
 struct Staged {
-  xcx_ctx* ctx; float* host; float* dev; size_t bytes; bool staged;
+  // host rows of a call are staged in a device copy for its duration; the destructor releases the copy on every
+  // path that leaves without end() / staged_discard() (an error return between begin() and end())
+  xcx_ctx* ctx = nullptr; float* host = nullptr; float* dev = nullptr; size_t bytes = 0; bool staged = false;
+  Staged() = default;
+  Staged(const Staged&) = delete;
+  Staged& operator=(const Staged&) = delete;
+  ~Staged() { drop(); }
+  void drop() {
+    if (staged && dev) {
+      (void)hipStreamSynchronize(ctx->stream);        // a kernel may still be using the copy
+      (void)hipFree(dev);
+    }
+    staged = false;
+  }
   int begin(xcx_ctx* c, float* x, size_t nbytes, int on_device) {
-    ctx = c; host = x; bytes = nbytes; staged = !on_device; dev = x;
-    if (staged) {
-      HIP_TRY(hipMalloc((void**)&dev, bytes ? bytes : 1));
+    ctx = c; host = x; bytes = nbytes; staged = false; dev = x;
+    if (!on_device) {
+      dev = nullptr;
+      HIP_TRY(ctx_malloc(ctx, (void**)&dev, bytes ? bytes : 1));
+      staged = true;
       HIP_TRY(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
     }
     return XCX_OK;
@@ -424,13 +439,12 @@ struct Staged {
     if (staged) {
       HIP_TRY(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
       HIP_TRY(hipStreamSynchronize(ctx->stream));
+      staged = false;
       HIP_TRY(hipFree(dev));
     }
     return XCX_OK;
   }
-  void staged_discard() {                   // read-only op: nothing to copy back (the stream is idle)
-    if (staged) (void)hipFree(dev);
-  }
+  void staged_discard() { drop(); }         // read-only op: nothing to copy back
 };
 
 inline int grid_for(long total) {
@@ -548,7 +562,7 @@ extern "C" int xcx_taper_table(xcx_ctx* ctx, float* x, long batch, long n, const
   if (nmax < 1 || nmax > n) return set_err(XCX_EINVAL, "taper length nmax=%ld must be in [1, n=%ld]", nmax, n);
   HIP_TRY(hipSetDevice(ctx->device));
   float* dtab = nullptr;                                   // the table is host memory in both modes
-  HIP_TRY(hipMalloc((void**)&dtab, sizeof(float) * 2 * (size_t)nmax));
+  HIP_TRY(ctx_malloc(ctx, (void**)&dtab, sizeof(float) * 2 * (size_t)nmax));
   if (hipMemcpyAsync(dtab, flanks, sizeof(float) * 2 * (size_t)nmax, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
     (void)hipFree(dtab);
     return set_err(XCX_EHIP, "window table upload failed");
@@ -600,18 +614,22 @@ __global__ void k_scale_rows(float* __restrict__ x, long n, const double* __rest
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
     row[i] = (float)((double)row[i] * fr);
 }
-// out[r][part] = max |x[r][i]| over the part's slice (NaN ignored like a comparison does); the host takes the maximum
+// out[r][part] = max |x[r][i]| over the part's slice, NaN if the slice holds one (numpy's np.abs(x).max() and the
+// reference propagate it: a gappy row normalises to NaN on the host path and must do so here); the host combines
 __global__ __launch_bounds__(NT) void k_absmax_part(const float* __restrict__ x, long n, float* __restrict__ out) {
   __shared__ float red[NT];
   const float* __restrict__ row = x + (size_t)blockIdx.y * n;
   const long per = (n + gridDim.x - 1) / gridDim.x;
   const long lo = (long)blockIdx.x * per, hi = (lo + per < n) ? lo + per : n;
   float m = 0.f;
-  row_visit(row, lo, hi, [&](long, float v) { const float a = fabsf(v); m = a > m ? a : m; });
+  row_visit(row, lo, hi, [&](long, float v) { const float a = fabsf(v); m = (a > m || a != a) ? a : m; });   // NaN sticks: NaN > x is false
   red[threadIdx.x] = m;
   __syncthreads();
   for (int o = NT / 2; o > 0; o >>= 1) {
-    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    if ((int)threadIdx.x < o) {
+      const float a = red[threadIdx.x], b = red[threadIdx.x + o];
+      red[threadIdx.x] = (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b);     // fmaxf drops a NaN operand
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0) out[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = red[0];
@@ -619,7 +637,7 @@ __global__ __launch_bounds__(NT) void k_absmax_part(const float* __restrict__ x,
 
 extern "C" int xcx_scale_rows(xcx_ctx* ctx, float* x, long batch, long n, const double* factor, int on_device) {
   if (!ctx || !x || !factor) return set_err(XCX_EINVAL, "null argument");
-  if (batch < 1 || n < 1 || batch > 65535) return set_err(XCX_EINVAL, "batch in [1, 65535] and n >= 1 required");
+  if (batch < 1 || n < 1 || batch > XCX_ROWS_MAX_BATCH) return set_err(XCX_EINVAL, "batch in [1, %ld] and n >= 1 required", XCX_ROWS_MAX_BATCH);
   HIP_TRY(hipSetDevice(ctx->device));
   DevBuf& fb = ctx->scratch[0];
   int rc;
@@ -634,9 +652,37 @@ extern "C" int xcx_scale_rows(xcx_ctx* ctx, float* x, long batch, long n, const 
   return st.end();
 }
 
+// (a, b) <- (c00 a + c01 b, c10 a + c11 b), float64 products rounded once
+__global__ __launch_bounds__(NT) void k_rotate2(float* __restrict__ a, float* __restrict__ b, long total,
+                                                double c00, double c01, double c10, double c11) {
+  const long stride = (long)gridDim.x * NT;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += stride) {
+    const double x = (double)a[i], y = (double)b[i];
+    a[i] = (float)(c00 * x + c01 * y);
+    b[i] = (float)(c10 * x + c11 * y);
+  }
+}
+
+extern "C" int xcx_rotate2(xcx_ctx* ctx, float* a, float* b, long batch, long n, const double* c4, int on_device) {
+  if (!ctx || !a || !b || !c4) return set_err(XCX_EINVAL, "null argument");
+  if (batch < 1 || n < 1) return set_err(XCX_EINVAL, "batch and n must be >= 1");
+  if (a == b) return set_err(XCX_EINVAL, "the two components must be different arrays");
+  HIP_TRY(hipSetDevice(ctx->device));
+  const size_t bytes = (size_t)batch * n * sizeof(float);
+  Staged sa, sb;
+  int rc;
+  if ((rc = sa.begin(ctx, a, bytes, on_device))) return rc;
+  if ((rc = sb.begin(ctx, b, bytes, on_device))) return rc;
+  hipLaunchKernelGGL(k_rotate2, dim3(grid_for(batch * n)), dim3(NT), 0, ctx->stream, sa.dev, sb.dev, batch * n,
+                     c4[0], c4[1], c4[2], c4[3]);
+  HIP_TRY(hipGetLastError());
+  if ((rc = sa.end())) return rc;
+  return sb.end();
+}
+
 extern "C" int xcx_absmax_rows(xcx_ctx* ctx, const float* x, long batch, long n, float* out, int on_device) {
   if (!ctx || !x || !out) return set_err(XCX_EINVAL, "null argument");
-  if (batch < 1 || n < 1 || batch > 65535) return set_err(XCX_EINVAL, "batch in [1, 65535] and n >= 1 required");
+  if (batch < 1 || n < 1 || batch > XCX_ROWS_MAX_BATCH) return set_err(XCX_EINVAL, "batch in [1, %ld] and n >= 1 required", XCX_ROWS_MAX_BATCH);
   HIP_TRY(hipSetDevice(ctx->device));
   const int parts = (int)std::max<long>(1, std::min<long>(64, n / 4096));
   DevBuf& pb = ctx->scratch[0];
@@ -652,7 +698,10 @@ extern "C" int xcx_absmax_rows(xcx_ctx* ctx, const float* x, long batch, long n,
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   for (long r = 0; r < batch; ++r) {
     float m = 0.f;
-    for (int q = 0; q < parts; ++q) m = std::max(m, h[(size_t)r * parts + q]);
+    for (int q = 0; q < parts; ++q) {
+      const float v = h[(size_t)r * parts + q];
+      m = (v > m || v != v) ? v : m;                    // a NaN part makes the row's maximum NaN
+    }
     out[r] = m;
   }
   st.staged_discard();
@@ -681,7 +730,7 @@ extern "C" int xcx_onebit(xcx_ctx* ctx, float* x, long batch, long n, int on_dev
 // output takes the difference of two prefix values.
 // ---------------------------------------------------------------------------
 constexpr int kRamChunk = 2048;
-constexpr int kRamMaxHalf = 3072;
+constexpr int kRamMaxHalf = (int)XCX_RAM_MAX_HALF_WIDTH;
 
 __global__ __launch_bounds__(NT) void k_ram(const float* __restrict__ src, float* __restrict__ dst, long n, int h) {
   extern __shared__ double pre[];                 // kRamChunk + 2h prefix sums

@@ -182,8 +182,8 @@ struct IO {
     else (void)hipGetLastError();
     if (ob >= ((size_t)1 << 20) && hipHostRegister(out, ob, hipHostRegisterDefault) == hipSuccess) pin_out = out;
     else (void)hipGetLastError();
-    HIP_TRY(hipMalloc(&a, in_bytes));
-    HIP_TRY(hipMalloc(&b, ob));
+    HIP_TRY(ctx_malloc(ctx, &a, in_bytes));
+    HIP_TRY(ctx_malloc(ctx, &b, ob));
     HIP_TRY(hipMemcpyAsync(a, in, in_bytes, hipMemcpyHostToDevice, c->stream));
     in_d = (const float*)a; out_d = (float*)b; out_h = out;
     return XCX_OK;

@@ -38,7 +38,7 @@ using namespace xcx;
 
 namespace {
 
-constexpr int kMaxK = 8;          // sections
+constexpr int kMaxK = (int)XCX_SOS_MAX_SECTIONS;          // sections
 constexpr int kTile = 64;
 
 struct SosCoef { double b0, b1, b2, a1, a2; };
@@ -632,7 +632,7 @@ int filt_entry(xcx_ctx* ctx, float* x, long batch, long n, const double* sos, in
   const size_t bytes = (size_t)batch * n * sizeof(float);
   HostPin pin_x(on_device ? nullptr : x, bytes);
   if (!on_device) {
-    HIP_TRY(hipMalloc((void**)&dx, bytes));
+    HIP_TRY(ctx_malloc(ctx, (void**)&dx, bytes));
     HIP_TRY(hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, ctx->stream));
   }
   switch (K) {

@@ -228,8 +228,8 @@ extern "C" int xcx_spectrogram(xcx_ctx* ctx, const float* x, float* S, long batc
                                const double* window, double scale, int detrend, int on_device) {
   if (!ctx || !x || !S || !window) return set_err(XCX_EINVAL, "null argument");
   if (batch < 1 || n < 1) return set_err(XCX_EINVAL, "batch and n must be >= 1");
-  if (win_len < 2 || win_len > 256) return set_err(XCX_EUNSUPPORTED, "win_len %d outside [2, 256]", win_len);
-  if (nfft < win_len || nfft > 8192) return set_err(XCX_EINVAL, "nfft %d outside [win_len, 8192]", nfft);
+  if (win_len < 2 || win_len > XCX_SPECTROGRAM_MAX_WIN) return set_err(XCX_EUNSUPPORTED, "win_len %d outside [2, %ld]", win_len, XCX_SPECTROGRAM_MAX_WIN);
+  if (nfft < win_len || nfft > XCX_SPECTROGRAM_MAX_NFFT) return set_err(XCX_EINVAL, "nfft %d outside [win_len, %ld]", nfft, XCX_SPECTROGRAM_MAX_NFFT);
   if (n < win_len) return set_err(XCX_EINVAL, "row shorter than one segment (%ld < %d)", n, win_len);
   HIP_TRY(hipSetDevice(ctx->device));
   const int nfreq = nfft / 2 + 1;
@@ -240,8 +240,8 @@ extern "C" int xcx_spectrogram(xcx_ctx* ctx, const float* x, float* S, long batc
   void *ha = nullptr, *hb = nullptr;
   HostPin pin_x(on_device ? nullptr : x, in_b), pin_S(on_device ? nullptr : S, out_b);
   if (!on_device) {
-    HIP_TRY(hipMalloc(&ha, in_b));
-    if (hipMalloc(&hb, out_b) != hipSuccess) { (void)hipFree(ha); return set_err(XCX_ENOMEM, "spectrogram output (%zu bytes)", out_b); }
+    HIP_TRY(ctx_malloc(ctx, &ha, in_b));
+    if (ctx_malloc(ctx, &hb, out_b) != hipSuccess) { (void)hipFree(ha); return set_err(XCX_ENOMEM, "spectrogram output (%zu bytes)", out_b); }
     (void)hipMemcpyAsync(ha, x, in_b, hipMemcpyHostToDevice, ctx->stream);
     xd = (const float*)ha; Sd = (float*)hb;
   }
@@ -333,12 +333,12 @@ extern "C" int xcx_spectrogram_seg(xcx_ctx* ctx, const float* x, float* S, long 
   if (win_len < 2) return set_err(XCX_EINVAL, "win_len must be >= 2");
   if (hop < 1 || hop > win_len) return set_err(XCX_EINVAL, "hop %ld outside [1, win_len]", hop);
   if (nfft < win_len) return set_err(XCX_EINVAL, "nfft %d < win_len %d", nfft, win_len);
-  if (nfft > (1 << 22)) return set_err(XCX_EUNSUPPORTED, "nfft %d beyond 2^22", nfft);
+  if (nfft > XCX_SPECTROGRAM_SEG_MAX_NFFT) return set_err(XCX_EUNSUPPORTED, "nfft %d beyond %ld", nfft, XCX_SPECTROGRAM_SEG_MAX_NFFT);
   if (n < win_len) return set_err(XCX_EINVAL, "row shorter than one segment (%ld < %d)", n, win_len);
   HIP_TRY(hipSetDevice(ctx->device));
   const long nseg = (n - win_len) / hop + 1;
   const int nfreq = nfft / 2 + 1;
-  if (win_len <= 256 && nfft <= 8192) {
+  if (win_len <= XCX_SPECTROGRAM_MAX_WIN && nfft <= XCX_SPECTROGRAM_MAX_NFFT) {
     // short segments: the same Hankel GEMM on the matrix cores as the hop-1 spectrogram, with column stride `hop`
     // (the DFT-engine route below spent 205 us on a row the hop-1 kernel, with 25 x the segments, does in 14)
     const size_t in_b = sizeof(float) * (size_t)batch * n, out_b = sizeof(float) * (size_t)batch * nfreq * nseg;
@@ -346,12 +346,14 @@ extern "C" int xcx_spectrogram_seg(xcx_ctx* ctx, const float* x, float* S, long 
     void *ha = nullptr, *hb = nullptr;
     HostPin pin_x(on_device ? nullptr : x, in_b), pin_S(on_device ? nullptr : S, out_b);
     if (!on_device) {
-      HIP_TRY(hipMalloc(&ha, in_b));
-      if (hipMalloc(&hb, out_b) != hipSuccess) { (void)hipFree(ha); return set_err(XCX_ENOMEM, "spectrogram output (%zu bytes)", out_b); }
-      (void)hipMemcpyAsync(ha, x, in_b, hipMemcpyHostToDevice, ctx->stream);
+      HIP_TRY(ctx_malloc(ctx, &ha, in_b));
+      if (ctx_malloc(ctx, &hb, out_b) != hipSuccess) { (void)hipFree(ha); return set_err(XCX_ENOMEM, "spectrogram output (%zu bytes)", out_b); }
       xd = (const float*)ha; Sd = (float*)hb;
     }
-    int rc = sg_launch(ctx, xd, Sd, batch, n, win_len, nfft, window, scale, detrend, hop, nseg, nseg, 0);
+    int rc = XCX_OK;
+    if (!on_device && hipMemcpyAsync(ha, x, in_b, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+      rc = set_err(XCX_EHIP, "copy of the input rows to the device failed");      // never run the kernel on uninitialised memory
+    if (rc == XCX_OK) rc = sg_launch(ctx, xd, Sd, batch, n, win_len, nfft, window, scale, detrend, hop, nseg, nseg, 0);
     if (!on_device && rc == XCX_OK && hipMemcpyAsync(S, Sd, out_b, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
       rc = set_err(XCX_EHIP, "copy back failed");
     if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == XCX_OK) rc = set_err(XCX_EHIP, "stream sync failed");
@@ -368,14 +370,14 @@ extern "C" int xcx_spectrogram_seg(xcx_ctx* ctx, const float* x, float* S, long 
   void *dw = nullptr, *dfr = nullptr, *dsp = nullptr, *ha = nullptr, *hb = nullptr;
   auto cleanup = [&]() { (void)hipFree(dw); (void)hipFree(dfr); (void)hipFree(dsp); (void)hipFree(ha); (void)hipFree(hb); };
   auto fail = [&](int rc) { cleanup(); return rc; };
-  if (hipMalloc(&dw, sizeof(float) * win_len) != hipSuccess ||
-      hipMalloc(&dfr, sizeof(float) * (size_t)nfft * (cplx ? 2 : 1) * chunk) != hipSuccess ||
-      hipMalloc(&dsp, sizeof(float2) * (size_t)(cplx ? nfft : nfreq) * chunk) != hipSuccess)
+  if (ctx_malloc(ctx, &dw, sizeof(float) * win_len) != hipSuccess ||
+      ctx_malloc(ctx, &dfr, sizeof(float) * (size_t)nfft * (cplx ? 2 : 1) * chunk) != hipSuccess ||
+      ctx_malloc(ctx, &dsp, sizeof(float2) * (size_t)(cplx ? nfft : nfreq) * chunk) != hipSuccess)
     return fail(set_err(XCX_ENOMEM, "spectrogram workspaces"));
   const size_t in_b = sizeof(float) * (size_t)batch * n, out_b = sizeof(float) * (size_t)batch * nfreq * nseg;
   const float* xd = x; float* Sd = S;
   if (!on_device) {
-    if (hipMalloc(&ha, in_b) != hipSuccess || hipMalloc(&hb, out_b) != hipSuccess)
+    if (ctx_malloc(ctx, &ha, in_b) != hipSuccess || ctx_malloc(ctx, &hb, out_b) != hipSuccess)
       return fail(set_err(XCX_ENOMEM, "spectrogram buffers"));
     (void)hipMemcpyAsync(ha, x, in_b, hipMemcpyHostToDevice, ctx->stream);
     xd = (const float*)ha; Sd = (float*)hb;

@@ -127,7 +127,7 @@ static int timeshift_rows(xcx_ctx* ctx, const float* x, float* y, long batch, lo
   int rc;
   if (!ctx->ts_plan || ctx->ts_n != n) {
     if (ctx->ts_plan) { xcx_plan_destroy(ctx->ts_plan); ctx->ts_plan = nullptr; }
-    if (n > 0x7fffffffL / 2) return set_err(XCX_EUNSUPPORTED, "row too long");
+    if (n > XCX_MAX_ROW_SAMPLES) return set_err(XCX_EUNSUPPORTED, "row too long");
     // direct form: operands of 2n-1 samples (the row is zero beyond its first n), lags -(n-1) .. 0 retained;
     // such a plan is alias-free at N >= 2n-1 (kPlanShortOperand, xcx_api.hip)
     const int np = (int)(2 * n - 1);

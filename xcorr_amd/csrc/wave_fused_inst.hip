@@ -18,6 +18,16 @@ hipError_t XCX_CAT3(launch_wdual_, XCX_FC_L, _, XCX_FR_L)(const WDualArgs& a, hi
   constexpr size_t lds = sizeof(float) * PG::kLdsFloats;
   const int Bm = a.Bc > a.Br ? a.Bc : a.Br;
   const dim3 grid(8u * (unsigned)((PG::CWX + PG::RWX) * Bm));
+  if (a.ts == 1) {
+    // q24 storage of T: plain pair products of whitened spectra only (the bound behind the fixed-point scale)
+    if constexpr (DualQ24<RXC, RXR>::ok) {
+      if (a.nstack != 1) return hipErrorInvalidValue;
+      hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, 0, 1>), grid, dim3(kWNT * kWPB), lds, s, a);
+      return hipGetLastError();
+    } else {
+      return hipErrorInvalidValue;
+    }
+  }
   if (a.nstack < 0)
     hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, 2>), grid, dim3(kWNT * kWPB), lds, s, a);
   else if (a.nstack > 1)
@@ -26,6 +36,8 @@ hipError_t XCX_CAT3(launch_wdual_, XCX_FC_L, _, XCX_FR_L)(const WDualArgs& a, hi
     hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, 0>), grid, dim3(kWNT * kWPB), lds, s, a);
   return hipGetLastError();
 }
+
+int XCX_CAT3(wdual_q24_, XCX_FC_L, _, XCX_FR_L)() { return DualQ24<RXC, RXR>::ok ? 1 : 0; }
 
 hipError_t XCX_CAT3(launch_wflow_, XCX_FC_L, _, XCX_FR_L)(const WFlowArgs& a, hipStream_t s) {
   using PG = PairGeom<RXC, RXR>;

@@ -97,6 +97,45 @@ XCX_DEV unsigned t_off(int res, int TC, int N2h) {
 XCX_DEV const cf* t_rows16(const cf* __restrict__ Tpw, int blk, int N2h, int TC) {
   return Tpw + t_off(blk * kWRB, TC, N2h);
 }
+// ---------------------------------------------------------------------------
+// T storage of the dual pair kernel (template parameter TS)
+//   TS = 0 : float2, 8 bytes per element
+//   TS = 1 : q24 -- (re, im) as two 24-bit two's-complement FIXED-POINT numbers, 6 bytes per element, for plans whose
+//            spectra have a known modulus (whitened plans: |X[k]| = gain(k) * scale exactly, so |T| <= scale^2 *
+//            sum_k1 gain^2 =: Bmax is a bound, not a statistic).  A column wave rounds T * tq to the nearest integer
+//            (tq = 0.98 * 2^23 / Bmax; v_cvt_rpi_i32_f32), keeps the low three bytes of each number and stores two
+//            adjacent rows as 12 bytes per lane; a row wave rebuilds i / tq.  Quantisation step Bmax / (0.98 * 2^23):
+//            ~1e-6 of rms(T) for the 0.1-10 Hz band at 50 Hz (Bmax / rms(T) = sqrt(in-band bins of a column));
+//            measured against float2 storage in profiles/r05_t24_error_table.txt.  The arithmetic on both sides
+//            stays float32.
+//   Same element indexing in both: [res / TC][k2][res % TC]; a pair-window's slot keeps its 8-byte pitch.
+// ---------------------------------------------------------------------------
+constexpr float kQ24Range = 8388608.f;           // 2^23: |T * tq| stays below 0.98 of it
+// round to nearest (floor(x + 0.5)); v_cvt_i32_f32 would truncate towards zero, a bias of half a step
+XCX_DEV float q24_round(float x) {
+  int r;
+  asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return __int_as_float(r);
+}
+template <int TS> XCX_DEV const char* t_rows16_b(const cf* __restrict__ Tpw, int blk, int N2h, int TC) {
+  return reinterpret_cast<const char*>(Tpw) + (size_t)t_off(blk * kWRB, TC, N2h) * (TS == 1 ? 6u : 8u);
+}
+// 4 numbers whose low three bytes are kept -> 3 dwords
+XCX_DEV void q24_pack(unsigned d0, unsigned d1, unsigned d2, unsigned d3, unsigned (&o)[3]) {
+  o[0] = __builtin_amdgcn_perm(d1, d0, 0x04020100u);
+  o[1] = __builtin_amdgcn_perm(d2, d1, 0x05040201u);
+  o[2] = __builtin_amdgcn_perm(d3, d2, 0x06050402u);
+}
+// ... and back: the three bytes go to the TOP of a dword (sign in place, low byte zero) = 256 i; s = tqi / 256
+XCX_DEV void q24_unpack(unsigned o0, unsigned o1, unsigned o2, float s, cf& a, cf& b) {
+  const int u0 = (int)__builtin_amdgcn_perm(o0, o0, 0x0201000cu);
+  const int u1 = (int)__builtin_amdgcn_perm(o1, o0, 0x0504030cu);
+  const int u2 = (int)__builtin_amdgcn_perm(o2, o1, 0x0403020cu);
+  const int u3 = (int)(o2 & 0xffffff00u);
+  a = make_float2((float)u0 * s, (float)u1 * s);
+  b = make_float2((float)u2 * s, (float)u3 * s);
+}
+
 // staging buffer of the workgroup-cooperative CCF store: (N2h + 1) lag blocks x 64 rows of float
 constexpr int lds_stage_floats(int N2h) { return (N2h + 1) * kTR; }
 
@@ -458,10 +497,15 @@ struct WI1Args {
 // descriptor d, column k2, T slot base `T`
 // MODE 0: C = X_a conj X_b;  1: sum of that over TWO consecutive slots (nstack == 2);
 // 2: C is read from a precomputed cross-spectrum (slot_a of the Gram buffer; nstack < 0)
-template <class RX, int MODE>
+template <class RX> struct ColPairStore {
+  using CG = ColGeom<RX>;
+  static constexpr bool ok = ColRot<RX>::ok && (CG::RL % 2 == 0) && (CG::Last::IT == 1) && (CG::NSL == kTR);
+};
+template <class RX, int MODE, int TS = 0>
 XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_t spec_pitch,
                            const PwDesc d, int nstack, int k2, cf* __restrict__ T,
-                           const cf* __restrict__ tw_sub, const cf* __restrict__ twN, const Geom& g XCX_ST_PARAM) {
+                           const cf* __restrict__ tw_sub, const cf* __restrict__ twN, const Geom& g XCX_ST_PARAM,
+                           float tq = 0.f) {
   constexpr int N1 = RX::L;
   const int N2h = g.N2h;
   const cf* __restrict__ A = X + (size_t)d.slot_a * spec_pitch + (size_t)k2 * N1;
@@ -478,7 +522,8 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
   // With NSL = 64 the stores go out as lane PAIRS (below): lanes 0..31 are given the even residues
   // 0, 2, .., 62 and lanes 32..63 the odd ones, so that one v_permlane32_swap per register pair hands
   // lane L rows (2L, 2L+1) of an even tile and lane 32+L the same rows of the next tile.
-  constexpr bool kPairStore = ColRot<RX>::ok && (CG::RL % 2 == 0) && (CG::Last::IT == 1) && (CG::NSL == kTR);
+  constexpr bool kPairStore = ColPairStore<RX>::ok;
+  static_assert(TS == 0 || kPairStore, "q24 storage is written by the lane-pair stores only");
   const int rlane = kPairStore ? (2 * (tid_of<kWNT>() & 31) + (tid_of<kWNT>() >> 5)) : tid_of<kWNT>();   // residue mod 64
   const int ltid = ColRot<RX>::ok ? ((rlane - shift) & (kWNT - 1)) : tid_of<kWNT>();
   cf f0[CG::Last::IT];
@@ -488,6 +533,7 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
     const int j = (CG::Last::GUARD && b >= CG::Last::NBF) ? 0 : b;
     const int k = j % CG::NSL;
     f0[it] = twN_lookup(twN, (unsigned)((j - k) * CG::RL + k) * kk);
+    if constexpr (TS == 1) f0[it] = cscale(f0[it], tq);         // the four-step factor carries the fixed-point scale
   }
   const cf gstep = twN_lookup(twN, (unsigned)CG::NSL * kk);
   // Band-limited spectra (whitened plans, Geom::band_hi): column k2 is exactly zero for k1 in [za, zb],
@@ -539,6 +585,7 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
         else f = cmul(f, gstep);
       }
       v[t] = cmulc(v[t], f);
+      if constexpr (TS == 1) v[t] = make_float2(q24_round(v[t].x), q24_round(v[t].y));     // integer bits from here on
     });
     if constexpr (kPairStore) {
       // NSL = 64: lane l holds residue l of the RL = N1/64 tiles a_l + t, a_l = a0 + (l < shift % 64)
@@ -575,8 +622,16 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
           __builtin_amdgcn_raw_buffer_store_b128(w4, trsrc, (int)(o * 8u), 0, XCX_TST_AUX);
         }
 #else
-        *reinterpret_cast<float4*>(uoff(Tc, o)) =
-            make_float4(__uint_as_float(sx[0]), __uint_as_float(sy[0]), __uint_as_float(sx[1]), __uint_as_float(sy[1]));
+        if constexpr (TS == 1) {
+          typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+          unsigned q[3];
+          q24_pack(sx[0], sy[0], sx[1], sy[1], q);
+          char* tb = reinterpret_cast<char*>(T) + (size_t)((unsigned)(k2 * TC) * 6u);
+          *reinterpret_cast<u32x3*>(tb + (size_t)(o * 6u)) = u32x3{q[0], q[1], q[2]};
+        } else {
+          *reinterpret_cast<float4*>(uoff(Tc, o)) =
+              make_float4(__uint_as_float(sx[0]), __uint_as_float(sy[0]), __uint_as_float(sx[1]), __uint_as_float(sy[1]));
+        }
 #endif
       });
     } else {
@@ -665,16 +720,30 @@ template <bool SC1> XCX_DEV cf load_t(const cf* p) {
 // pair-windows/s, 16-byte 256-byte runs at 1.57 M.  `stg` = workgroup-wide staging buffer
 // (lds_stage_floats(N2h) floats, may alias the waves' exchange buffers); contains __syncthreads().
 // TCT: T chunk rows (t_chunk(N1)) when N1 is known at compile time, 0 = from g.N1
-template <class RX, bool SC1, bool UNBIAS, int TCT = 0>
+// PR ("pair rows", always with TS = 1; -DXCX_ROW_PAIRS: with float2 storage as well): a lane takes TWO adjacent rows
+// of one first-stage butterfly pair instead of one row in each of two iterations -- lane = (j, row pair), one
+// iteration, 12- / 16-byte T loads (half the load instructions), the untangle twiddles shared by the two rows.
+// Needs (S/2 + 1) * 8 == 64 work items: N2h / R0 in {14, 15} (the N2h = 120 rows of the day-long configs).
+template <class RX> struct RowPairs {
+  static constexpr int S = RX::L / RX::R0;
+  static constexpr bool ok = ((S / 2 + 1) * (kWRB / 2) == kWNT);
+};
+#ifndef XCX_ROW_PAIRS
+#define XCX_ROW_PAIRS 0
+#endif
+template <class RX, bool SC1, bool UNBIAS, int TCT = 0, int TS = 0>
 XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, float* __restrict__ out, int blk,
                            const cf* __restrict__ tw_sub, const cf* __restrict__ twu,
-                           float* __restrict__ stg, const Geom& g XCX_ST_PARAM) {
+                           float* __restrict__ stg, const Geom& g XCX_ST_PARAM, float tqi = 0.f) {
   constexpr int N2h = RX::L;
   constexpr int R = RX::R0;
   constexpr int S = N2h / R;
   constexpr int NITEM = S / 2 + 1;
   constexpr int TOTAL = NITEM * kWRB;
   constexpr int IT = (TOTAL + kWNT - 1) / kWNT;
+  constexpr bool PR = (TS == 1) || (XCX_ROW_PAIRS && RowPairs<RX>::ok && !SC1);
+  static_assert(!PR || (RowPairs<RX>::ok && IT == 2), "pair-row mapping: 8 butterfly pairs x 8 row pairs = one wave");
+  static_assert(TS == 0 || !SC1, "q24 storage: dual kernel only");
   const int N1 = g.N1, N = g.N, n = g.n;
   const int TC = TCT ? TCT : t_chunk(N1);          // elements from one k2 to the next
   const int lane = tid_of<kWNT>();
@@ -720,7 +789,36 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
 #pragma unroll
     for (int t = 0; t < R; ++t) { s0a[it][t] = uj[t]; s0b[it][t] = ujp[t]; }
   };
-  {
+  if constexpr (PR) {
+    const int r2 = 2 * (lane & 7);                  // rows r2, r2 + 1 of the wave's 16
+    const int j = lane >> 3;                        // 0..S/2
+    const int jp = (j == 0) ? 0 : (S - j);
+    const bool single = jp == j;
+    cf ava[R], avb[R], bva[R], bvb[R];
+    float nya = 0.f, nyb = 0.f;
+    const char* __restrict__ Tb = reinterpret_cast<const char*>(Tt);
+    const float qs = tqi * (1.f / 256.f);
+    auto load2 = [&](int k2, cf& a, cf& b) {
+      if constexpr (TS == 1) {
+        typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+        const u32x3 q = *reinterpret_cast<const u32x3*>(Tb + (size_t)((unsigned)(k2 * TC + r2) * 6u));
+        q24_unpack(q[0], q[1], q[2], qs, a, b);
+      } else {
+        const float4 q = *reinterpret_cast<const float4*>(Tb + (size_t)((unsigned)(k2 * TC + r2) * 8u));
+        a = make_float2(q.x, q.y); b = make_float2(q.z, q.w);
+      }
+    };
+#pragma unroll
+    for (int t = 0; t < R; ++t) load2(j + S * t, ava[t], avb[t]);
+    if (!single) {
+#pragma unroll
+      for (int t = 0; t < R; ++t) load2(jp + S * t, bva[t], bvb[t]);
+    }
+    if (j == 0) { cf na, nb; load2(N2h, na, nb); nya = na.x; nyb = nb.x; }
+    untangle(0, j, single, ava, bva, nya);
+    untangle(1, j, single, avb, bvb, nyb);
+    XCX_STAMP(2, s0a[0][0].x);
+  } else {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int w = lane + it * kWNT;
@@ -747,6 +845,23 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
   cf v1[G1::IT][RX::R1];
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
+    if constexpr (PR) {
+      // the lane's two rows are neighbours in the [pos][16] buffer: one 8-byte store per butterfly output
+      const int r = 2 * (lane & 7), j = lane >> 3;
+      const int jp = (j == 0) ? 0 : (S - j);
+      static_assert(!PR || R % 8 == 0, "pair-row LDS stores assume a first radix of 8");
+      const int wa = rpad(j * R, r), wb = rpad(jp * R, r);
+#pragma unroll
+      for (int t = 0; t < R; ++t)
+        *reinterpret_cast<float2*>(ldsf + wa + (t + (t >> 3)) * kWRB) =
+            half ? make_float2(s0a[0][t].y, s0a[1][t].y) : make_float2(s0a[0][t].x, s0a[1][t].x);
+      if (jp != j) {
+#pragma unroll
+        for (int t = 0; t < R; ++t)
+          *reinterpret_cast<float2*>(ldsf + wb + (t + (t >> 3)) * kWRB) =
+              half ? make_float2(s0b[0][t].y, s0b[1][t].y) : make_float2(s0b[0][t].x, s0b[1][t].x);
+      }
+    } else {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int w = lane + it * kWNT;
@@ -766,6 +881,7 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
         for (int t = 0; t < R; ++t)
           ldsf[WF ? wb + (t + (t >> 3)) * kWRB : rpad(jp * R + t, r)] = half ? s0b[it][t].y : s0b[it][t].x;
       }
+    }
     }
     group_sync<kWNT>();
 #pragma unroll
@@ -910,9 +1026,15 @@ struct WDualArgs {
   const PwDesc* pw_r; int Br; const cf* Tr; float* out;               // row pass: batch b-1
   const cf* tw_N1; const cf* tw_N2h; const cf* tw_unt; const cf* tw_N;
   Geom g;
+  int ts;                          // T storage: 0 float2, 1 q24 (whitened plans; tq = fixed-point scale, tqi = 1 / tq)
+  float tq, tqi;
 #ifdef XCX_STAMPS
   unsigned long long* stamps;      // [waves of the launch][kNStamp] or null
 #endif
+};
+// q24 storage exists for the (N1, N2h) whose column wave stores lane pairs and whose row wave maps row pairs
+template <class RXC, class RXR> struct DualQ24 {
+  static constexpr bool ok = ColPairStore<RXC>::ok && RowPairs<RXR>::ok;
 };
 
 // amdgpu_waves_per_eu(4,4): the pair pass is bound by memory latency x occupancy (the arithmetic
@@ -940,7 +1062,7 @@ template <class RXC, class RXR> struct PairGeom {
   static_assert(N1 % kTR == 0, "column lengths are multiples of 64");
 };
 
-template <class RXC, class RXR, int MODE>
+template <class RXC, class RXR, int MODE, int TS = 0>
 __global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(XCX_DUAL_WAVES, XCX_DUAL_WAVES)))
 void k_wpair_dual(WDualArgs a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
@@ -980,20 +1102,21 @@ void k_wpair_dual(WDualArgs a) {
     if (ci >= per || item >= (N2h + 1) * a.Bc) return;
     const int k2 = item / a.Bc;
     const int pwl = item - k2 * a.Bc;
-    pair_col_body<RXC, MODE>(lds, a.X, a.spec_pitch, a.pw_c[pwl], a.nstack, k2,
-                              a.Tc + (size_t)pwl * N1 * (N2h + 1), a.tw_N1, a.tw_N, g XCX_ST_ARG);
+    pair_col_body<RXC, MODE, TS>(lds, a.X, a.spec_pitch, a.pw_c[pwl], a.nstack, k2,
+                                  a.Tc + (size_t)pwl * N1 * (N2h + 1), a.tw_N1, a.tw_N, g XCX_ST_ARG, a.tq);
   } else {
     const int ri = grp * PG::RWX + (pos - PG::CWX);
     const int pwl = ri / PG::RWX;
     const int wgblk = (ri % PG::RWX) * 8 + x;
     if (wgblk >= PG::NRW || pwl >= a.Br) return;             // workgroup-uniform
     const int blk = wgblk * kWPB + wave;
-    const cf* __restrict__ Tt = t_rows16(a.Tr + (size_t)pwl * N1 * (N2h + 1), blk, N2h, t_chunk(N1));
+    const cf* __restrict__ Tt = reinterpret_cast<const cf*>(
+        t_rows16_b<TS>(a.Tr + (size_t)pwl * N1 * (N2h + 1), blk, N2h, t_chunk(N1)));
     float* stg = reinterpret_cast<float*>(lds_all);
     if (g.flags & XCX_F_UNBIAS)
-      pair_row_body<RXR, false, true, t_chunk(N1)>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG);
+      pair_row_body<RXR, false, true, t_chunk(N1), TS>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG, a.tqi);
     else
-      pair_row_body<RXR, false, false, t_chunk(N1)>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG);
+      pair_row_body<RXR, false, false, t_chunk(N1), TS>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG, a.tqi);
   }
 }
 

@@ -55,9 +55,14 @@ static const WColEntry kWCols[] = {XCX_WCOL_LIST(XCX_WCOL_ROW)};
 static const WRowEntry kWRows[] = {XCX_WROW_LIST(XCX_WROW_ROW)};
 static const int kNWCols = sizeof(kWCols) / sizeof(kWCols[0]);
 static const int kNWRows = sizeof(kWRows) / sizeof(kWRows[0]);
-#define XCX_WFUSED_ROW(C, R) {C, R, launch_wdual_##C##_##R, launch_wflow_##C##_##R},
+#define XCX_WFUSED_ROW(C, R) {C, R, launch_wdual_##C##_##R, launch_wflow_##C##_##R, wdual_q24_##C##_##R},
 static const WFusedEntry kWFused[] = {XCX_WFUSED_LIST(XCX_WFUSED_ROW)};
 static const int kNWFused = sizeof(kWFused) / sizeof(kWFused[0]);
+// default T storage of whitened plans: q24 after the error table of profiles/r05_t24_error_table.txt
+#ifndef XCX_Q24_DEFAULT
+#define XCX_Q24_DEFAULT 0
+#endif
+static const bool kQ24Default = XCX_Q24_DEFAULT != 0;
 
 // ---------------------------------------------------------------------------
 // k_wstats: partial sums of a station-window, grid = (kStatParts, cnt).
@@ -182,7 +187,24 @@ extern "C" int xcx_device_name(xcx_ctx* ctx, char* buf, size_t len) {
 extern "C" int xcx_malloc(xcx_ctx* ctx, size_t bytes, void** dptr) {
   if (!ctx || !dptr) return set_err(XCX_EINVAL, "null argument");
   HIP_TRY(hipSetDevice(ctx->device));
-  HIP_TRY(hipMalloc(dptr, bytes ? bytes : 1));
+  HIP_TRY(ctx_malloc(ctx, dptr, bytes ? bytes : 1));
+  return XCX_OK;
+}
+// every numeric limit include/xcx.h quotes, as this build enforces it
+static_assert(kMaxTransformN == XCX_MAX_SINGLE_TRANSFORM, "include/xcx.h: XCX_MAX_SINGLE_TRANSFORM");
+extern "C" int xcx_limits(long* out, int count) {
+  if (!out || count < 1) return set_err(XCX_EINVAL, "null argument");
+  const long v[XCX_LIM_COUNT] = {
+      XCX_MAX_SINGLE_TRANSFORM, XCX_MAX_CHIRP_POINTS, XCX_MAX_ROW_SAMPLES, XCX_MAX_SPLIT_PARTS, XCX_CC2D_MAX_F, XCX_CC2D_MAX_L,
+      XCX_RAM_MAX_HALF_WIDTH, XCX_SOS_MAX_SECTIONS, XCX_SPECTROGRAM_MAX_WIN, XCX_SPECTROGRAM_MAX_NFFT,
+      XCX_SPECTROGRAM_SEG_MAX_NFFT, XCX_ROWS_MAX_BATCH, XCX_SEG_WORKSPACE_MAX_GB};
+  for (int i = 0; i < count && i < XCX_LIM_COUNT; ++i) out[i] = v[i];
+  return XCX_OK;
+}
+extern "C" int xcx_set_reclaim(xcx_ctx* ctx, size_t (*cb)(void*), void* user) {
+  if (!ctx) return set_err(XCX_EINVAL, "null ctx");
+  ctx->reclaim = cb;
+  ctx->reclaim_user = user;
   return XCX_OK;
 }
 extern "C" int xcx_free(xcx_ctx* ctx, void* dptr) {
@@ -273,13 +295,29 @@ extern "C" int xcx_timer_stop(xcx_ctx* ctx, float* ms) {
 // workspace helper
 // ---------------------------------------------------------------------------
 namespace xcx {
+size_t ctx_reclaim(xcx_ctx* ctx) {
+  if (!ctx || !ctx->reclaim) return 0;
+  auto cb = ctx->reclaim;
+  ctx->reclaim = nullptr;                       // not re-entered from the xcx_free calls it makes
+  const size_t got = cb(ctx->reclaim_user);
+  ctx->reclaim = cb;
+  return got;
+}
+hipError_t ctx_malloc(xcx_ctx* ctx, void** ptr, size_t nbytes) {
+  hipError_t e = hipMalloc(ptr, nbytes);
+  if (e == hipErrorOutOfMemory && ctx_reclaim(ctx) > 0) {
+    (void)hipGetLastError();
+    e = hipMalloc(ptr, nbytes);
+  }
+  return e;
+}
 int DevBuf::ensure(xcx_ctx* ctx, size_t need) {
   if (need <= bytes) return XCX_OK;
   HIP_TRY(hipStreamSynchronize(ctx->stream));
   if (ptr) HIP_TRY(hipFree(ptr));
   ptr = nullptr;
   bytes = 0;
-  HIP_TRY(hipMalloc(&ptr, need));
+  HIP_TRY(ctx_malloc(ctx, &ptr, need));
   bytes = need;
   // process-wide allocation number: (ptr, gen) identifies THIS memory even when the allocator hands the same
   // address to another buffer later (a per-buffer count could repeat there and revive a stale "zeroed" record)
@@ -350,6 +388,9 @@ struct xcx_plan {
   float wb[4] = {0, 0, 0, 0};
   float fixed_norm = 1.f;
   bool whiten_set = false;
+  // q24 storage of the intermediate T (wave_kernels.h): fixed-point scale from the bound of |T| of a whitened plan
+  float tq = 0.f, tqi = 0.f;
+  bool t_q24 = false;        // the dual launches of plain pair products store T as 2 x 24 bits
   // tables
   DevBuf tw_N1, tw_N2h, tw_unt, tw_N;
   // workspaces
@@ -598,6 +639,42 @@ extern "C" int xcx_plan_set_whiten(xcx_plan* p, double fs, double fmin,
   }
   p->fixed_norm = (float)sqrt(acc / N);
   p->whiten_set = true;
+  // q24 storage of T: |X[k]| = gain(k) * scale exactly, so |T[m1][k2]| <= scale^2 * sum_k1 gain(k1 N2 + k2)^2 for
+  // every input; the largest column sum gives the fixed-point scale (2 % headroom for the float32 rounding of the
+  // transform).  XCX_T_STORAGE=f32 keeps float2.
+  {
+    const Geom& g = p->g;
+    double bmax = 0.0;
+    for (int k2 = 0; k2 <= g.N2h; ++k2) {
+      double sum = 0.0;
+      for (int k1 = 0; k1 < g.N1; ++k1) {
+        long long k = (long long)k1 * g.N2 + k2;
+        if (k > N - k) k = N - k;
+        const float f = (float)k;
+        double gk;
+        if (f >= p->wb[1] && f <= p->wb[2]) gk = 1.0;
+        else if (f >= p->wb[0] && f < p->wb[1]) gk = 0.5 * (1.0 - cos(M_PI * (f - p->wb[0]) / (p->wb[1] - p->wb[0])));
+        else if (f > p->wb[2] && f <= p->wb[3]) gk = 0.5 * (1.0 + cos(M_PI * (f - p->wb[2]) / (p->wb[3] - p->wb[2])));
+        else gk = 0.0;
+        sum += gk * gk;
+      }
+      bmax = std::max(bmax, sum);
+    }
+    const double nrm = (g.flags & XCX_F_NORMALIZE) ? (double)p->fixed_norm : 1.0;
+    const double sc = (double)(float)(1.0 / (nrm * sqrt((double)N)));      // sw_scale()
+    const double B = bmax * sc * sc;
+    const char* ts_env = getenv("XCX_T_STORAGE");      // read per call: a process may compare the two
+    const bool want = ts_env ? !strcmp(ts_env, "q24") : kQ24Default;
+    p->t_q24 = false;
+    if (want && (g.flags & XCX_F_WHITEN) && B > 0.0 && p->dual && p->dual->q24 && p->dual->q24()) {
+      const double tq = 0.98 * 8388608.0 / B;
+      if (std::isfinite(tq) && tq < 1e30 && tq > 1e-30) {
+        p->tq = (float)tq;
+        p->tqi = (float)(1.0 / (double)p->tq);
+        p->t_q24 = true;
+      }
+    }
+  }
   // whiten_gain() is 0 for every folded bin k > wb[3] (float compare, k exact below 2^24): those spectrum
   // elements are stored as exact zeros by the forward column pass and the pair pass skips their loads
   {
@@ -830,6 +907,10 @@ static int dual_launch(xcx_plan* p, int chain, size_t d0, int Bc, int nstack, fl
   a.tw_unt = (const cf*)p->tw_unt.ptr;
   a.tw_N = (const cf*)p->tw_N.ptr;
   a.g = g;
+  // plain pair products of whitened spectra (nstack == 1, no precomputed cross-spectrum): T may go through the ring as
+  // 2 x 24-bit fixed point; the row launch that reads a slot follows the column launch that wrote it within one run
+  a.ts = (p->t_q24 && nstack == 1 && !Xsrc && (g.flags & XCX_F_WHITEN) && p->whiten_set) ? 1 : 0;
+  a.tq = p->tq; a.tqi = p->tqi;
   if (Bc == 0 && a.Br == 0) return XCX_OK;
 #ifdef XCX_STAMPS
   {
@@ -1994,9 +2075,15 @@ static int seg_run(xcx_plan* p, const float* const* xs_h, const float* const* ys
       const long env_mb = eb ? atol(eb) : 0;
       size_t free_b = 0, total_b = 0;
       if (env_mb > 0) budget = (size_t)env_mb << 20;
-      else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-        budget = std::min<size_t>((size_t)64 << 30, std::max<size_t>((size_t)4 << 30, free_b / 2));
-      else (void)hipGetLastError();
+      else {
+        (void)ctx_reclaim(ctx);                  // buffers idling in the caller's pool count as free memory
+        const char* ef = getenv("XCX_SEG_FREE_MB");             // tests: pretend this much is free
+        if (ef && atol(ef) > 0) { free_b = (size_t)atol(ef) << 20; }
+        else if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)32 << 30; }
+        // half of what is free, at most 64 GB; no floor above the free memory itself (a 4 GB floor with 3 GB free
+        // failed where smaller chunks run); 64 MB is what one row of the largest block transform needs
+        budget = std::min<size_t>((size_t)XCX_SEG_WORKSPACE_MAX_GB << 30, std::max<size_t>((size_t)64 << 20, free_b / 2));
+      }
     }
     std::vector<int> ua, ub, ia, ib, ints;
     std::unordered_map<int, int> posa, posb;

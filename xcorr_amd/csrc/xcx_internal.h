@@ -9,7 +9,7 @@ struct xcx_ctx;
 // library-internal plan flag (above the 16 public flag bits of include/xcx.h), see xcx_plan_cc1d
 constexpr int kPlanShortOperand = 0x10000;
 // longest single transform of the instantiated kernels: N = 2 * N1 * N2h = 2 * 3072 * 128
-constexpr int kMaxTransformN = 786432;
+constexpr int kMaxTransformN = 786432;   // == XCX_MAX_SINGLE_TRANSFORM (include/xcx.h; asserted in xcx_api.hip)
 
 namespace xcx {
 int set_err(int code, const char* fmt, ...);
@@ -32,6 +32,10 @@ struct HostPin {
   HostPin& operator=(const HostPin&) = delete;
 };
 
+// hipMalloc that asks the caller's pool back once (xcx_ctx::reclaim) when the device is out of memory
+hipError_t ctx_malloc(xcx_ctx* ctx, void** ptr, size_t bytes);
+size_t ctx_reclaim(xcx_ctx* ctx);
+
 struct DevBuf {
   void* ptr = nullptr;
   size_t bytes = 0;
@@ -44,6 +48,11 @@ struct DevBuf {
 struct xcx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  // The caller may keep freed device buffers in a pool of its own (the Python binding does): the library asks for
+  // them back before it gives up on an allocation and before it sizes a workspace from the free device memory
+  // (xcx_set_reclaim).  The callback may call xcx_free; it returns the number of bytes it released.
+  size_t (*reclaim)(void* user) = nullptr;
+  void* reclaim_user = nullptr;
   // Streams of the pair-phase pipelines, shared by every plan of the context and created WITH the context: a
   // process has few hardware queues (4 by default) and HIP deals streams onto them in creation order, so two
   // pipelines created late (after the streams of other plans) can land on ONE queue and lose their overlap --

@@ -6,6 +6,7 @@ This is plumbing only; all arithmetic happens in libxcx.so.
 """
 import ctypes as C
 import os
+import time
 import weakref
 
 import numpy as np
@@ -114,19 +115,57 @@ class Context:
         self._children = weakref.WeakSet()      # plans and arrays that must go first
         self._pin_pool = {}                     # capacity -> [addresses] of idle page-locked blocks
         self._pin_idle = 0                      # bytes held by those idle blocks
+        self._pin_live = 0                      # bytes of page-locked blocks inside live result arrays
         self._plans = {}                        # (n, lag slice, flags) -> CCPlan kept for repeated driver calls
         # Freed device buffers of a chain of row ops are handed to the next result of the same size instead of going
         # through hipFree / hipMalloc (milliseconds each for day-long rows, and hipFree drains the device): exact-size
-        # free lists, bounded (XCX_DEV_POOL_MB, default 8192; 0 = off; single blocks up to half of it).
-        self._dev_pool = {}                     # nbytes -> [device pointers]
+        # free lists in least-recently-freed order, bounded three ways -- XCX_DEV_POOL_MB (default 2048; 0 = off;
+        # single blocks up to half of it; the oldest blocks make room for a new one), an age limit (blocks idle for
+        # XCX_DEV_POOL_AGE_S seconds, default 30, go back to the driver at the next take / give: a chain whose row
+        # lengths keep changing -- trim, decimate, resample -- never reuses its sizes), and the library itself, which
+        # asks for everything back before one of its own allocations fails or a segmented plan sizes its workspace
+        # from the free device memory (xcx_set_reclaim).
+        self._dev_pool = {}                     # nbytes -> [(device pointer, time freed)], oldest first
         self._dev_pool_bytes = 0
-        self._dev_pool_cap = max(0, int(os.environ.get('XCX_DEV_POOL_MB', '8192'))) << 20
+        self._dev_pool_cap = max(0, int(os.environ.get('XCX_DEV_POOL_MB', '2048'))) << 20
+        self._dev_pool_age = float(os.environ.get('XCX_DEV_POOL_AGE_S', '30'))
+        wself = weakref.ref(self)                # no cycle through the callback object
+
+        def _cb(_user):
+            c = wself()
+            return c._reclaim() if c is not None else 0
+        self._reclaim_cb = _ffi.RECLAIM_CB(_cb)
+        check(_ffi.lib().xcx_set_reclaim(self.handle, C.cast(self._reclaim_cb, C.c_void_p), None))
+
+    def _reclaim(self):
+        """Called BY the library (xcx_set_reclaim): hand every pooled device buffer back, report the bytes."""
+        try:
+            got = self._dev_pool_bytes
+            self.trim_pool()
+            return got
+        except Exception:
+            return 0
+
+    def _pool_expire(self, now):
+        if not self._dev_pool_bytes or self._dev_pool_age <= 0:
+            return
+        for nbytes in list(self._dev_pool):
+            blocks = self._dev_pool[nbytes]
+            while blocks and now - blocks[0][1] > self._dev_pool_age:
+                p, _ = blocks.pop(0)
+                self._dev_pool_bytes -= nbytes
+                _ffi.lib().xcx_free(self.handle, C.c_void_p(p))
+            if not blocks:
+                del self._dev_pool[nbytes]
 
     def _pool_take(self, nbytes):
+        self._pool_expire(time.monotonic())
         blocks = self._dev_pool.get(nbytes)
         if not blocks:
             return None
-        p = blocks.pop()
+        p, _ = blocks.pop()                     # the most recently freed block of that size
+        if not blocks:
+            del self._dev_pool[nbytes]
         self._dev_pool_bytes -= nbytes
         # the previous owner's kernels may still be queued on the context's streams, and host copies run on another
         # (blocking) stream: wait once here -- what hipFree used to do implicitly
@@ -134,19 +173,28 @@ class Context:
         return p
 
     def _pool_give(self, p, nbytes):
-        if nbytes < (1 << 20) or nbytes > self._dev_pool_cap // 2 or self._dev_pool_bytes + nbytes > self._dev_pool_cap:
+        if nbytes < (1 << 20) or nbytes > self._dev_pool_cap // 2:
             return False
-        self._dev_pool.setdefault(nbytes, []).append(p)
+        now = time.monotonic()
+        self._pool_expire(now)
+        while self._dev_pool_bytes + nbytes > self._dev_pool_cap and self._dev_pool_bytes:
+            # least recently freed block of any size makes room
+            size = min(self._dev_pool, key=lambda k: self._dev_pool[k][0][1])
+            q, _ = self._dev_pool[size].pop(0)
+            if not self._dev_pool[size]:
+                del self._dev_pool[size]
+            self._dev_pool_bytes -= size
+            _ffi.lib().xcx_free(self.handle, C.c_void_p(q))
+        self._dev_pool.setdefault(nbytes, []).append((p, now))
         self._dev_pool_bytes += nbytes
         return True
 
     def trim_pool(self):
         """Return every pooled device buffer to the driver."""
-        for blocks in self._dev_pool.values():
-            for p in blocks:
+        pool, self._dev_pool, self._dev_pool_bytes = self._dev_pool, {}, 0
+        for blocks in pool.values():
+            for p, _ in blocks:
                 _ffi.lib().xcx_free(self.handle, C.c_void_p(p))
-        self._dev_pool = {}
-        self._dev_pool_bytes = 0
 
     def plan(self, n, index_min=0, index_max=None, **flags):
         """A :class:`CCPlan` owned by the context and reused by later calls with the same arguments
@@ -166,6 +214,7 @@ class Context:
             for child in list(self._children):
                 child.close()
             self.trim_pool()
+            _ffi.lib().xcx_set_reclaim(self.handle, None, None)
             for blocks in self._pin_pool.values():
                 for addr in blocks:
                     _ffi.lib().xcx_host_free(self.handle, C.c_void_p(addr))
@@ -196,6 +245,7 @@ class Context:
     # --- page-locked result arrays ------------------------------------------
     PIN_MAX = 2 << 30          # larger results come back in ordinary (pageable) numpy memory
     PIN_IDLE_MAX = 4 << 30     # idle page-locked bytes kept for reuse, per context
+    PIN_LIVE_MAX = 16 << 30    # page-locked bytes in live arrays + idle blocks, per context: beyond it results are pageable
     PIN_GRANULE = 2 << 20
 
     def pinned_empty(self, shape, dtype=np.float32):
@@ -218,10 +268,13 @@ class Context:
             addr = pool.pop()
             self._pin_idle -= cap
         else:
+            if self._pin_live + self._pin_idle + cap > self.PIN_LIVE_MAX:
+                return np.empty(shape, dtype)            # page-locked memory cannot be swapped: bounded per context
             p = C.c_void_p()
             if _ffi.lib().xcx_host_alloc(self.handle, cap, C.byref(p)) != 0 or not p.value:
                 return np.empty(shape, dtype)            # driver refused (limits, fragmentation): pageable result
             addr = p.value
+        self._pin_live += cap
         buf = (C.c_char * nbytes).from_address(addr)
         arr = np.frombuffer(buf, dtype=dtype, count=nbytes // dtype.itemsize).reshape(shape)
         ctx_ref = weakref.ref(self)
@@ -229,6 +282,8 @@ class Context:
 
         def _release(addr=addr, cap=cap):
             c = ctx_ref()
+            if c is not None:
+                c._pin_live -= cap
             if c is not None and c.handle:
                 lst = c._pin_pool.setdefault(cap, [])
                 if len(lst) < 4 and c._pin_idle + cap <= idle_max:

@@ -18,14 +18,16 @@ from .engine import DeviceArray, default_context
 __all__ = ['copy', 'norm1d', 'demean', 'detrend_linear', 'taper', 'taper_table', 'detrend_nan', 'unbias', 'post_prep',
            'onebit', 'sosfiltfilt', 'sosfilt', 'sosfilt_zerophase', 'timeshift', 'snr', 'correlate2d',
            'fft', 'ifft', 'rfft', 'irfft', 'hilbert', 'decimate', 'resample', 'lanczos', 'block_rms', 'spectrogram', 'spectrogram_seg',
-           'ram_normalize']
+           'ram_normalize', 'scale_rows', 'absmax_rows', 'rotate2']
 
 
-def _prep(x):
+def _prep(x, ctx=None):
     """-> (buffer, batch, n, on_device, restore).  Host rows are copied (the ops work in place on their argument, the
     mirrors of the reference return a new array): for a megabyte and more the copy lives in page-locked memory from
-    the default context's pool, so that the library's H2D / D2H of it run at link speed -- through pageable memory
-    the two transfers of a 68 MB block of CCF rows took 17 of a call's 21 ms."""
+    the CALLER's context pool (`ctx`; the default context only when the op was called without one), so that the
+    library's H2D / D2H of it run at link speed -- through pageable memory the two transfers of a 68 MB block of CCF
+    rows took 17 of a call's 21 ms.  An op given an explicit context never opens another one: a rank on GPU k must
+    not create streams, events and pinned pools on GPU 0."""
     if isinstance(x, DeviceArray):
         n = x.shape[-1]
         batch = int(np.prod(x.shape[:-1])) if len(x.shape) > 1 else 1
@@ -34,7 +36,7 @@ def _prep(x):
     if src.ndim == 0:
         raise ValueError('array with at least one dimension required')
     if src.size * 4 >= (1 << 20):
-        a = default_context().pinned_empty(src.shape, np.float32)
+        a = (ctx if ctx is not None else default_context()).pinned_empty(src.shape, np.float32)
         np.copyto(a, src, casting='unsafe')
     else:
         a = np.array(src, dtype=np.float32, order='C', copy=True)
@@ -68,7 +70,7 @@ def _ctx(ctx, x):
 def norm1d(ctx, x):
     """x / ||x||_2 (xcorr/signal/normalize.py:73-80)."""
     ctx = _ctx(ctx, x)
-    buf, b, n, dev, _ = _prep(x)
+    buf, b, n, dev, _ = _prep(x, ctx)
     check(_ffi.lib().xcx_norm1d(ctx.handle, ptr(buf), b, n, dev))
     return buf
 
@@ -97,7 +99,7 @@ def demean(ctx, x, out=None, cols=None):
         return out
     if out is not None:
         return _detrend_to(ctx, x, out, 0)
-    buf, b, n, dev, _ = _prep(x)
+    buf, b, n, dev, _ = _prep(x, ctx)
     check(_ffi.lib().xcx_demean(ctx.handle, ptr(buf), b, n, dev))
     return buf
 
@@ -105,7 +107,7 @@ def demean(ctx, x, out=None, cols=None):
 def detrend_linear(ctx, x):
     """Remove the least-squares line (xcorr/signal/detrend.py:87-99)."""
     ctx = _ctx(ctx, x)
-    buf, b, n, dev, _ = _prep(x)
+    buf, b, n, dev, _ = _prep(x, ctx)
     check(_ffi.lib().xcx_detrend_linear(ctx.handle, ptr(buf), b, n, dev))
     return buf
 
@@ -114,7 +116,7 @@ def taper(ctx, x, nmax, wtype='hann'):
     """Taper both flanks over nmax samples (xcorr/signal/window.py:92-106;
     wtype 'cosine' = ObsPy Trace.taper flank)."""
     ctx = _ctx(ctx, x)
-    buf, b, n, dev, _ = _prep(x)
+    buf, b, n, dev, _ = _prep(x, ctx)
     wt = {'hann': 0, 'cosine': 1}[wtype]
     check(_ffi.lib().xcx_taper(ctx.handle, ptr(buf), b, n, int(nmax), wt, dev))
     return buf
@@ -123,7 +125,7 @@ def taper(ctx, x, nmax, wtype='hann'):
 def unbias(ctx, x, npts, index_min=0, index_max=0):
     """x * npts/(npts-|lag|) (xcorr/signal/unbias.py:73-85)."""
     ctx = _ctx(ctx, x)
-    buf, b, n, dev, _ = _prep(x)
+    buf, b, n, dev, _ = _prep(x, ctx)
     index_max = index_max or 2 * npts - 1
     if n != index_max - index_min:
         raise ValueError('last dimension does not match the lag slice')
@@ -135,7 +137,7 @@ def unbias(ctx, x, npts, index_min=0, index_max=0):
 def detrend_nan(ctx, x, linear=False):
     """detrend with skipna=True (signal/detrend.py:87-110): fit on the finite samples, NaN stays NaN."""
     ctx = _ctx(ctx, x)
-    buf, b, n, dev, _ = _prep(x)
+    buf, b, n, dev, _ = _prep(x, ctx)
     check(_ffi.lib().xcx_detrend_nan(ctx.handle, ptr(buf), b, n, int(bool(linear)), dev))
     return buf
 
@@ -144,7 +146,7 @@ def taper_table(ctx, x, flanks):
     """Taper with explicit flanks: flanks = window(2*nmax) (float32, host): first half on the left,
     second half on the right (signal/window.py:92-106 for any scipy window)."""
     ctx = _ctx(ctx, x)
-    buf, b, n, dev, _ = _prep(x)
+    buf, b, n, dev, _ = _prep(x, ctx)
     fl = np.ascontiguousarray(flanks, dtype=np.float32)
     if fl.ndim != 1 or fl.size % 2:
         raise ValueError('flanks must hold 2*nmax samples')
@@ -156,7 +158,7 @@ def post_prep(ctx, x, npts, index_min=0, index_max=0, unbiased=True, taper_nmax=
     """unbias -> demean -> taper in one op (core/postprocess.py:133-136), in place; bit-identical
     to ``taper(demean(unbias(x)))`` with two passes over the rows instead of five."""
     ctx = _ctx(ctx, x)
-    buf, b, n, dev, _ = _prep(x)
+    buf, b, n, dev, _ = _prep(x, ctx)
     index_max = index_max or 2 * npts - 1
     if n != index_max - index_min:
         raise ValueError('last dimension does not match the lag slice')
@@ -170,10 +172,25 @@ def scale_rows(ctx, x, factor):
     """x[r] *= factor[r] in place (one float64 factor per row, or a scalar): the division by a sensitivity or a
     norm of the ObsPy-named preprocess ops on device-resident (or host) rows."""
     ctx = _ctx(ctx, x)
-    buf, b, n, dev, _ = _prep(x)
+    buf, b, n, dev, _ = _prep(x, ctx)
     f = np.ascontiguousarray(np.broadcast_to(np.asarray(factor, dtype=np.float64).reshape(-1), (b,)))
     check(_ffi.lib().xcx_scale_rows(ctx.handle, ptr(buf), b, n, ptr(f), dev))
     return buf
+
+
+def rotate2(ctx, a, b, c00, c01, c10, c11):
+    """(a, b) <- (c00 a + c01 b, c10 a + c11 b): two components of equal shape, both device-resident (in place) or
+    both host arrays (copies are returned).  The horizontal rotations of ``Stream.rotate`` (stream/process.py:70-73)."""
+    if isinstance(a, DeviceArray) != isinstance(b, DeviceArray):
+        raise ValueError('rotate2: both components on the device or both on the host')
+    if tuple(a.shape) != tuple(b.shape):
+        raise TypeError('North and East component have different length.')
+    ctx = _ctx(ctx, a)
+    ba, nb, n, dev, _ = _prep(a, ctx)
+    bb, _, _, _, _ = _prep(b, ctx)
+    c4 = np.array([c00, c01, c10, c11], np.float64)
+    check(_ffi.lib().xcx_rotate2(ctx.handle, ptr(ba), ptr(bb), nb, n, ptr(c4), dev))
+    return ba, bb
 
 
 def absmax_rows(ctx, x):
@@ -194,7 +211,7 @@ def absmax_rows(ctx, x):
 
 def onebit(ctx, x):
     ctx = _ctx(ctx, x)
-    buf, b, n, dev, _ = _prep(x)
+    buf, b, n, dev, _ = _prep(x, ctx)
     check(_ffi.lib().xcx_onebit(ctx.handle, ptr(buf), b, n, dev))
     return buf
 
@@ -210,7 +227,7 @@ def sosfiltfilt(ctx, x, sos):
     """scipy.signal.sosfiltfilt(sos, x, axis=-1) (xcorr/signal/filter.py:95)."""
     ctx = _ctx(ctx, x)
     sos = _sos(sos)
-    buf, b, n, dev, _ = _prep(x)
+    buf, b, n, dev, _ = _prep(x, ctx)
     check(_ffi.lib().xcx_sosfiltfilt(ctx.handle, ptr(buf), b, n, ptr(sos),
                                      sos.shape[0], dev))
     return buf
@@ -238,7 +255,7 @@ def sosfilt(ctx, x, sos, cols=None):
         check(_ffi.lib().xcx_sosfilt_cols(ctx.handle, ptr(x), x.shape[0], x.shape[1], ptr(sos), sos.shape[0],
                                           int(cols[0]), int(cols[1]), C.byref(first)))
         return first.value
-    buf, b, n, dev, _ = _prep(x)
+    buf, b, n, dev, _ = _prep(x, ctx)
     check(_ffi.lib().xcx_sosfilt(ctx.handle, ptr(buf), b, n, ptr(sos),
                                  sos.shape[0], dev))
     return buf
@@ -249,7 +266,7 @@ def sosfilt_zerophase(ctx, x, sos):
     signal from rest (no padding; not scipy's sosfiltfilt)."""
     ctx = _ctx(ctx, x)
     sos = _sos(sos)
-    buf, b, n, dev, _ = _prep(x)
+    buf, b, n, dev, _ = _prep(x, ctx)
     check(_ffi.lib().xcx_sosfilt_zerophase(ctx.handle, ptr(buf), b, n, ptr(sos),
                                            sos.shape[0], dev))
     return buf
@@ -524,6 +541,6 @@ def ram_normalize(ctx, x, half_width):
     """Running-absolute-mean normalisation: x / mean(|x|) over a centred window of
     2*half_width+1 samples (truncated at the ends).  Self-defined (Bensen et al. 2007)."""
     ctx = _ctx(ctx, x)
-    buf, batch, n, dev, ret = _prep(x)
+    buf, batch, n, dev, ret = _prep(x, ctx)
     check(_ffi.lib().xcx_ram_normalize(ctx.handle, ptr(buf), batch, n, int(half_width), dev))
     return buf

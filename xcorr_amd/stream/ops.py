@@ -179,9 +179,65 @@ def running_rms(x, sampling_rate, window=1., ctx=None):
     return _ops.block_rms(ctx, x, win, step, nwin), 1.0 / window
 
 
+def rotate(components, method, back_azimuth=None, ctx=None, **unused):
+    """``Stream.rotate(method, back_azimuth=...)`` on a component set ``{channel code: array}``
+    (stream/process.py:70-73; scripts/cc.py:83-84 runs ``'->ZNE'`` then ``'NE->RT'``).
+
+    ``'NE->RT'``: the channels ending in N and E (same band / instrument prefix) become R and T, renamed like ObsPy
+    does (``BHN, BHE -> BHR, BHT``); `back_azimuth` in degrees is required (ObsPy can also take it from trace
+    stats set by the client; there is no inventory here).
+    ``'->ZNE'``: components that are already Z / N / E are returned as they are; anything else (``BH1``, ``BH2``)
+    needs the orientations of an ObsPy inventory and raises."""
+    if not isinstance(components, dict):
+        raise TypeError('rotate needs a component set {channel: array} (e.g. {"BHZ": z, "BHN": n, "BHE": e})')
+    if method == '->ZNE':
+        odd = [c for c in components if c[-1:] not in ('Z', 'N', 'E')]
+        if odd:
+            raise NotImplementedError(f'rotate("->ZNE") of {odd} needs the channel orientations of an ObsPy inventory')
+        return components
+    if method != 'NE->RT':
+        raise NotImplementedError(f'rotate method "{method}" is not built (built: "->ZNE" for ZNE input, "NE->RT")')
+    if back_azimuth is None:
+        raise ValueError('rotate("NE->RT") needs back_azimuth (degrees)')
+    out = dict(components)
+    done = 0
+    for cn in [c for c in components if c.endswith('N')]:
+        ce = cn[:-1] + 'E'
+        if ce not in components:
+            continue
+        r, t = _seg.rotate_ne_rt(components[cn], components[ce], float(back_azimuth), ctx=ctx)
+        del out[cn], out[ce]
+        out[cn[:-1] + 'R'], out[cn[:-1] + 'T'] = r, t
+        done += 1
+    if not done:
+        raise ValueError('rotate("NE->RT"): no pair of N / E components with a common prefix')
+    return out
+
+
+def select(components, channel=None, component=None, **other):
+    """``Stream.select(channel=..., component=...)`` on a component set (stream/process.py:74-77; scripts/cc.py:85
+    keeps ``BHR``): UNIX wildcards as in ObsPy.  Station / network / location selectors do not apply to a
+    component set of one receiver and are refused."""
+    import fnmatch
+    if not isinstance(components, dict):
+        raise TypeError('select needs a component set {channel: array}')
+    extra = [k for k, v in other.items() if v is not None]
+    if extra:
+        raise NotImplementedError(f'select by {extra} is not built (a component set holds one receiver)')
+    keep = {c: v for c, v in components.items()
+            if (channel is None or fnmatch.fnmatchcase(c, channel))
+            and (component is None or fnmatch.fnmatchcase(c[-1:], component))}
+    if not keep:
+        raise ValueError(f'select(channel={channel!r}, component={component!r}) matches none of {list(components)}')
+    return keep
+
+
+_NEEDS_INVENTORY = ('attach_response', 'remove_response', 'simulate')
+
 _OPS = {'detrend': detrend, 'filter': filter, 'taper': taper, 'decimate': decimate, 'resample': resample,
         'interpolate': interpolate, 'running_rms': running_rms, 'merge': _seg.merge, 'trim': _seg.trim,
-        'remove_sensitivity': _seg.remove_sensitivity, 'normalize': _seg.normalize}
+        'remove_sensitivity': _seg.remove_sensitivity, 'normalize': _seg.normalize,
+        'rotate': rotate, 'select': select}
 
 
 def apply_operations(x, sampling_rate, operations, ctx=None, t0=0.0, starttime=None, endtime=None,
@@ -195,11 +251,46 @@ def apply_operations(x, sampling_rate, operations, ctx=None, t0=0.0, starttime=N
     `starttime` / `endtime` / `sensitivity` are the dynamic parameters the reference
     injects from the window bounds and the inventory (stream/process.py:153-196):
     ``trim`` cuts to [starttime, endtime], ``remove_sensitivity`` divides by
-    `sensitivity`."""
+    `sensitivity`.
+
+    A COMPONENT SET ``{channel code: array}`` (``{'BHZ': z, 'BHN': n, 'BHE': e}``, equal shapes and one time axis)
+    takes the place of the multi-trace ``obspy.Stream`` of one receiver: per-trace operations run on every
+    component, ``rotate`` and ``select`` act on the set (scripts/cc.py:70-90, the BHR list).  When ``select``
+    leaves one component the result is that array, otherwise the set.  ``attach_response`` / ``remove_response`` /
+    ``simulate`` need an ObsPy inventory and raise."""
+    if isinstance(x, dict):
+        comps = dict(x)
+        if not comps:
+            raise ValueError('empty component set')
+        ops_left = list(operations)
+        while ops_left:
+            name, params = ops_left[0]
+            if name in ('rotate', 'select'):
+                comps = _OPS[name](comps, ctx=ctx, **params) if name == 'rotate' else select(comps, **params)
+                ops_left.pop(0)
+                continue
+            # the run of per-trace operations up to the next set operation, component by component
+            k = next((i for i, (nm, _) in enumerate(ops_left) if nm in ('rotate', 'select')), len(ops_left))
+            run, ops_left = ops_left[:k], ops_left[k:]
+            res = {c: apply_operations(v, sampling_rate, run, ctx=ctx, t0=t0, starttime=starttime, endtime=endtime,
+                                       sensitivity=(sensitivity.get(c) if isinstance(sensitivity, dict) else sensitivity),
+                                       return_t0=True) for c, v in comps.items()}
+            comps = {c: r[0] for c, r in res.items()}
+            rates = {r[1] for r in res.values()}
+            starts = {r[2] for r in res.values()}
+            if len(rates) != 1 or len(starts) != 1:
+                raise ValueError('the components left the operations with different time axes')
+            sampling_rate, t0 = rates.pop(), starts.pop()
+        y = next(iter(comps.values())) if len(comps) == 1 else comps
+        return (y, sampling_rate, t0) if return_t0 else (y, sampling_rate)
     for name, params in operations:
         if callable(name):
             x = name(x, **params)
             continue
+        if name in _NEEDS_INVENTORY:
+            raise NotImplementedError(f'"{name}" needs an ObsPy inventory (instrument response): not built')
+        if name in ('rotate', 'select'):
+            raise TypeError(f'"{name}" acts on a component set {{channel: array}}, not on a single trace')
         if name not in _OPS:
             raise NotImplementedError(f'"{name}" is not an implemented operation or callable.')
         p = dict(params)

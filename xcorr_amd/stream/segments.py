@@ -200,14 +200,16 @@ def normalize(x, norm=None):
     return (x / norm).astype(x.dtype if x.dtype.kind == 'f' else np.float64)
 
 
-def rotate_ne_rt(n, e, back_azimuth):
+def rotate_ne_rt(n, e, back_azimuth, ctx=None):
     """``rotate('NE->RT', back_azimuth)`` (obspy.signal.rotate.rotate_ne_rt): degrees from
-    north of the direction from station to source.  Returns (radial, transverse)."""
-    if n.shape != e.shape:
+    north of the direction from station to source.  Returns (radial, transverse):
+    r = -e sin(ba) - n cos(ba), t = -e cos(ba) + n sin(ba).  The arithmetic runs in the library
+    (``xcx_rotate2``): device-resident components are rotated in place, host arrays come back as copies."""
+    if tuple(n.shape) != tuple(e.shape):
         raise TypeError('North and East component have different length.')
     if back_azimuth < 0 or back_azimuth > 360:
         raise ValueError('Back Azimuth should be between 0 and 360 degrees.')
+    from .. import ops as _ops
     ba = math.radians(back_azimuth)
-    r = -e * math.sin(ba) - n * math.cos(ba)
-    t = -e * math.cos(ba) + n * math.sin(ba)
-    return r, t
+    # (n, e) <- (r, t)
+    return _ops.rotate2(ctx, n, e, -math.cos(ba), -math.sin(ba), math.sin(ba), -math.cos(ba))
