@@ -453,6 +453,7 @@ def main():
         'config': {
             'workload': workload_str,
             'fft_length': plan.N, 'pair_batch': plan.batch,
+            't_storage': plan.t_storage,      # intermediate of the two-pass inverse: 'q24' = 2 x 24-bit fixed point
             'shard': shard,
             'overlap_next_step_front_end': bool(pipelined), 'per_rank_pair_windows_per_step': units_rank // a.steps,
         },

@@ -133,6 +133,12 @@ int xcx_timer_stop(xcx_ctx* ctx, float* ms);
  * once, and the rows go through in chunks whose workspace is half of the free device memory, at most
  * XCX_SEG_WORKSPACE_MAX_GB (XCX_SEG_BUDGET_MB overrides; a registered xcx_set_reclaim callback is asked first).
  */
+/* What a plan for `need` = n + max|lag| points (nfft != 0: exactly that transform) runs on, without a GPU or a plan:
+ * out5 = {N, N1, N2h, 1 if the (N1, N2h) pair has a dual / flow pair kernel, 1 if that kernel has the q24 T storage};
+ * N = -1: no single transform holds it (segmented plan).  xcx_plan_fused_list: the instantiated (N1, N2h) pair
+ * kernels, out[2 i], out[2 i + 1], *count of them. */
+int xcx_plan_geometry(long long need, int nfft, int* out5);
+int xcx_plan_fused_list(int* out, int cap, int* count);
 int xcx_plan_cc1d(xcx_ctx* ctx, int n, int nfft, int idx_min, int idx_max,
                   int flags, xcx_plan** plan);
 int xcx_plan_destroy(xcx_plan* plan);
@@ -140,6 +146,15 @@ int xcx_plan_destroy(xcx_plan* plan);
  * ramps of width ftaper outside, 0 beyond. */
 int xcx_plan_set_whiten(xcx_plan* plan, double sampling_rate, double fmin,
                         double fmax, double ftaper);
+/* Storage of the pair pass's intermediate T between its two kernels: *ts = 0 float2 (8 bytes per element), 1 "q24"
+ * (two 24-bit fixed-point numbers, 6 bytes per element).  q24 is the default for WHITENED plans whose column length
+ * has the lane-pair store (N1 in {512, 768, 1024, 1536}) on the dual launches of plain pair products: a whitened
+ * spectrum has the known modulus gain(k) * scale, so |T| has a bound and the fixed-point scale never overflows;
+ * the arithmetic stays float32.  Measured: +4-6 % pair-windows/s, worst error against the float64 oracle 2.1e-6 of
+ * max|cc| (pure-noise CCFs; float2 storage: 1.2e-6), profiles/r05_t24_error_table.txt.  Stacked plans, precomputed
+ * cross-spectra and plans without whitening keep float2.  Environment XCX_T_STORAGE=f32 | q24 overrides, read by
+ * xcx_plan_set_whiten. */
+int xcx_plan_t_storage(xcx_plan* plan, int* ts);
 /* Host-only (no GPU): the processing order xcx_cc1d_pairs gives a pair list -- launch batches of at most
  * `batch` pairs that touch few stations (csrc/pair_order.h: lines of the affine plane AG(2,8) for <= 64
  * stations, greedy station sets otherwise).  perm[P] = order (indices into `pairs`), bounds[ngroups + 1] =

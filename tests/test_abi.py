@@ -147,3 +147,38 @@ def test_reclaim_hook_is_part_of_the_context(monkeypatch):
     ctx._dev_pool[2 << 20][0] = (0x4000, -1e9)              # idle since long ago: expires at the next take / give
     assert ctx._pool_take(1 << 20) is None and calls[-1] == 0x4000 and not ctx._dev_pool
     ctx.handle = None                                       # no __del__ work on the fake
+
+
+def test_every_pair_kernel_instantiation_is_reachable():
+    """walk the planner (xcx_plan_geometry, no GPU) over every transform length it can pick --
+    each instantiated dual / flow pair kernel is selected by some plan, and the list in csrc/Makefile (WFUSED) is
+    the list the library carries.  Geometries without a dual kernel run the separate column / row launches."""
+    from xcorr_amd import _ffi
+    lib = _ffi.lib()
+    cnt = C.c_int(0)
+    buf = (C.c_int * 128)()
+    assert lib.xcx_plan_fused_list(buf, 128, C.byref(cnt)) == 0
+    fused = {(buf[2 * i], buf[2 * i + 1]) for i in range(cnt.value)}
+    mk = open(os.path.join(ROOT, 'xcorr_amd', 'csrc', 'Makefile')).read()
+    listed = {tuple(int(v) for v in f.split(':')) for f in re.search(r'^WFUSED = (.*)$', mk, flags=re.M).group(1).split()}
+    assert fused == listed and len(fused) == cnt.value
+    out = (C.c_int * 5)()
+    chosen, lengths = set(), set()
+    need = 1
+    while True:                                   # every N the planner can return for nfft = 0, smallest first
+        assert lib.xcx_plan_geometry(need, 0, out) == 0
+        if out[0] < 0:
+            break
+        assert out[0] >= need and out[0] == 2 * out[1] * out[2]
+        lengths.add(out[0])
+        chosen.add((out[1], out[2]))
+        assert bool(out[3]) == ((out[1], out[2]) in fused)
+        # a forced nfft gives the same geometry as the automatic choice of that length
+        forced = (C.c_int * 5)()
+        assert lib.xcx_plan_geometry(1, out[0], forced) == 0 and list(forced) == list(out)
+        need = out[0] + 1
+    limits = (C.c_long * 1)()
+    assert lib.xcx_limits(limits, 1) == 0 and max(lengths) == limits[0]       # XCX_MAX_SINGLE_TRANSFORM
+    assert fused <= chosen, f'never selected: {sorted(fused - chosen)}'
+    assert (1536, 120) in fused and out[0] == -1
+    assert lib.xcx_plan_geometry(368640 - 100, 0, out) == 0 and list(out) == [368640, 1536, 120, 1, 1]   # the headline plan

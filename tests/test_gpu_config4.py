@@ -70,3 +70,63 @@ def test_thirty_day_stack_full_pair_count(ctx):
     assert abs(P * L * 4 / 1e9 - 2.90) < 0.01
     print(f'30-day stack, P=2016: accumulated vs sum of per-day stacks {worst:.2e}')
     acc.close(); per.close()
+
+
+def test_stack_of_full_days_through_the_chain_the_bench_times(ctx):
+    """configs[3] at the chain `bench.py --stack --days D` times -- 64 stations x 47-window
+    days through StationDay(preprocess=True, stack=True): demean -> cosine taper -> band-pass per station-day,
+    one-bit + whitening per window, frequency-domain accumulation (xcx_cc1d_stack_add per day, ONE
+    xcx_cc1d_stack_finish) -- the very loop of bench.py's step(), for 3 days at P = 2016.  Sampled pairs against
+    the oracle's R.cc_pairs(onebit_=True, whiten=g) summed over the 141 windows:
+      C. strict 1e-5 with the oracle fed the GPU's own float32 preprocessed rows,
+      A. the composed chain (oracle preprocess in float64) with the config-3 flip rule: one-bit is discontinuous,
+         every counted sign difference between the float32 and float64 rows of a pair's windows adds 5e-4 of ONE
+         window's noise floor, i.e. 5e-4 / sqrt(windows) of the stack's."""
+    from xcorr_amd import workload
+    S, T, n, hop, ndays = 64, 4320000, 180000, 90000, 3
+    pairs = R.all_pairs(S)
+    sd = workload.StationDay(ctx, S, T, n, hop, pairs, preprocess=True, stack=True)
+    W, L, N = sd.W, sd.L, sd.plan.N
+    assert (W, sd.P, N) == (47, 2016, 368640)
+    sampled = [(0, 1), (5, 40), (62, 63)]
+    pidx = {(int(i), int(j)): k for k, (i, j) in enumerate(pairs)}
+    stations = sorted({s for p in sampled for s in p})
+    g = R.whiten_weights(N, *workload.WHITEN)
+    taper = R.cosine_taper_obspy(T, workload.FS, *workload.TAPER)
+    ref_c = {p: np.zeros(L) for p in sampled}
+    ref_a = {p: np.zeros(L) for p in sampled}
+    flips = {p: 0 for p in sampled}
+    try:
+        for d in range(ndays):
+            raw = _day(S, T, d)
+            sd.load(raw)
+            sd.front()                                              # exactly bench.py's multi-day step()
+            sd.plan.stack_add(sd.view, pairs, W, hop, stride_s=T)
+            gpu_pre = {s: sd.work.rows_to_host(s, 1, T)[0] for s in stations}
+            ora_pre = {s: R.sosfilt(workload.band_sos(), R.demean(raw[s][None].astype(np.float64)) * taper)[0]
+                       for s in stations}
+            for (i, j) in sampled:
+                ref_c[(i, j)] += R.cc_pairs(np.stack([gpu_pre[i], gpu_pre[j]]), [(0, 1)], n, hop, onebit_=True,
+                                            whiten=g, nfft=N, dtype=np.float64)[0].sum(axis=0)
+                ref_a[(i, j)] += R.cc_pairs(np.stack([ora_pre[i], ora_pre[j]]), [(0, 1)], n, hop, onebit_=True,
+                                            whiten=g, nfft=N, dtype=np.float64)[0].sum(axis=0)
+                for s in (i, j):          # every sample is in two windows except the day's two half-window flanks
+                    flips[(i, j)] += 2 * int(np.count_nonzero(np.sign(gpu_pre[s].astype(np.float64)) != np.sign(ora_pre[s])))
+        _, nw = sd.plan.stack_finish(pairs, out=sd.out, ld_out=sd.ld)
+    except BaseException:
+        sd.plan.stack_reset()
+        raise
+    assert nw == ndays * W
+    worst_c = worst_a = 0.0
+    for (i, j) in sampled:
+        got = sd.rows(pidx[(i, j)], 0).astype(np.float64)
+        ec = np.abs(got - ref_c[(i, j)]).max() / np.abs(ref_c[(i, j)]).max()
+        ea = np.abs(got - ref_a[(i, j)]).max() / np.abs(ref_a[(i, j)]).max()
+        worst_c, worst_a = max(worst_c, ec), max(worst_a, ea)
+        assert ec < TOL, f'pair ({i},{j}): stack vs oracle on the GPU rows {ec:.2e}'
+        assert ea < TOL + 5e-4 * flips[(i, j)] / np.sqrt(nw), \
+            f'pair ({i},{j}): composed chain {ea:.2e} with {flips[(i, j)]} one-bit sign flips'
+        assert int(np.argmax(got)) == n - 1 + 25 * (i - j)
+    print(f'3 full days through the bench chain, P=2016: per-window chain {worst_c:.2e}, composed {worst_a:.2e} '
+          f'({sum(flips.values())} sign flips)')
+    sd.close()

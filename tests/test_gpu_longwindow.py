@@ -1,7 +1,7 @@
 """GPU: windows longer than any single transform: the reference's production
 setting window_length = 86400 s @ 50 Hz (n = 4 320 000) with clip_lag = (0, 9 h)
 (scripts/cc.py:25-29, examples/core/process.py:25-28) needs n + max|lag| = 5.94 M points; the
-plan assembles it block-wise on the time-stacking engine (csrc/xcx_api.hip: seg_run).
+plan assembles it block-wise on the time-stacking engine (csrc/seg_plan.hip: seg_run).
 Checked against the oracle's rfft restatement of util/cc.py (R.cc_fair, float64)."""
 import os
 

@@ -541,3 +541,43 @@ def test_tiny_windows_single_station(ctx):
                 plan.close()
             x, y = tr[:1, :n], tr[-1:, :n]
             assert np.abs(X.CCPlan(ctx, n).cc(x, y)[0] - R.cc(x[0], y[0], normalize=True, dtype=np.float64)).max() < TOL
+
+
+def test_q24_storage_of_the_intermediate_on_whitened_plans(ctx, monkeypatch):
+    """The pair pass of a WHITENED plan keeps its intermediate T as 2 x 24-bit fixed point (include/xcx.h,
+    xcx_plan_t_storage; wave_kernels.h): the scale comes from the bound |T| <= scale^2 sum gain^2, so nothing can
+    overflow -- not even identical traces, which reach the bound -- and the arithmetic stays float32.  What the
+    24-bit intermediate itself adds is bounded against float2 storage ON THE SAME INPUTS: <= 2.5e-6 of max|cc|, the
+    worst case being a CCF that is pure noise (profiles/r05_t24_error_table.txt: 2.0e-6); both storages meet the
+    suite's 1e-5 against the float64 oracle (a one-bit window with a nearly empty in-band bin costs either of them
+    several 1e-6: float32 whitening, not storage).  Plans without whitening, stacked plans and column lengths
+    without the lane-pair store keep float2."""
+    rng = np.random.default_rng(77)
+    for n, band in ((180000, (50., .1, 10., .05)), (180000, (50., 1., 20., .5)), (60000, (50., .1, 10., .05)),
+                    (90000, (50., .5, 5., .1))):
+        S, W, hop = 3, 2, n // 2
+        T = hop * (W - 1) + n
+        tr = rng.standard_normal((S, T)).astype(np.float32)
+        tr[2] = tr[0]                                              # pair (0, 2): identical traces, T at its bound
+        pairs = np.array([(0, 1), (0, 2), (1, 1)], np.int32)
+        res = {}
+        for ts in ('f32', 'q24'):
+            monkeypatch.setenv('XCX_T_STORAGE', ts)
+            plan = X.CCPlan(ctx, n, whiten=band, onebit=True, demean=True)
+            assert plan.t_storage == ts
+            res[ts] = np.asarray(plan.pairs(tr, pairs, W, hop), np.float64)
+            N = plan.N
+            plan.close()
+        g = R.whiten_weights(N, *band)
+        ref = R.cc_pairs(tr, pairs, n, hop, dtype=np.float64, whiten=g, nfft=N, onebit_=True, demean_=True)
+        for p in range(len(pairs)):
+            for w in range(W):
+                m = np.abs(ref[p, w]).max()
+                assert np.abs(res['f32'][p, w] - ref[p, w]).max() / m < TOL, (n, band, p, w)
+                assert np.abs(res['q24'][p, w] - ref[p, w]).max() / m < TOL, (n, band, p, w)
+                assert np.abs(res['q24'][p, w] - res['f32'][p, w]).max() / m < 2.5e-6, (n, band, p, w)
+        assert not np.array_equal(res['f32'], res['q24'])          # the storage really differed
+    monkeypatch.delenv('XCX_T_STORAGE')
+    assert X.CCPlan(ctx, 180000, whiten=(50., .1, 10., .05)).t_storage == 'q24'          # the default of whitened plans
+    assert X.CCPlan(ctx, 180000).t_storage == 'f32'                                       # no whitening: no bound
+    assert X.CCPlan(ctx, 30000, whiten=(50., 1., 10., .5)).t_storage == 'f32'             # N1 = 256: no lane-pair store

@@ -36,6 +36,9 @@ _pf, _pi, _pd = C.POINTER(C.c_float), C.POINTER(C.c_int), C.POINTER(C.c_double)
 SIGNATURES = {
     'xcx_device_count': [_pi],
     'xcx_limits': [C.POINTER(C.c_long), _i],
+    'xcx_plan_geometry': [C.c_longlong, _i, _pi],
+    'xcx_plan_t_storage': [_vp, _pi],
+    'xcx_plan_fused_list': [_pi, _i, _pi],
     'xcx_init': [_i, C.POINTER(_vp)],
     'xcx_destroy': [_vp],
     'xcx_last_error': [C.c_char_p, _sz],

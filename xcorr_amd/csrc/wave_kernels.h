@@ -126,16 +126,6 @@ XCX_DEV void q24_pack(unsigned d0, unsigned d1, unsigned d2, unsigned d3, unsign
   o[1] = __builtin_amdgcn_perm(d2, d1, 0x05040201u);
   o[2] = __builtin_amdgcn_perm(d3, d2, 0x06050402u);
 }
-// ... and back: the three bytes go to the TOP of a dword (sign in place, low byte zero) = 256 i; s = tqi / 256
-XCX_DEV void q24_unpack(unsigned o0, unsigned o1, unsigned o2, float s, cf& a, cf& b) {
-  const int u0 = (int)__builtin_amdgcn_perm(o0, o0, 0x0201000cu);
-  const int u1 = (int)__builtin_amdgcn_perm(o1, o0, 0x0504030cu);
-  const int u2 = (int)__builtin_amdgcn_perm(o2, o1, 0x0403020cu);
-  const int u3 = (int)(o2 & 0xffffff00u);
-  a = make_float2((float)u0 * s, (float)u1 * s);
-  b = make_float2((float)u2 * s, (float)u3 * s);
-}
-
 // staging buffer of the workgroup-cooperative CCF store: (N2h + 1) lag blocks x 64 rows of float
 constexpr int lds_stage_floats(int N2h) { return (N2h + 1) * kTR; }
 
@@ -171,12 +161,6 @@ template <class RX> struct ColRot {
 // Used for the first 2 x 64 butterflies of stage 0 when the column has at least that many
 // (lane l takes butterflies 2l and 2l+1); see pair_src_index.
 struct NoIn2 {};
-#ifndef XCX_TST_AUX
-#define XCX_TST_AUX -1       // T stores: -1 = plain global stores
-#endif
-#ifndef XCX_COL_WIDE
-#define XCX_COL_WIDE 1       // 16-byte spectrum loads in the pair column pass (+0.9 %, profiles/r02_ablation.txt)
-#endif
 template <class RX, bool INV, class In, class Epi, class In2 = NoIn2>
 XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in, Epi epi, int ltid XCX_ST_PARAM, In2 in2 = In2()) {
   constexpr int L = RX::L;
@@ -568,10 +552,6 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
   };
   constexpr int TC = t_chunk(N1);
   cf* __restrict__ Tc = T + k2 * TC;
-#if XCX_TST_AUX >= 0
-  // experiment: T stores as buffer stores with an explicit cache policy (aux: 2 = nt, 16 = sc1, 18 = both)
-  const __amdgpu_buffer_rsrc_t trsrc = __builtin_amdgcn_make_buffer_rsrc(Tc, 0, 0x7fffffff, 0x00020000);
-#endif
   const int crow = (N2h + 1) * TC;            // float2 per chunk of TC rows
   // Pair stores: every lane ends up with two adjacent rows and stores 16 bytes; lanes 0..31 cover one
   // 64-row half chunk, lanes 32..63 the next one, in lane order.
@@ -615,13 +595,7 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
         if (tile >= NT) tile -= NT;
         const unsigned o = (TC == 128) ? (unsigned)(tile >> 1) * (unsigned)crow + (unsigned)((tile & 1) * 64 + 2 * (lane & 31))
                                        : (unsigned)tile * (unsigned)crow + (unsigned)(2 * (lane & 31));
-#if XCX_TST_AUX >= 0
-        {
-          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-          const u32x4 w4 = {sx[0], sy[0], sx[1], sy[1]};
-          __builtin_amdgcn_raw_buffer_store_b128(w4, trsrc, (int)(o * 8u), 0, XCX_TST_AUX);
-        }
-#else
+        // plain global stores: sc1 / nt policies for T measured slower
         if constexpr (TS == 1) {
           typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
           unsigned q[3];
@@ -632,7 +606,6 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
           *reinterpret_cast<float4*>(uoff(Tc, o)) =
               make_float4(__uint_as_float(sx[0]), __uint_as_float(sy[0]), __uint_as_float(sx[1]), __uint_as_float(sy[1]));
         }
-#endif
       });
     } else {
       static_for<CG::RL>([&](auto tc) {
@@ -643,7 +616,8 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
       });
     }
   };
-#if XCX_COL_WIDE && !defined(XCX_STAMPS)
+#if !defined(XCX_STAMPS)
+  // 16-byte spectrum loads for the first 2 x 64 butterflies (+0.9 %, profiles/r02_ablation.txt)
   if constexpr (MODE != 1) {
     auto in2 = [=](int k1, cf& ra, cf& rb, int kb) {
       typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -720,17 +694,10 @@ template <bool SC1> XCX_DEV cf load_t(const cf* p) {
 // pair-windows/s, 16-byte 256-byte runs at 1.57 M.  `stg` = workgroup-wide staging buffer
 // (lds_stage_floats(N2h) floats, may alias the waves' exchange buffers); contains __syncthreads().
 // TCT: T chunk rows (t_chunk(N1)) when N1 is known at compile time, 0 = from g.N1
-// PR ("pair rows", always with TS = 1; -DXCX_ROW_PAIRS: with float2 storage as well): a lane takes TWO adjacent rows
-// of one first-stage butterfly pair instead of one row in each of two iterations -- lane = (j, row pair), one
-// iteration, 12- / 16-byte T loads (half the load instructions), the untangle twiddles shared by the two rows.
-// Needs (S/2 + 1) * 8 == 64 work items: N2h / R0 in {14, 15} (the N2h = 120 rows of the day-long configs).
-template <class RX> struct RowPairs {
-  static constexpr int S = RX::L / RX::R0;
-  static constexpr bool ok = ((S / 2 + 1) * (kWRB / 2) == kWNT);
-};
-#ifndef XCX_ROW_PAIRS
-#define XCX_ROW_PAIRS 0
-#endif
+// TS = 1 (q24 storage of T): every lane fetches the aligned 8 bytes that contain the 6 of its element (neighbouring
+// lanes overlap by 2 bytes) -- the same lane mapping, load count and schedule as float2 storage.  A mapping with two
+// adjacent rows per lane and 12- / 16-byte loads (half the load instructions) measured the same with q24 and 1.6 %
+// SLOWER with float2 storage (profiles/r05_t24_notes.txt) and was dropped.
 template <class RX, bool SC1, bool UNBIAS, int TCT = 0, int TS = 0>
 XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, float* __restrict__ out, int blk,
                            const cf* __restrict__ tw_sub, const cf* __restrict__ twu,
@@ -741,8 +708,6 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
   constexpr int NITEM = S / 2 + 1;
   constexpr int TOTAL = NITEM * kWRB;
   constexpr int IT = (TOTAL + kWNT - 1) / kWNT;
-  constexpr bool PR = (TS == 1) || (XCX_ROW_PAIRS && RowPairs<RX>::ok && !SC1);
-  static_assert(!PR || (RowPairs<RX>::ok && IT == 2), "pair-row mapping: 8 butterfly pairs x 8 row pairs = one wave");
   static_assert(TS == 0 || !SC1, "q24 storage: dual kernel only");
   const int N1 = g.N1, N = g.N, n = g.n;
   const int TC = TCT ? TCT : t_chunk(N1);          // elements from one k2 to the next
@@ -789,36 +754,7 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
 #pragma unroll
     for (int t = 0; t < R; ++t) { s0a[it][t] = uj[t]; s0b[it][t] = ujp[t]; }
   };
-  if constexpr (PR) {
-    const int r2 = 2 * (lane & 7);                  // rows r2, r2 + 1 of the wave's 16
-    const int j = lane >> 3;                        // 0..S/2
-    const int jp = (j == 0) ? 0 : (S - j);
-    const bool single = jp == j;
-    cf ava[R], avb[R], bva[R], bvb[R];
-    float nya = 0.f, nyb = 0.f;
-    const char* __restrict__ Tb = reinterpret_cast<const char*>(Tt);
-    const float qs = tqi * (1.f / 256.f);
-    auto load2 = [&](int k2, cf& a, cf& b) {
-      if constexpr (TS == 1) {
-        typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
-        const u32x3 q = *reinterpret_cast<const u32x3*>(Tb + (size_t)((unsigned)(k2 * TC + r2) * 6u));
-        q24_unpack(q[0], q[1], q[2], qs, a, b);
-      } else {
-        const float4 q = *reinterpret_cast<const float4*>(Tb + (size_t)((unsigned)(k2 * TC + r2) * 8u));
-        a = make_float2(q.x, q.y); b = make_float2(q.z, q.w);
-      }
-    };
-#pragma unroll
-    for (int t = 0; t < R; ++t) load2(j + S * t, ava[t], avb[t]);
-    if (!single) {
-#pragma unroll
-      for (int t = 0; t < R; ++t) load2(jp + S * t, bva[t], bvb[t]);
-    }
-    if (j == 0) { cf na, nb; load2(N2h, na, nb); nya = na.x; nyb = nb.x; }
-    untangle(0, j, single, ava, bva, nya);
-    untangle(1, j, single, avb, bvb, nyb);
-    XCX_STAMP(2, s0a[0][0].x);
-  } else {
+  {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int w = lane + it * kWNT;
@@ -828,14 +764,37 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
       const int jp = (j == 0) ? 0 : (S - j);
       const bool single = jp == j;
       cf av[R], bv[R];
+      float ny = 0.f;
+      if constexpr (TS == 1) {
+        // element e = k2 TC + r sits at byte 6 e; the aligned 8 bytes from 6 e - 2 (r odd) or 6 e (r even) hold it
+        const char* __restrict__ Tb = reinterpret_cast<const char*>(Tt);
+        const unsigned odd = (unsigned)(r & 1);
+        const unsigned boff = 6u * (unsigned)r - 2u * odd;
+        const unsigned sel_re = odd ? 0x0403020cu : 0x0201000cu;       // three bytes to the top of a dword, low byte 0
+        const unsigned sel_im = odd ? 0x0706050cu : 0x0504030cu;
+        const float qs = tqi * (1.f / 256.f);
+        auto ld6 = [&](int k2) -> cf {
+          const uint2 q = *reinterpret_cast<const uint2*>(Tb + (size_t)((unsigned)(k2 * TC) * 6u + boff));
+          const int re = (int)__builtin_amdgcn_perm(q.y, q.x, sel_re);
+          const int im = (int)__builtin_amdgcn_perm(q.y, q.x, sel_im);
+          return make_float2((float)re * qs, (float)im * qs);
+        };
+#pragma unroll
+        for (int t = 0; t < R; ++t) av[t] = ld6(j + S * t);
+        if (!single) {
+#pragma unroll
+          for (int t = 0; t < R; ++t) bv[t] = ld6(jp + S * t);
+        }
+        if (j == 0) ny = ld6(N2h).x;
+      } else {
 #pragma unroll
       for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(uoff(Tt, (unsigned)((j + S * t) * TC + r)));
       if (!single) {
 #pragma unroll
         for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(uoff(Tt, (unsigned)((jp + S * t) * TC + r)));
       }
-      float ny = 0.f;
       if (j == 0) ny = load_t<SC1>(uoff(Tt, (unsigned)(N2h * TC + r))).x;
+      }
       untangle(it, j, single, av, bv, ny);
     }
     XCX_STAMP(2, s0a[0][0].x);
@@ -845,23 +804,6 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
   cf v1[G1::IT][RX::R1];
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
-    if constexpr (PR) {
-      // the lane's two rows are neighbours in the [pos][16] buffer: one 8-byte store per butterfly output
-      const int r = 2 * (lane & 7), j = lane >> 3;
-      const int jp = (j == 0) ? 0 : (S - j);
-      static_assert(!PR || R % 8 == 0, "pair-row LDS stores assume a first radix of 8");
-      const int wa = rpad(j * R, r), wb = rpad(jp * R, r);
-#pragma unroll
-      for (int t = 0; t < R; ++t)
-        *reinterpret_cast<float2*>(ldsf + wa + (t + (t >> 3)) * kWRB) =
-            half ? make_float2(s0a[0][t].y, s0a[1][t].y) : make_float2(s0a[0][t].x, s0a[1][t].x);
-      if (jp != j) {
-#pragma unroll
-        for (int t = 0; t < R; ++t)
-          *reinterpret_cast<float2*>(ldsf + wb + (t + (t >> 3)) * kWRB) =
-              half ? make_float2(s0b[0][t].y, s0b[1][t].y) : make_float2(s0b[0][t].x, s0b[1][t].x);
-      }
-    } else {
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int w = lane + it * kWNT;
@@ -881,7 +823,6 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
         for (int t = 0; t < R; ++t)
           ldsf[WF ? wb + (t + (t >> 3)) * kWRB : rpad(jp * R + t, r)] = half ? s0b[it][t].y : s0b[it][t].x;
       }
-    }
     }
     group_sync<kWNT>();
 #pragma unroll
@@ -1032,9 +973,9 @@ struct WDualArgs {
   unsigned long long* stamps;      // [waves of the launch][kNStamp] or null
 #endif
 };
-// q24 storage exists for the (N1, N2h) whose column wave stores lane pairs and whose row wave maps row pairs
+// q24 storage exists for the N1 whose column wave stores lane pairs (any row length)
 template <class RXC, class RXR> struct DualQ24 {
-  static constexpr bool ok = ColPairStore<RXC>::ok && RowPairs<RXR>::ok;
+  static constexpr bool ok = ColPairStore<RXC>::ok;
 };
 
 // amdgpu_waves_per_eu(4,4): the pair pass is bound by memory latency x occupancy (the arithmetic

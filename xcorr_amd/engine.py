@@ -407,6 +407,13 @@ class CCPlan:
         except Exception:
             pass
 
+    @property
+    def t_storage(self):
+        """'q24' when the pair pass keeps its intermediate as 24-bit fixed point (whitened plans), else 'f32'."""
+        ts = C.c_int(0)
+        check(_ffi.lib().xcx_plan_t_storage(self.handle, C.byref(ts)))
+        return 'q24' if ts.value == 1 else 'f32'
+
     def counters(self):
         a, b = C.c_longlong(), C.c_longlong()
         check(_ffi.lib().xcx_plan_counters(self.handle, C.byref(a), C.byref(b)))
