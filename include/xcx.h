@@ -93,6 +93,10 @@ int xcx_free(xcx_ctx* ctx, void* dptr);
  * XCX_ENOMEM (plan workspaces, staged host rows, xcx_malloc itself) and before a segmented plan sizes its workspace
  * from the free device memory.  cb = NULL removes it.  Not re-entered from the xcx_free calls it makes. */
 int xcx_set_reclaim(xcx_ctx* ctx, size_t (*cb)(void* user), void* user);
+/* Release what the context caches between calls: the grow-only workspaces of the row ops, filters and transforms, its
+ * tables, and the cached plans of xcx_timeshift and of the any-length transforms (after a day-long rfft, time shift
+ * or segmented correlation they hold tens of GB until xcx_destroy).  Plans created by the caller are not touched. */
+int xcx_trim(xcx_ctx* ctx);
 /* page-locked host memory (hipHostMalloc): device-to-host copies into it run at PCIe speed; the
  * Python mirrors return their result arrays in it (xcorr_amd.Context.pinned_empty) */
 int xcx_host_alloc(xcx_ctx* ctx, size_t bytes, void** hptr);

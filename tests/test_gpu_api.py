@@ -474,3 +474,71 @@ def test_plain_c_caller(ctx, tmp_path):
     assert np.allclose(kat, [0, .5, 2, 3.5, 5, 4, 0], atol=1e-5)
     f = out[1].split()
     assert int(f[2]) == 359999 and int(f[6]) == -250 and 0.8 < float(f[8]) < 1.0
+
+
+def test_bench_gpus_2_starts_its_own_ranks(ctx):
+    """`python bench.py --gpus 2` without a launcher starts two rank processes itself (here both
+    on the one visible GPU: --oversubscribe) and prints ONE line with n_gpus = 2; without --oversubscribe it refuses
+    when fewer than two devices are visible, and --stack (an RCCL communicator of two ranks on ONE device is refused
+    by RCCL) fails loudly instead of hanging: the launcher stops the surviving rank."""
+    import ctypes
+    import json
+    import subprocess
+    import sys
+    from xcorr_amd import _ffi
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    small = ['--stations', '6', '--seconds', '14400', '--steps', '1', '--warmup', '1', '--no-cpu-baseline']
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--oversubscribe'] + small,
+                         capture_output=True, text=True, timeout=600, cwd=root, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['scaling'] == 'strong' and d['value'] > 0
+    ndev = ctypes.c_int(0)
+    _ffi.check(_ffi.lib().xcx_device_count(ctypes.byref(ndev)))
+    if ndev.value < 2:
+        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2'] + small,
+                             capture_output=True, text=True, timeout=600, cwd=root, env=env)
+        assert out.returncode != 0 and 'n_gpus' not in out.stdout and '--oversubscribe' in out.stderr
+        out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--oversubscribe', '--stack',
+                              '--days', '2'] + small, capture_output=True, text=True, timeout=600, cwd=root, env=env)
+        assert out.returncode != 0 and 'n_gpus' not in out.stdout
+        assert 'stopping the other ranks' in out.stderr or 'exited with status' in out.stderr
+
+
+def test_context_trim_reclaim_and_explicit_context(ctx):
+    """(1) freed device buffers wait in the binding's pool and go back to the driver when the LIBRARY asks
+    (xcx_set_reclaim callback) or Context.trim() is called; xcx_trim drops the context's cached workspaces and plans,
+    later calls rebuild them and give the same numbers; (2) an op that is given a context stages large host rows in
+    THAT context's pinned pool and never opens the process-wide default context."""
+    import subprocess
+    import sys
+    from xcorr_amd import ops
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 400001)).astype(np.float32)
+    y1 = np.array(ops.rfft(ctx, x))
+    ctx.trim()
+    y2 = np.array(ops.rfft(ctx, x))
+    assert np.array_equal(y1, y2)
+    a = ctx.empty((3 << 18,))                     # 3 MB
+    b = ctx.empty((3 << 18,))
+    a.free(); b.free()
+    assert ctx._dev_pool_bytes == 2 * (3 << 20)
+    c = ctx.empty((3 << 18,))                     # same size: comes from the pool
+    assert ctx._dev_pool_bytes == 3 << 20
+    assert ctx._reclaim_cb(None) == 3 << 20 and ctx._dev_pool_bytes == 0        # what the library calls when it runs out
+    c.free()
+    ctx.trim()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ('import numpy as np, xcorr_amd as X\n'
+            'from xcorr_amd import engine, ops\n'
+            'c = X.Context(0)\n'
+            'x = np.random.default_rng(0).standard_normal((4, 300000)).astype(np.float32)\n'      # 4.8 MB: pinned staging
+            'y = ops.demean(c, x); ops.taper(c, x, 100); ops.norm1d(c, x)\n'
+            'assert abs(float(np.asarray(y).mean())) < 1e-6\n'
+            'assert engine._default == {}, "an op with an explicit context opened the default one"\n'
+            'assert c._pin_live + c._pin_idle > 0\n'
+            'c.close()\n')
+    subprocess.run([sys.executable, '-c', code], check=True, cwd=root, timeout=300)

@@ -580,4 +580,5 @@ def test_q24_storage_of_the_intermediate_on_whitened_plans(ctx, monkeypatch):
     monkeypatch.delenv('XCX_T_STORAGE')
     assert X.CCPlan(ctx, 180000, whiten=(50., .1, 10., .05)).t_storage == 'q24'          # the default of whitened plans
     assert X.CCPlan(ctx, 180000).t_storage == 'f32'                                       # no whitening: no bound
+    assert X.CCPlan(ctx, 180000, whiten=(50., .1, 10., .05), stack=True).t_storage == 'f32'   # stacks read a Gram matrix
     assert X.CCPlan(ctx, 30000, whiten=(50., 1., 10., .5)).t_storage == 'f32'             # N1 = 256: no lane-pair store

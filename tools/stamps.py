@@ -53,20 +53,28 @@ ghz = 2.1
 names = {1: ['launch -> inputs arrived (desc + twiddle + 48 loads, product)', 'stage 0 (3 x radix 8)', 'LDS exchange 1',
              'stage 1 (twiddle chain + 3 x radix 8)', 'LDS exchange 2', 'stage 2 (twiddle chain + radix 24)',
              'four-step twiddle + T stores issued', 'T stores acknowledged', 'tail'],
-         2: ['launch -> T tile arrived (desc + 60 loads)', 'stage 0 (untangle + radix 8 pairs)', 'LDS exchange (2 rounds)',
-             'stage 1 (twiddle chain + 2 x radix 15)', '-', '-', 'lag index + CCF stores issued', 'CCF stores acknowledged',
-             'tail']}
+         2: ['launch -> stage 0 done (desc + 34 T loads in two batches, untangle, radix-8 pairs)', 'LDS exchange (2 rounds)',
+             'stage 1 (twiddle chain + 2 x radix 15)', 'staging + cooperative CCF stores issued (4 barriers)',
+             'CCF stores acknowledged', 'tail']}
 for k, label in ((1, 'COLUMN waves'), (2, 'ROW waves')):
     w = t[kind == k]
     if not len(w):
         continue
     print(f'\n{label}: {len(w)}   lifetime median {np.median(w[:, 9] - w[:, 0]) / (ghz * 1e3):.2f} us '
           f'(p10 {np.percentile(w[:, 9] - w[:, 0], 10) / (ghz * 1e3):.2f}, p90 {np.percentile(w[:, 9] - w[:, 0], 90) / (ghz * 1e3):.2f})')
-    idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9] if k == 1 else [0, 1, 2, 3, 4, 7, 8, 9]
-    lab = names[k]
-    labs = lab if k == 1 else [lab[0], lab[1], lab[2], lab[3], lab[6], lab[7], lab[8]]
+    idx = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9] if k == 1 else [0, 2, 3, 4, 7, 8, 9]      # the row body has no stamp 1
+    labs = names[k]
     for (i0, i1), nm in zip(zip(idx[:-1], idx[1:]), labs):
         d = (w[:, i1] - w[:, i0]).astype(np.float64)
         print(f'  {nm:62s} median {np.median(d):8.0f} cyc = {np.median(d) / (ghz * 1e3):6.2f} us   '
               f'(p10 {np.percentile(d, 10):7.0f}, p90 {np.percentile(d, 90):7.0f})')
+# slot occupancy of this launch: stamp 11 = s_memrealtime (100 MHz) at the wave's end, its life from the cycle stamps
+end_us = t[:, 11] / 100.0
+life_us = (t[:, 9] - t[:, 0]) / (ghz * 1e3)
+start_us = end_us - life_us
+span = end_us.max() - start_us.min()
+print(f'\nlaunch span {span:.1f} us, sum of wave lifetimes {life_us.sum() / 1e3:.2f} ms -> {life_us.sum() / span:.0f} wave slots held on '
+      f'average (of 4096 on the chip; the other pipeline\'s launch holds the rest of what is busy)')
+grid = np.linspace(start_us.min(), end_us.max(), 21)
+print('waves alive at 5 % steps of the span:', ' '.join(str(int(((start_us <= x) & (end_us > x)).sum())) for x in grid))
 np.save(os.path.join(ROOT, 'gpurun_out', 'stamps_last.npy'), live)

@@ -46,6 +46,7 @@ SIGNATURES = {
     'xcx_malloc': [_vp, _sz, C.POINTER(_vp)],
     'xcx_free': [_vp, _vp],
     'xcx_set_reclaim': [_vp, _vp, _vp],
+    'xcx_trim': [_vp],
     'xcx_host_alloc': [_vp, _sz, C.POINTER(_vp)],
     'xcx_host_free': [_vp, _vp],
     'xcx_memset': [_vp, _vp, _i, _sz],

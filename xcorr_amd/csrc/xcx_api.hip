@@ -163,6 +163,28 @@ extern "C" int xcx_destroy(xcx_ctx* ctx) {
   return XCX_OK;
 }
 
+// Give back what the context keeps between calls: the grow-only workspaces of the row ops / filters / transforms, the
+// cached tables, and the cached plans of xcx_timeshift and of the any-length transforms (a day-long rfft, time shift or
+// segmented correlation leaves tens of GB in them).  Plans the CALLER created are the caller's to destroy.
+extern "C" int xcx_trim(xcx_ctx* ctx) {
+  if (!ctx) return set_err(XCX_EINVAL, "null ctx");
+  HIP_TRY(hipSetDevice(ctx->device));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (auto& ps : ctx->pipe) if (ps) HIP_TRY(hipStreamSynchronize(ps));
+  if (ctx->ts_plan) { xcx_plan_destroy(ctx->ts_plan); ctx->ts_plan = nullptr; ctx->ts_n = 0; }
+  for (int i = 0; i < 2; ++i) {
+    if (ctx->bs_plan[i]) { xcx_plan_destroy(ctx->bs_plan[i]); ctx->bs_plan[i] = nullptr; }
+    ctx->bs_key[i][0] = ctx->bs_key[i][1] = ctx->bs_key[i][2] = 0;
+    if (ctx->bs_seg_plan[i]) { xcx_plan_destroy(ctx->bs_seg_plan[i]); ctx->bs_seg_plan[i] = nullptr; }
+    ctx->bs_seg_n[i] = 0;
+  }
+  ctx->sg_tab.release(); ctx->sg_key = 0;
+  for (int i = 0; i < xcx_ctx::kSosTabs; ++i) { ctx->sos_tab[i].release(); ctx->sos_key[i] = 0; }
+  ctx->bs_tab.release(); ctx->bs_tab_n = 0;
+  for (auto& b : ctx->scratch) b.release();
+  return XCX_OK;
+}
+
 extern "C" int xcx_last_error(char* buf, size_t len) {
   if (!buf || len == 0) return XCX_EINVAL;
   snprintf(buf, len, "%s", g_err.c_str());
@@ -655,7 +677,7 @@ extern "C" int xcx_plan_info(xcx_plan* p, int* out6) {
 extern "C" int xcx_plan_t_storage(xcx_plan* p, int* ts) {
   if (!p || !ts) return set_err(XCX_EINVAL, "null argument");
   const xcx_plan* q = (p->seg && p->seg->sub) ? p->seg->sub : p;
-  *ts = (q->t_q24 && q->dual && !q->flow && (q->g.flags & XCX_F_WHITEN) && q->whiten_set) ? 1 : 0;
+  *ts = (q->t_q24 && q->dual && !q->flow && (q->g.flags & XCX_F_WHITEN) && !(q->g.flags & XCX_F_STACK) && q->whiten_set) ? 1 : 0;
   return XCX_OK;
 }
 
@@ -899,7 +921,7 @@ static int dual_run(xcx_plan* p, size_t first, size_t count, int nstack, float* 
     }
     ch.B = 0;
   }
-  p->run_ts = (p->t_q24 && nstack == 1 && !Xsrc && (p->g.flags & XCX_F_WHITEN) && p->whiten_set) ? 1 : 0;
+  p->run_ts = (p->t_q24 && nstack == 1 && !Xsrc && (p->g.flags & XCX_F_WHITEN) && !(p->g.flags & XCX_F_STACK) && p->whiten_set) ? 1 : 0;
   if (!p->ev_fwd) HIP_TRY(hipEventCreateWithFlags(&p->ev_fwd, hipEventDisableTiming));
   // wall time of the whole pair phase on the main stream (the pipelines overlap,
   // so per-launch durations do not add up)

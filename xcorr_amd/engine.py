@@ -196,6 +196,12 @@ class Context:
             for p, _ in blocks:
                 _ffi.lib().xcx_free(self.handle, C.c_void_p(p))
 
+    def trim(self):
+        """Release everything the context caches between calls: the pooled device buffers of this binding and the
+        library's own workspaces, tables and cached plans (xcx_trim).  Plans and arrays of the caller stay."""
+        self.trim_pool()
+        check(_ffi.lib().xcx_trim(self.handle))
+
     def plan(self, n, index_min=0, index_max=None, **flags):
         """A :class:`CCPlan` owned by the context and reused by later calls with the same arguments
         (the reference-style driver makes one call per pair and day: plan workspaces are allocated
