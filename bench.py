@@ -68,6 +68,11 @@ def parse():
     ap.add_argument('--stack', action='store_true', help='time-stack mode (configs[3])')
     ap.add_argument('--days', type=int, default=0,
                     help='--stack: station-days per step, dealt to the ranks (default: one per rank)')
+    ap.add_argument('--stack-reduce', choices=['freq', 'time'], default='freq',
+                    help='--stack with N > 1: sum the ranks\' partial stacks in the frequency domain (one RCCL '
+                         'reduce-scatter of the in-band cross-spectra, each rank inverse-transforms its share of the '
+                         'pairs: xcx_cc1d_stack_finish_reduce) or in the time domain (every rank inverse-transforms all '
+                         'pairs, then xcx_stack_reduce of the P x L stacks)')
     ap.add_argument('--oversubscribe', action='store_true',
                     help='rehearsal: allow more ranks than visible GPUs (ranks share devices; RCCL will refuse)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -285,6 +290,8 @@ def main():
         uid = rdzv.broadcast(X.Context.comm_unique_id() if rank == 0 else b'')
         ctx.comm_init(uid, world, rank)          # a failure here is fatal: no silent partial stacks
         rccl = 'reduce_scatter' if (nrows * ld) % world == 0 else 'all_reduce'
+        if a.stack_reduce == 'freq' and ndays >= world:      # every rank has a day to accumulate
+            rccl = 'reduce_scatter_freq'
         rccl_ranks, rccl_rank = ctx.comm_info()  # what RCCL itself says, not what we passed in
         if rccl_ranks != world or rccl_rank != rank:
             raise SystemExit(f'RCCL communicator spans {rccl_ranks} ranks (rank {rccl_rank}); '
@@ -302,6 +309,9 @@ def main():
                 sd.raw = r
                 sd.front()
                 plan.stack_add(sd.view, pairs, W, hop, stride_s=T)
+            if rccl == 'reduce_scatter_freq':
+                owned, _ = plan.stack_finish_reduce(pairs, out, ld_out=ld)     # the sum across ranks, this rank's pairs
+                return
             if raws:
                 plan.stack_finish(pairs, out=out, ld_out=ld)
             else:

@@ -196,6 +196,16 @@ int xcx_cc1d_stack_add(xcx_plan* plan, const float* traces, int S, int W, long s
                        long stride_w, const int* pairs, int P, int on_device);
 int xcx_cc1d_stack_finish(xcx_plan* plan, const int* pairs, int P, float* out, long ld_out,
                           int on_device, long long* windows);
+/* ... across ranks, in the frequency domain (configs[3]; needs xcx_comm_init on the plan's context).  Every rank
+ * calls it with the SAME pair list after accumulating its own station-days: the in-band elements of the ranks'
+ * cross-spectrum accumulators are summed with ONE ncclReduceScatter (a plan whitened to 0.1-10 Hz at 50 Hz: 1.19 GB
+ * per rank instead of the 2.90 GB of P x L float32 stacks that xcx_cc1d_stack_finish + xcx_stack_reduce move), and
+ * each rank inverse-transforms only the ceil(P / nranks) accumulator rows it receives.  out: DEVICE [P][ld_out]; only
+ * the rows of the pairs this rank owns are written, owned[i] (P host bytes) = 1 for those pairs (every pair is owned
+ * by exactly one rank; which one follows the engine's processing order of the pair list, not the caller's).
+ * By linearity the owned rows equal the sum over ranks of what xcx_cc1d_stack_finish would have produced. */
+int xcx_cc1d_stack_finish_reduce(xcx_plan* plan, const int* pairs, int P, float* out, long ld_out,
+                                 unsigned char* owned, long long* windows);
 /* Abandon an open accumulation (after a failed add or an error in the driver loop): clears the
  * accumulator state so that the plan accepts xcx_cc1d_pairs or a new series of adds again. */
 int xcx_cc1d_stack_reset(xcx_plan* plan);

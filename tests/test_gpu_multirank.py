@@ -44,6 +44,14 @@ ctx.sync()
 share = out.to_host().reshape(world, -1)[rank].copy()
 np.save(os.path.join(rdir, f'total_{{rank}}.npy'), total)
 np.save(os.path.join(rdir, f'share_{{rank}}.npy'), share)
+# the same sum in the frequency domain: one reduce-scatter of the accumulators, each rank inverts its pairs
+for d in days:
+    plan.stack_add(synthetic_traces(S, hop * (W - 1) + n, day=d), pairs, W, hop)
+fout = ctx.empty((len(pairs), L)).zero()
+owned, _ = plan.stack_finish_reduce(pairs, fout)
+ctx.sync()
+np.save(os.path.join(rdir, f'freq_{{rank}}.npy'), fout.to_host())
+np.save(os.path.join(rdir, f'owned_{{rank}}.npy'), owned)
 rd.barrier()
 '''
 
@@ -76,6 +84,12 @@ def test_two_rank_rccl_stack_reduce(tmp_path):
     assert np.array_equal(tot[0], tot[1])
     shares = np.concatenate([np.load(tmp_path / f'share_{r}.npy') for r in range(world)])
     assert np.array_equal(shares.reshape(tot[0].shape), tot[0])
+    # xcx_cc1d_stack_finish_reduce: every pair owned by exactly one rank, its row = the total
+    owned = [np.load(tmp_path / f'owned_{r}.npy') for r in range(world)]
+    assert (sum(o.astype(int) for o in owned) == 1).all()
+    for r in range(world):
+        f = np.load(tmp_path / f'freq_{r}.npy')
+        assert np.abs(f[owned[r]] - ref[owned[r]]).max() / np.abs(ref).max() < 1e-5
 
 
 _RANK_WINDOWS = r'''

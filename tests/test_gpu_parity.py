@@ -582,3 +582,67 @@ def test_q24_storage_of_the_intermediate_on_whitened_plans(ctx, monkeypatch):
     assert X.CCPlan(ctx, 180000).t_storage == 'f32'                                       # no whitening: no bound
     assert X.CCPlan(ctx, 180000, whiten=(50., .1, 10., .05), stack=True).t_storage == 'f32'   # stacks read a Gram matrix
     assert X.CCPlan(ctx, 30000, whiten=(50., 1., 10., .5)).t_storage == 'f32'             # N1 = 256: no lane-pair store
+
+
+def test_stack_finish_reduce_in_the_frequency_domain(ctx, monkeypatch):
+    """configs[3] across ranks (xcx_cc1d_stack_finish_reduce): the ranks' cross-spectrum accumulators are summed with
+    one reduce-scatter of their IN-BAND elements and every rank inverse-transforms only its share of the pairs.
+    One GPU can check (a) the whole path through RCCL on a one-rank communicator: bit for bit what
+    xcx_cc1d_stack_finish gives, all pairs owned; (b) the partition for 3 and 5 ranks without RCCL
+    (XCX_STACK_REDUCE_FAKE: the other ranks contribute nothing): every pair is owned by exactly one rank, a rank's
+    rows equal the plain finish, rows it does not own are never written.  Band-limited and full-band plans, a pair
+    list in arbitrary order with a duplicate."""
+    S, n, hop, W = 9, 2400, 1200, 4
+    tr = [R.synthetic_traces(S, hop * (W - 1) + n, day=d) for d in range(2)]
+    pairs = R.all_pairs(S)[::-1].copy()
+    pairs = np.concatenate([pairs, pairs[3:4]])                    # a duplicate shares its accumulator row
+    P = len(pairs)
+    own_ctx = X.Context(0)
+    own_ctx.comm_init(X.Context.comm_unique_id(), 1, 0)
+    try:
+        for kw in (dict(whiten=(50., 1., 10., .5), onebit=True, demean=True), dict()):
+            plan = X.CCPlan(own_ctx, n, stack=True, **kw)
+            L = plan.L
+
+            def accumulate():
+                for x in tr:
+                    plan.stack_add(x, pairs, W, hop)
+            accumulate()
+            ref = own_ctx.empty((P, L))
+            plan.stack_finish(pairs, out=ref)
+            want = ref.to_host()
+            g = R.whiten_weights(plan.N, *kw['whiten']) if kw else None
+            orc = sum(R.cc_pairs(x, pairs, n, hop, dtype=np.float64, nfft=plan.N, whiten=g, onebit_=bool(kw),
+                                 demean_=bool(kw)).sum(axis=1) for x in tr)
+            assert relerr(want, orc) < TOL
+            accumulate()                                            # (a) through RCCL, one rank
+            out = own_ctx.empty((P, L))
+            owned, nw = plan.stack_finish_reduce(pairs, out)
+            assert owned.all() and nw == 2 * W
+            assert np.array_equal(out.to_host(), want)
+            for world in (3, 5):                                    # (b) the partition, no RCCL
+                count = np.zeros(P, int)
+                for rank in range(world):
+                    monkeypatch.setenv('XCX_STACK_REDUCE_FAKE', f'{world},{rank}')
+                    accumulate()
+                    out.copy_from(np.full((P, L), np.nan, np.float32))
+                    owned, _ = plan.stack_finish_reduce(pairs, out)
+                    got = out.to_host()
+                    assert np.array_equal(got[owned], want[owned])
+                    assert np.isnan(got[~owned]).all()
+                    count += owned
+                monkeypatch.delenv('XCX_STACK_REDUCE_FAKE')
+                assert (count == 1).all()
+            plan.close()
+        bare = X.Context(0)                                         # a context without a communicator refuses
+        try:
+            plain = X.CCPlan(bare, n, stack=True)
+            plain.stack_add(tr[0], pairs, W, hop)
+            with pytest.raises(XcxError, match='xcx_comm_init'):
+                plain.stack_finish_reduce(pairs, bare.empty((P, plain.L)))
+            plain.stack_reset()
+            plain.close()
+        finally:
+            bare.close()
+    finally:
+        own_ctx.close()

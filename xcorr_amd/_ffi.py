@@ -110,6 +110,7 @@ SIGNATURES = {
     'xcx_ram_normalize': [_vp, _vp, _l, _l, _l, _i],
     'xcx_cc1d_stack_add': [_vp, _vp, _i, _i, _l, _l, _vp, _i, _i],
     'xcx_cc1d_stack_finish': [_vp, _vp, _i, _vp, _l, _i, _vp],
+    'xcx_cc1d_stack_finish_reduce': [_vp, _vp, _i, _vp, _l, _vp, _vp],
     'xcx_cc1d_stack_reset': [_vp],
     'xcx_cc1d_prepare': [_vp, _vp, _i, _i, _l, _l],
     'xcx_cc1d_prepare_sync': [_vp],

@@ -56,6 +56,14 @@ extern "C" int xcx_comm_info(xcx_ctx* ctx, int* nranks, int* rank) {
   return XCX_OK;
 }
 
+namespace xcx {
+int comm_reduce_scatter(xcx_ctx* ctx, const float* send, float* recv, size_t per) {
+  if (!ctx->comm) return set_err(XCX_EINVAL, "xcx_comm_init() not called on this context");
+  NCCL_TRY(ncclReduceScatter(send, recv, per, ncclFloat, ncclSum, (ncclComm_t)ctx->comm, ctx->stream));
+  return XCX_OK;
+}
+}  // namespace xcx
+
 extern "C" int xcx_stack_reduce(xcx_ctx* ctx, float* stack, size_t count, int reduce_scatter) {
   if (!ctx || !stack) return set_err(XCX_EINVAL, "null argument");
   // No communicator is an error even for one rank: a multi-rank job whose xcx_comm_init failed

@@ -546,7 +546,8 @@ extern "C" int xcx_plan_destroy(xcx_plan* p) {
   }
   DevBuf* bufs[] = {&p->tw_N1, &p->tw_N2h, &p->tw_unt, &p->tw_N,
                     &p->Tm_f, &p->spectra, &p->T, &p->descs,
-                    &p->dtraces, &p->dout, &p->dpairs, &p->psum, &p->psq, &p->gramC, &p->gramTiles, &p->gramPidx};
+                    &p->dtraces, &p->dout, &p->dpairs, &p->psum, &p->psq, &p->gramC, &p->gramTiles, &p->gramPidx,
+                    &p->gramPack, &p->gramRecv, &p->gramOwn, &p->bandTab};
   for (DevBuf* b : bufs) b->release();
   delete p;
   return XCX_OK;
@@ -1234,6 +1235,113 @@ extern "C" int xcx_cc1d_stack_finish(xcx_plan* p, const int* pairs, int P, float
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return flow_check(ctx);
   }
+  return XCX_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Time-stack across ranks in the FREQUENCY domain (SURVEY 8e, configs[3]): every rank has accumulated the
+// cross-spectra of its station-days (xcx_cc1d_stack_add); instead of P inverse transforms per rank followed by a
+// reduce-scatter of P x L float32 stacks (2.90 GB per rank at P = 2016), the ranks reduce-scatter the IN-BAND
+// elements of the accumulators (a whitened plan: 40 % of the half spectrum for 0.1-10 Hz at 50 Hz, 1.19 GB) and each
+// rank inverse-transforms only the P / nranks rows it receives.  k_band_pack / k_band_unpack move the in-band
+// stretches [0, za) and (zb, N1) of every column k2 between the [k2][N1] accumulator rows and dense rows.
+// ---------------------------------------------------------------------------
+struct BandCol { int za, zb, off; };
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_band_move(cf* __restrict__ rows, size_t pitch, cf* __restrict__ dense, size_t nib,
+                                                   const BandCol* __restrict__ tab, int N1, int nrows_valid) {
+  const int k2 = blockIdx.x, r = blockIdx.y;
+  const BandCol b = tab[k2];
+  const int cnt = (b.zb >= b.za) ? b.za + (N1 - 1 - b.zb) : N1;
+  cf* __restrict__ row = rows + (size_t)r * pitch + (size_t)k2 * N1;
+  cf* __restrict__ d = dense + (size_t)r * nib + b.off;
+  for (int i = threadIdx.x; i < cnt; i += 256) {
+    const int k1 = (b.zb >= b.za && i >= b.za) ? b.zb + 1 + (i - b.za) : i;
+    if (PACK) d[i] = (r < nrows_valid) ? row[k1] : make_float2(0.f, 0.f);       // rows beyond P pad the last share
+    else row[k1] = d[i];
+  }
+}
+
+extern "C" int xcx_cc1d_stack_finish_reduce(xcx_plan* p, const int* pairs, int P, float* out, long ld_out,
+                                            unsigned char* owned, long long* windows) {
+  if (!p || !pairs || !out || !owned) return set_err(XCX_EINVAL, "null argument");
+  if (p->acc_broken)
+    return set_err(XCX_EINVAL, "xcx_cc1d_stack_finish_reduce: an add of this accumulation failed; call xcx_cc1d_stack_reset");
+  if (p->acc_count < 1) return set_err(XCX_EINVAL, "xcx_cc1d_stack_finish_reduce: nothing accumulated");
+  xcx_ctx* ctx = p->ctx;
+  const Geom& g = p->g;
+  HIP_TRY(hipSetDevice(ctx->device));
+  // XCX_STACK_REDUCE_FAKE="nranks,rank" (tests on one GPU): the partition of rank `rank` of `nranks` without RCCL --
+  // the other ranks contribute nothing, so the rows this rank owns equal those of xcx_cc1d_stack_finish
+  int nr = ctx->nranks, rk = ctx->rank;
+  bool fake = false;
+  if (const char* fk = getenv("XCX_STACK_REDUCE_FAKE")) {
+    if (sscanf(fk, "%d,%d", &nr, &rk) != 2 || nr < 1 || rk < 0 || rk >= nr) return set_err(XCX_EINVAL, "XCX_STACK_REDUCE_FAKE=nranks,rank");
+    fake = true;
+  } else if (!ctx->comm) {
+    return set_err(XCX_EINVAL, "xcx_cc1d_stack_finish_reduce: xcx_comm_init() not called on this context");
+  }
+  const long L = p->L;
+  if (ld_out == 0) ld_out = L;
+  if (ld_out < L) return set_err(XCX_EINVAL, "ld_out (%ld) < L (%ld)", ld_out, L);
+  int rc;
+  const int S = p->acc_S;
+  if (P != p->acc_P) return set_err(XCX_EINVAL, "xcx_cc1d_stack_finish_reduce: P differs from the accumulated pair list");
+  if ((rc = check_pairs(pairs, S, P))) return rc;
+  unsigned long long akey = fnv(pairs, sizeof(int) * 2 * (size_t)P, 1469598103934665603ULL);
+  akey = fnv(&S, sizeof S, akey) | 1ULL;
+  if (akey != p->acc_key) return set_err(XCX_EINVAL, "xcx_cc1d_stack_finish_reduce: pair list differs from the accumulated one");
+  p->acc_ld = ld_out;
+  if ((rc = stack_tables(p, pairs, S, P, ld_out))) return rc;
+  if ((rc = stack_flush(p))) { p->acc_broken = true; return rc; }
+  // band table of the accumulator columns
+  std::vector<BandCol> tab(g.N2h + 1);
+  size_t nib = 0;
+  for (int k2 = 0; k2 <= g.N2h; ++k2) {
+    int za = (g.band_hi >= k2) ? (g.band_hi - k2) / g.N2 + 1 : 0;
+    int zb = (g.N - g.band_hi - k2 + g.N2 - 1) / g.N2 - 1;                      // band_zero_stretch (wave_kernels.h)
+    if (g.band_hi >= g.N) { za = g.N1; zb = g.N1 - 1; }                         // no band limit: everything
+    if (za > g.N1) za = g.N1;
+    tab[k2] = BandCol{za, zb, (int)nib};
+    nib += (zb >= za) ? (size_t)za + (size_t)(g.N1 - 1 - zb) : (size_t)g.N1;
+  }
+  const int Pr = (P + nr - 1) / nr, Ppad = Pr * nr;                             // rows per rank, rows with padding
+  if ((rc = upload(ctx, p->bandTab, tab.data(), tab.size() * sizeof(BandCol)))) return rc;
+  if ((rc = p->gramPack.ensure(ctx, sizeof(cf) * nib * (size_t)Ppad))) return rc;
+  if ((rc = p->gramRecv.ensure(ctx, sizeof(cf) * nib * (size_t)Pr))) return rc;
+  if ((rc = p->gramOwn.ensure(ctx, sizeof(cf) * p->spec_pitch * (size_t)Pr))) return rc;
+  if (p->gram_own_zeroed != p->gramOwn.ptr || p->gram_own_gen != p->gramOwn.gen || p->gram_own_band != g.band_hi) {
+    HIP_TRY(hipMemsetAsync(p->gramOwn.ptr, 0, p->gramOwn.bytes, ctx->stream));   // out-of-band stretches stay zero
+    p->gram_own_zeroed = p->gramOwn.ptr; p->gram_own_gen = p->gramOwn.gen; p->gram_own_band = g.band_hi;
+  }
+  hipLaunchKernelGGL(k_band_move<true>, dim3(g.N2h + 1, Ppad), dim3(256), 0, ctx->stream, (cf*)p->gramC.ptr, p->spec_pitch,
+                     (cf*)p->gramPack.ptr, nib, (const BandCol*)p->bandTab.ptr, g.N1, P);
+  HIP_TRY(hipGetLastError());
+  if (fake) {
+    HIP_TRY(hipMemcpyAsync(p->gramRecv.ptr, (const cf*)p->gramPack.ptr + (size_t)rk * Pr * nib, sizeof(cf) * nib * (size_t)Pr,
+                           hipMemcpyDeviceToDevice, ctx->stream));
+  } else if ((rc = comm_reduce_scatter(ctx, (const float*)p->gramPack.ptr, (float*)p->gramRecv.ptr, 2 * nib * (size_t)Pr))) {
+    return rc;
+  }
+  hipLaunchKernelGGL(k_band_move<false>, dim3(g.N2h + 1, Pr), dim3(256), 0, ctx->stream, (cf*)p->gramOwn.ptr, p->spec_pitch,
+                     (cf*)p->gramRecv.ptr, nib, (const BandCol*)p->bandTab.ptr, g.N1, Pr);
+  HIP_TRY(hipGetLastError());
+  // this rank's rows: accumulator rows [rk Pr, rk Pr + Pr) in processing order; descriptors against gramOwn
+  std::vector<PwDesc> own;
+  memset(owned, 0, (size_t)P);
+  for (int q = 0; q < P; ++q) {
+    const PwDesc& d = p->hdescs[q];
+    if (d.slot_a < rk * Pr || d.slot_a >= (rk + 1) * Pr) continue;
+    own.push_back(PwDesc{d.slot_a - rk * Pr, d.slot_b - rk * Pr, d.out_off});
+    owned[d.out_off / ld_out] = 1;
+  }
+  p->desc_key = 0;                                                               // p->descs no longer holds the full table
+  if (!own.empty()) {
+    if ((rc = upload(ctx, p->descs, own.data(), own.size() * sizeof(PwDesc)))) return rc;
+    if ((rc = stack_inverse(p, (int)own.size(), out, 0, (const cf*)p->gramOwn.ptr))) return rc;
+  }
+  if (windows) *windows = p->acc_windows;
+  p->acc_count = 0; p->acc_windows = 0; p->acc_grams = 0;
   return XCX_OK;
 }
 

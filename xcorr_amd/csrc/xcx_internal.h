@@ -36,6 +36,9 @@ struct HostPin {
 hipError_t ctx_malloc(xcx_ctx* ctx, void** ptr, size_t bytes);
 size_t ctx_reclaim(xcx_ctx* ctx);
 
+// comm.hip: ncclReduceScatter of `per` floats per rank on the context's stream (send: nranks * per floats)
+int comm_reduce_scatter(xcx_ctx* ctx, const float* send, float* recv, size_t per);
+
 struct DevBuf {
   void* ptr = nullptr;
   size_t bytes = 0;

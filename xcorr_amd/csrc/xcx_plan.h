@@ -27,6 +27,10 @@ struct xcx_plan {
   const WColEntry* wcol = nullptr;
   const WRowEntry* wrow = nullptr;
   DevBuf gramC, gramTiles, gramPidx;   // time-stack cross-spectra [P][spec_pitch], tile list, pair lookup
+  // xcx_cc1d_stack_finish_reduce: in-band elements of gramC packed for the reduce-scatter, this rank's share of the
+  // sum, its share unpacked into cross-spectrum rows, the per-column band table {za, zb, offset}
+  DevBuf gramPack, gramRecv, gramOwn, bandTab;
+  void* gram_own_zeroed = nullptr; unsigned long long gram_own_gen = 0; int gram_own_band = 0;
   const WFusedEntry* dual = nullptr;    // one-launch I2(b-1) + I1(b) kernel, if built for (N1, N2h)
   // windows too long for one transform (n + max|lag| beyond the planner's table, e.g. the reference's
   // production setting window_length = 86400 s, clip_lag = (0, 9 h): scripts/cc.py:25-29): the

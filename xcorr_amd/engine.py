@@ -522,6 +522,22 @@ class CCPlan:
                                                int(on_dev), C.byref(nw)))
         return out, nw.value
 
+    def stack_finish_reduce(self, pairs, out, ld_out=0):
+        """The multi-rank finish of an accumulation (xcx_cc1d_stack_finish_reduce): the ranks' cross-spectrum
+        accumulators are summed in the frequency domain with one RCCL reduce-scatter of their in-band elements and
+        every rank inverse-transforms only the pairs it receives.  `out`: DeviceArray [P, ld]; returns
+        (owned, windows): owned[i] is True for the pairs whose rows of `out` this rank wrote (the finished stacks)."""
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        P = len(pairs)
+        if not isinstance(out, DeviceArray):
+            raise ValueError('stack_finish_reduce needs a DeviceArray `out`')
+        _check_out(out, P, int(ld_out) or self.L, self.L)
+        owned = np.zeros(P, np.uint8)
+        nw = C.c_longlong(0)
+        check(_ffi.lib().xcx_cc1d_stack_finish_reduce(self.handle, ptr(pairs), P, ptr(out), int(ld_out), ptr(owned),
+                                                      C.byref(nw)))
+        return owned.astype(bool), nw.value
+
     def cc(self, x, y, out=None):
         """Batched two-input form: x, y [batch, n] -> [batch, L]."""
         on_dev = isinstance(x, DeviceArray)
