@@ -20,7 +20,8 @@ template <class K> static hipError_t ensure_lds(K kernel, size_t bytes) {
 constexpr size_t kLds = sizeof(float) * lds_col_floats(RX::L) * kWPB;
 hipError_t XCX_CAT(launch_wfwd_cols_, XCX_INST_L)(const WF2Args& a, dim3 grid, hipStream_t s) {
   grid.x = (grid.x + kWPB - 1) / kWPB;
-  hipLaunchKernelGGL(k_wfwd_cols<RX>, grid, dim3(kWNT * kWPB), kLds, s, a);
+  if (a.nt) hipLaunchKernelGGL((k_wfwd_cols<RX, true>), grid, dim3(kWNT * kWPB), kLds, s, a);
+  else hipLaunchKernelGGL((k_wfwd_cols<RX, false>), grid, dim3(kWNT * kWPB), kLds, s, a);
   return hipGetLastError();
 }
 hipError_t XCX_CAT(launch_wpair_cols_, XCX_INST_L)(const WI1Args& a, dim3 grid, hipStream_t s) {
@@ -38,14 +39,17 @@ constexpr size_t kLdsF = sizeof(float) * lds_frow_floats(RX::L) * kF1WPB;   // f
 constexpr size_t kLds = sizeof(float) * lds_row_floats(RX::L) * kWPB;
 hipError_t XCX_CAT(launch_wfwd_rows_, XCX_INST_L)(const WF1Args& a, dim3 grid, hipStream_t s) {
   grid.x = (grid.x + kF1WPB - 1) / kF1WPB;
-  static hipError_t once = ensure_lds((k_wfwd_rows<RX, false>), kLdsF);
-  static hipError_t once1 = ensure_lds((k_wfwd_rows<RX, true>), kLdsF);
-  if (once != hipSuccess) return once;
-  if (once1 != hipSuccess) return once1;
-  if (a.g.flags & XCX_F_ONEBIT)
-    hipLaunchKernelGGL((k_wfwd_rows<RX, true>), grid, dim3(kWNT * kF1WPB), kLdsF, s, a);
-  else
-    hipLaunchKernelGGL((k_wfwd_rows<RX, false>), grid, dim3(kWNT * kF1WPB), kLdsF, s, a);
+  static hipError_t once = ensure_lds((k_wfwd_rows<RX, false, false>), kLdsF);
+  static hipError_t once1 = ensure_lds((k_wfwd_rows<RX, true, false>), kLdsF);
+  static hipError_t once2 = ensure_lds((k_wfwd_rows<RX, false, true>), kLdsF);
+  static hipError_t once3 = ensure_lds((k_wfwd_rows<RX, true, true>), kLdsF);
+  for (hipError_t e : {once, once1, once2, once3})
+    if (e != hipSuccess) return e;
+  const bool ob = a.g.flags & XCX_F_ONEBIT;
+  if (ob && a.nt) hipLaunchKernelGGL((k_wfwd_rows<RX, true, true>), grid, dim3(kWNT * kF1WPB), kLdsF, s, a);
+  else if (ob) hipLaunchKernelGGL((k_wfwd_rows<RX, true, false>), grid, dim3(kWNT * kF1WPB), kLdsF, s, a);
+  else if (a.nt) hipLaunchKernelGGL((k_wfwd_rows<RX, false, true>), grid, dim3(kWNT * kF1WPB), kLdsF, s, a);
+  else hipLaunchKernelGGL((k_wfwd_rows<RX, false, false>), grid, dim3(kWNT * kF1WPB), kLdsF, s, a);
   return hipGetLastError();
 }
 hipError_t XCX_CAT(launch_wpair_rows_, XCX_INST_L)(const WI2Args& a, dim3 grid, hipStream_t s) {

@@ -291,6 +291,33 @@ XCX_DEV float sw_scale(const double* __restrict__ psq, int sw, int N, int flags,
   return (float)(1.0 / (nrm * sqrt((double)N)));
 }
 
+// Cache policy of the forward transforms' global accesses (template parameter NT of k_wfwd_rows / k_wfwd_cols).  A large
+// launch streams everything it touches exactly once (traces in, Tf out and back in, spectra out: 0.76 GB of Tf per
+// 512-window launch against 256 MiB of Infinity Cache), so its accesses are non-temporal and leave the cache to the
+// pair pipelines' T ring (headline +0.8 %, profiles/r05_session2_notes.txt); small launches (a few rows of a time
+// shift or an any-length transform), whose Tf does fit, keep the default policy.  forward() decides per launch.
+constexpr size_t kFwdNtBytes = (size_t)128 << 20;           // Tf bytes of a launch from which it streams
+template <bool NT> XCX_DEV float fwd_ld(const float* p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <bool NT> XCX_DEV cf fwd_ld(const cf* p) {
+  if constexpr (NT) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const f32x2 v = __builtin_nontemporal_load(reinterpret_cast<const f32x2*>(p));
+    return make_float2(v.x, v.y);
+  } else {
+    return *p;
+  }
+}
+template <bool NT> XCX_DEV void fwd_st(cf* p, cf v) {
+  if constexpr (NT) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(f32x2{v.x, v.y}, reinterpret_cast<f32x2*>(p));
+  } else {
+    *p = v;
+  }
+}
 // ---------------------------------------------------------------------------
 // W-F1: forward rows.  grid = (N1/16, station-windows), block = 64
 // ---------------------------------------------------------------------------
@@ -302,6 +329,7 @@ struct WF1Args {
   const cf* tw_unt;          // W_{N2}[k], k < N2h
   const cf* tw_N;
   Geom g;
+  int nt;                    // 1: non-temporal accesses (large launches, see fwd_ld)
 };
 
 // waves per workgroup of the forward row kernel: its full-complex LDS slice (15 KB per wave at
@@ -313,7 +341,7 @@ constexpr int kF1WPB = XCX_F1_WPB;
 // ONEBIT is a template parameter: as a run-time flag the sign() branch sat between every
 // pair of loads and its s_waitcnt vmcnt(0) serialised the whole gather (30 memory round
 // trips per lane; the kernel ran at 1 TB/s)
-template <class RX, bool ONEBIT>
+template <class RX, bool ONEBIT, bool NT = false>
 __global__ __launch_bounds__(kWNT * kF1WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
 void k_wfwd_rows(WF1Args a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
@@ -334,7 +362,7 @@ void k_wfwd_rows(WF1Args a) {
   auto in = [=](int m, int r) -> cf {
     const int i0 = row0 + r + N1 * (2 * m);
     const int i1 = i0 + N1;
-    const float x0 = x[i0 < n ? i0 : n - 1], x1 = x[i1 < n ? i1 : n - 1];
+    const float x0 = fwd_ld<NT>(x + (i0 < n ? i0 : n - 1)), x1 = fwd_ld<NT>(x + (i1 < n ? i1 : n - 1));
     float v0, v1;
     if constexpr (ONEBIT) {
       v0 = onebit_of(x0, mean_d);
@@ -388,7 +416,7 @@ void k_wfwd_rows(WF1Args a) {
       const cf e = cmul(tu, df);
       cf H = make_float2(0.5f * (sm.x + e.y), 0.5f * (sm.y - e.x));
       H = cmul(H, tn);
-      Tf[k * N1 + m1] = H;
+      fwd_st<NT>(Tf + (k * N1 + m1), H);
     });
   }
   if (tid_of<kWNT>() < kWRB) {
@@ -396,7 +424,7 @@ void k_wfwd_rows(WF1Args a) {
     const cf u = lds[r];
     const float hn = u.x - u.y;
     const cf w = twN_lookup(a.tw_N, (unsigned)m1 * (unsigned)N2h);
-    Tf[N2h * N1 + m1] = make_float2(hn * w.x, hn * w.y);
+    fwd_st<NT>(Tf + (N2h * N1 + m1), make_float2(hn * w.x, hn * w.y));
   }
 }
 
@@ -414,9 +442,10 @@ struct WF2Args {
   // q = sw_first + blockIdx.y goes to slot slot0 + (q / slot_w) * slot_ld + q % slot_w; slot_ld = 0:
   // dense, slot0 + blockIdx.y
   int sw_first, slot_w, slot_ld;
+  int nt;                    // 1: non-temporal accesses (large launches, see fwd_ld)
 };
 
-template <class RX>
+template <class RX, bool NT = false>
 __global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(RX::L > 2048 ? 1 : 3, RX::L > 2048 ? 2 : 3)))
 void k_wfwd_cols(WF2Args a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
@@ -434,7 +463,7 @@ void k_wfwd_cols(WF2Args a) {
   if (a.slot_ld) { const int q = a.sw_first + sw; slot = a.slot0 + (q / a.slot_w) * a.slot_ld + q % a.slot_w; }
   cf* __restrict__ dst = a.X + (size_t)slot * a.spec_pitch + (size_t)k2 * N1;
   const float wb0 = a.wb0, wb1 = a.wb1, wb2 = a.wb2, wb3 = a.wb3;
-  auto in = [=](int m1, int) -> cf { return src[m1]; };
+  auto in = [=](int m1, int) -> cf { return fwd_ld<NT>(src + m1); };
   using CG = ColGeom<RX>;
   // the out-of-band stretch of a band-limited plan is never stored: the buffer holds zeros there
   // (zeroed once per allocation by forward()), which is what the whitening gain would produce
@@ -454,7 +483,7 @@ void k_wfwd_cols(WF2Args a) {
         const float mag = sqrtf(o.x * o.x + o.y * o.y);
         o = cscale(o, (mag > 0.f) ? gain / mag : 0.f);
       }
-      dst[k1] = cscale(o, scale);
+      fwd_st<NT>(dst + k1, cscale(o, scale));
     }
   };
 #ifdef XCX_STAMPS

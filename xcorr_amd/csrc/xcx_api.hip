@@ -777,6 +777,10 @@ static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_
     f1.tw_N = (const cf*)p->tw_N.ptr;
     f1.g = g;
     if (n_valid > 0) f1.g.n = n_valid;
+    // a launch whose Tf (written here, read back by the column pass) is beyond what stays cache-resident streams
+    static const int nt_env = getenv("XCX_FWD_NT") ? atoi(getenv("XCX_FWD_NT")) : -1;    // A/B: 0 never, 1 always
+    const int nt = nt_env >= 0 ? (nt_env != 0) : (sizeof(cf) * tf_per * (size_t)cnt >= kFwdNtBytes);
+    f1.nt = nt;
     {
       ProfScope ps(p, KID_FWD_ROWS, cnt);
       HIP_TRY(p->wrow->fwd(f1, dim3(g.N1 / kWRB, cnt), ctx->stream));
@@ -792,6 +796,7 @@ static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_
     f2.wb0 = p->wb[0]; f2.wb1 = p->wb[1]; f2.wb2 = p->wb[2]; f2.wb3 = p->wb[3];
     f2.fixed_norm = p->fixed_norm;
     f2.g = g;
+    f2.nt = nt;
     {
       ProfScope ps(p, KID_FWD_COLS, cnt);
       HIP_TRY(p->wcol->fwd(f2, dim3(g.N2h + 1, cnt), ctx->stream));
