@@ -839,12 +839,25 @@ extern "C" int xcx_snr(xcx_ctx* ctx, const float* x, long batch, long n, const u
 // passes (HIP events on the context's stream): the ceiling an output-bound pass can reach on this
 // chip, reported by bench.py beside the nominal 8 TB/s.
 namespace {
-__global__ void k_stream_fill(float4* __restrict__ dst, size_t n16, float v) {
+// Every wave streams through a contiguous region of its own, 16 KB (sixteen 1 KB instructions) at a time: 5.7-5.8 TB/s.
+// (Until round 5 one grid-wide front of 16 bytes per thread swept the buffer: 4.4 TB/s -- the chip writes many separate
+// streams faster than one wide front; tools/micro/hol.hip mode 3.  The runtime's own memset, plain stores, reaches
+// 6.5 TB/s on a 4.5 GB buffer, profiles/r05c_summary.txt.)
+constexpr int kFillWaves = 2048;                              // 8 per CU
+__global__ __launch_bounds__(256) void k_stream_fill(float4* __restrict__ dst, size_t n16, float v) {
   typedef float f32x4 __attribute__((ext_vector_type(4)));
   const f32x4 w = {v, v, v, v};
   f32x4* __restrict__ d = reinterpret_cast<f32x4*>(dst);
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x)
-    __builtin_nontemporal_store(w, d + i);
+  const size_t wave = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const size_t lane = threadIdx.x & 63;
+  const size_t per = ((n16 + kFillWaves - 1) / kFillWaves + 63) & ~(size_t)63;     // 16-byte elements per wave, whole 1 KB runs
+  const size_t b = wave * per, e = b + per < n16 ? b + per : n16;
+  size_t i = b + lane;
+  for (; i + 15 * 64 < e; i += 16 * 64) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) __builtin_nontemporal_store(w, d + i + j * 64);
+  }
+  for (; i < e; i += 64) __builtin_nontemporal_store(w, d + i);
 }
 }  // namespace
 
@@ -853,11 +866,11 @@ extern "C" int xcx_stream_write_rate(xcx_ctx* ctx, void* dptr, size_t bytes, int
   if (bytes < 16 || reps < 1) return set_err(XCX_EINVAL, "bytes >= 16 and reps >= 1 required");
   HIP_TRY(hipSetDevice(ctx->device));
   const size_t n16 = bytes / 16;
-  const unsigned grid = 256 * 16;
-  hipLaunchKernelGGL(k_stream_fill, dim3(grid), dim3(NT), 0, ctx->stream, (float4*)dptr, n16, 0.f);   // warm-up
+  const unsigned grid = kFillWaves / 4;
+  hipLaunchKernelGGL(k_stream_fill, dim3(grid), dim3(256), 0, ctx->stream, (float4*)dptr, n16, 0.f);   // warm-up
   HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
   for (int r = 0; r < reps; ++r)
-    hipLaunchKernelGGL(k_stream_fill, dim3(grid), dim3(NT), 0, ctx->stream, (float4*)dptr, n16, 0.f);
+    hipLaunchKernelGGL(k_stream_fill, dim3(grid), dim3(256), 0, ctx->stream, (float4*)dptr, n16, 0.f);
   HIP_TRY(hipGetLastError());
   HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
   HIP_TRY(hipEventSynchronize(ctx->ev1));
