@@ -464,6 +464,8 @@ def main():
             'workload': workload_str,
             'fft_length': plan.N, 'pair_batch': plan.batch,
             't_storage': plan.t_storage,      # intermediate of the two-pass inverse: 'q24' = 2 x 24-bit fixed point
+            'zero_skip_blocks': ('%d..%d of %d' % (plan.zero_skip[0], plan.zero_skip[1] - 1 - plan.zero_skip[0], plan.zero_skip[1])
+                                 if plan.zero_skip[0] else 'none'),   # 64-point spectrum blocks the column pass knows to be zero
             'shard': shard,
             'overlap_next_step_front_end': bool(pipelined), 'per_rank_pair_windows_per_step': units_rank // a.steps,
         },

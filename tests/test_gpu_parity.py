@@ -584,6 +584,68 @@ def test_q24_storage_of_the_intermediate_on_whitened_plans(ctx, monkeypatch):
     assert X.CCPlan(ctx, 30000, whiten=(50., 1., 10., .5)).t_storage == 'f32'             # N1 = 256: no lane-pair store
 
 
+def _zskip_expected(N, N1, band_hi):
+    """Restatement of zskip_need / zskip_pick (csrc/wave_kernels.h): the instantiated symmetric block range inside the
+    zero stretch of EVERY column of a band-limited spectrum."""
+    N2 = N // N1
+    if band_hi >= N:
+        return 0
+    za = max((band_hi - k2) // N2 + 1 if band_hi >= k2 else 0 for k2 in range(N2 // 2 + 1))
+    zb = min((N - band_hi - k2 + N2 - 1) // N2 - 1 for k2 in range(N2 // 2 + 1))
+    nb = N1 // 64
+    first, last = -(-za // 64), (zb + 1) // 64 - 1
+    need = max(first, nb - 1 - last)
+    if need < 1 or 2 * need >= nb:
+        return 0
+    for v in {1536: (3, 5, 7, 9), 1024: (2, 4, 6), 768: (2, 3, 4), 512: (1, 2)}.get(N1, ()):
+        if v >= need and 2 * v < nb:
+            return v
+    return 0
+
+
+def test_zero_stretch_skip_of_band_limited_columns(ctx, monkeypatch):
+    """q24 plans do not load the 64-point blocks of a spectrum column that the whitening band leaves zero in EVERY
+    column (xcx_plan_zero_skip; template parameter ZB0 of the column body): every instantiated range of every column
+    length is reached through a band chosen for it, the plan reports the range the restatement above expects, and the
+    results meet the oracle like float2 storage (whose kernel loads everything) does -- the skipped products are
+    0 * x, so nothing but the q24 rounding may differ."""
+    rng = np.random.default_rng(5)
+    seen = set()
+    cases = [(180000, (50., .1, f, .05)) for f in (5.9, 10., 14., 18.5, 24.)] + \
+            [(120000, (50., .1, f, .05)) for f in (5., 11., 17.)] + \
+            [(90000, (50., .1, f, .05)) for f in (7., 11., 15.)] + \
+            [(60000, (50., .1, f, .05)) for f in (5., 11.)]
+    for n, band in cases:
+        S, W, hop = 3, 2, n // 2
+        tr = rng.standard_normal((S, hop * (W - 1) + n)).astype(np.float32)
+        pairs = np.array([(0, 1), (1, 2), (2, 2)], np.int32)
+        res = {}
+        for ts in ('f32', 'q24'):
+            monkeypatch.setenv('XCX_T_STORAGE', ts)
+            plan = X.CCPlan(ctx, n, whiten=band, onebit=True, demean=True)
+            N, N1 = plan.N, plan.N1
+            zs = plan.zero_skip
+            if ts == 'f32':
+                assert zs[0] == 0
+            else:
+                band_hi = int(np.floor((band[2] + band[3]) * N / band[0]))      # the last bin the gain can be non-zero in
+                assert zs == (_zskip_expected(N, N1, band_hi), N1 // 64), (n, band, zs)
+                seen.add((N1, zs[0]))
+            res[ts] = np.asarray(plan.pairs(tr, pairs, W, hop), np.float64)
+            plan.close()
+        g = R.whiten_weights(N, *band)
+        ref = R.cc_pairs(tr, pairs, n, hop, dtype=np.float64, whiten=g, nfft=N, onebit_=True, demean_=True)
+        for p in range(len(pairs)):
+            for w in range(W):
+                m = np.abs(ref[p, w]).max()
+                assert np.abs(res['q24'][p, w] - ref[p, w]).max() / m < TOL, (n, band, p, w)
+                assert np.abs(res['q24'][p, w] - res['f32'][p, w]).max() / m < 2.5e-6, (n, band, p, w)
+    monkeypatch.delenv('XCX_T_STORAGE')
+    # every instantiated range was exercised (and a band too wide for any: the generic kernel)
+    assert {(1536, 3), (1536, 5), (1536, 7), (1536, 9), (1536, 0), (1024, 2), (1024, 4), (1024, 6),
+            (768, 2), (768, 3), (768, 4), (512, 1), (512, 2)} <= seen, sorted(seen)
+
+
 def test_stack_finish_reduce_in_the_frequency_domain(ctx, monkeypatch):
     """configs[3] across ranks (xcx_cc1d_stack_finish_reduce): the ranks' cross-spectrum accumulators are summed with
     one reduce-scatter of their IN-BAND elements and every rank inverse-transforms only its share of the pairs.

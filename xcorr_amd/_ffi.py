@@ -38,6 +38,7 @@ SIGNATURES = {
     'xcx_limits': [C.POINTER(C.c_long), _i],
     'xcx_plan_geometry': [C.c_longlong, _i, _pi],
     'xcx_plan_t_storage': [_vp, _pi],
+    'xcx_plan_zero_skip': [_vp, _pi],
     'xcx_plan_fused_list': [_pi, _i, _pi],
     'xcx_init': [_i, C.POINTER(_vp)],
     'xcx_destroy': [_vp],

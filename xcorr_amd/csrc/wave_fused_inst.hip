@@ -13,6 +13,20 @@ static_assert(RXC::L == XCX_FC_L && RXR::L == XCX_FR_L, "radices do not multiply
 #define XCX_CAT3_(a, b, c, d) a##b##c##d
 #define XCX_CAT3(a, b, c, d) XCX_CAT3_(a, b, c, d)
 
+// q24 launch with the zero-stretch skip a.zb0 (one of ZSkipList<N1>::v)
+template <int I> static bool launch_zskip(const WDualArgs& a, dim3 grid, size_t lds, hipStream_t s) {
+  using ZL = ZSkipList<RXC::L>;
+  if constexpr (I < ZL::n) {
+    if (a.zb0 == ZL::v[I]) {
+      hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, 0, 1, ZL::v[I]>), grid, dim3(kWNT * kWPB), lds, s, a);
+      return true;
+    }
+    return launch_zskip<I + 1>(a, grid, lds, s);
+  } else {
+    return false;
+  }
+}
+
 hipError_t XCX_CAT3(launch_wdual_, XCX_FC_L, _, XCX_FR_L)(const WDualArgs& a, hipStream_t s) {
   using PG = PairGeom<RXC, RXR>;
   constexpr size_t lds = sizeof(float) * PG::kLdsFloats;
@@ -22,7 +36,8 @@ hipError_t XCX_CAT3(launch_wdual_, XCX_FC_L, _, XCX_FR_L)(const WDualArgs& a, hi
     // q24 storage of T: plain pair products of whitened spectra only (the bound behind the fixed-point scale)
     if constexpr (DualQ24<RXC, RXR>::ok) {
       if (a.nstack != 1) return hipErrorInvalidValue;
-      hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, 0, 1>), grid, dim3(kWNT * kWPB), lds, s, a);
+      if (a.zb0 == 0) hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, 0, 1>), grid, dim3(kWNT * kWPB), lds, s, a);
+      else if (!launch_zskip<0>(a, grid, lds, s)) return hipErrorInvalidValue;
       return hipGetLastError();
     } else {
       return hipErrorInvalidValue;
@@ -38,6 +53,7 @@ hipError_t XCX_CAT3(launch_wdual_, XCX_FC_L, _, XCX_FR_L)(const WDualArgs& a, hi
 }
 
 int XCX_CAT3(wdual_q24_, XCX_FC_L, _, XCX_FR_L)() { return DualQ24<RXC, RXR>::ok ? 1 : 0; }
+int XCX_CAT3(wdual_zskip_, XCX_FC_L, _, XCX_FR_L)(const Geom& g) { return DualQ24<RXC, RXR>::ok ? zskip_pick<RXC::L>(g) : 0; }
 
 hipError_t XCX_CAT3(launch_wflow_, XCX_FC_L, _, XCX_FR_L)(const WFlowArgs& a, hipStream_t s) {
   using PG = PairGeom<RXC, RXR>;

@@ -514,7 +514,13 @@ template <class RX> struct ColPairStore {
   using CG = ColGeom<RX>;
   static constexpr bool ok = ColRot<RX>::ok && (CG::RL % 2 == 0) && (CG::Last::IT == 1) && (CG::NSL == kTR);
 };
-template <class RX, int MODE, int TS = 0>
+// ZB0 > 0 (band-limited plans, MODE 0): the 64-point blocks ZB0 .. N1/64 - 1 - ZB0 of EVERY column lie inside the
+// zero stretch (zskip_blocks() below; chosen by the plan from its band), so a wave instruction whose points all fall
+// into those blocks is not issued at all -- its lane offset is a compile-time constant after unrolling, the test
+// folds away and the butterflies that follow see literal zeros.  With ZB0 = 0 such loads go to the zero chunk (L1 hits
+// that still cost a register pair and a slot in the memory pipeline each): 14 of the 24 blocks of a 0.1-10 Hz column
+// at 50 Hz, +3.7 % on the headline (profiles/r05_session2_notes.txt).
+template <class RX, int MODE, int TS = 0, int ZB0 = 0>
 XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_t spec_pitch,
                            const PwDesc d, int nstack, int k2, cf* __restrict__ T,
                            const cf* __restrict__ tw_sub, const cf* __restrict__ twN, const Geom& g XCX_ST_PARAM,
@@ -567,7 +573,12 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
     const bool uz = zok && kb >= za && kb + span - 1 <= zb;       // wave-uniform
     return uz ? base + (zev - kb) : base;
   };
+  static_assert(ZB0 == 0 || MODE == 0, "the zero stretch is skipped for plain pair products only");
+  constexpr int kZLo = ZB0 * kWNT, kZHi = N1 - ZB0 * kWNT - 1;           // elements [kZLo, kZHi] are zero in every column
   auto in = [=](int k1, int kb) -> cf {
+    if constexpr (ZB0 > 0) {
+      if (kb >= kZLo && kb + kWNT - 1 <= kZHi) return make_float2(0.f, 0.f);      // folds at compile time
+    }
     if constexpr (MODE == 1) {
       // exactly two windows per station (the chirp convolutions of fftn.hip), four loads and no loop: as a
       // loop over nstack windows every call waited for its own loads -- 24 serial round trips per wave
@@ -650,6 +661,9 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
   if constexpr (MODE != 1) {
     auto in2 = [=](int k1, cf& ra, cf& rb, int kb) {
       typedef float f32x4 __attribute__((ext_vector_type(4)));
+      if constexpr (ZB0 > 0) {
+        if (kb >= kZLo && kb + 2 * kWNT - 1 <= kZHi) { ra = rb = make_float2(0.f, 0.f); return; }
+      }
       const f32x4 qa = *reinterpret_cast<const f32x4*>(uoff(zbase(A, kb, 2 * kWNT), (unsigned)k1));
       if constexpr (MODE == 2) {
         ra = make_float2(qa.x, qa.y); rb = make_float2(qa.z, qa.w);
@@ -998,10 +1012,42 @@ struct WDualArgs {
   Geom g;
   int ts;                          // T storage: 0 float2, 1 q24 (whitened plans; tq = fixed-point scale, tqi = 1 / tq)
   float tq, tqi;
+  int zb0;                         // q24 launches: instantiated ZB0 of the column body (0: none), from zskip_pick()
 #ifdef XCX_STAMPS
   unsigned long long* stamps;      // [waves of the launch][kNStamp] or null
 #endif
 };
+// Zero-stretch skipping (template parameter ZB0 of the column body): the instantiated values per column length, in
+// 64-point blocks, and the choice for a plan.  A band [0, band_hi] of an N-point spectrum leaves the blocks
+// first .. last of every column k2 = 0 .. N2h inside the zero stretch; the largest instantiated symmetric range
+// ZB0 .. N1/64 - 1 - ZB0 inside first .. last is taken (0: none fits, the generic kernel runs).
+template <int N1> struct ZSkipList { static constexpr int n = 0; static constexpr int v[1] = {0}; };
+template <> struct ZSkipList<1536> { static constexpr int n = 4; static constexpr int v[4] = {3, 5, 7, 9}; };
+template <> struct ZSkipList<1024> { static constexpr int n = 3; static constexpr int v[3] = {2, 4, 6}; };
+template <> struct ZSkipList<768> { static constexpr int n = 3; static constexpr int v[3] = {2, 3, 4}; };
+template <> struct ZSkipList<512> { static constexpr int n = 2; static constexpr int v[2] = {1, 2}; };
+inline int zskip_need(const Geom& g) {
+  // smallest ZB0 whose range lies inside the zero stretch of every column; 0: there is none
+  if (g.band_hi >= g.N) return 0;
+  int za_max = 0, zb_min = g.N1;
+  for (int k2 = 0; k2 <= g.N2h; ++k2) {
+    const int za = (g.band_hi >= k2) ? (g.band_hi - k2) / g.N2 + 1 : 0;
+    const int zb = (g.N - g.band_hi - k2 + g.N2 - 1) / g.N2 - 1;
+    za_max = za > za_max ? za : za_max;
+    zb_min = zb < zb_min ? zb : zb_min;
+  }
+  const int nb = g.N1 / kWNT;
+  const int first = (za_max + kWNT - 1) / kWNT, last = (zb_min + 1) / kWNT - 1;
+  const int need = first > nb - 1 - last ? first : nb - 1 - last;
+  return (need >= 1 && 2 * need < nb) ? need : 0;
+}
+template <int N1> inline int zskip_pick(const Geom& g) {
+  const int need = zskip_need(g);
+  if (need == 0) return 0;
+  for (int i = 0; i < ZSkipList<N1>::n; ++i)
+    if (ZSkipList<N1>::v[i] >= need && 2 * ZSkipList<N1>::v[i] < N1 / kWNT) return ZSkipList<N1>::v[i];
+  return 0;
+}
 // q24 storage exists for the N1 whose column wave stores lane pairs (any row length)
 template <class RXC, class RXR> struct DualQ24 {
   static constexpr bool ok = ColPairStore<RXC>::ok;
@@ -1032,7 +1078,7 @@ template <class RXC, class RXR> struct PairGeom {
   static_assert(N1 % kTR == 0, "column lengths are multiples of 64");
 };
 
-template <class RXC, class RXR, int MODE, int TS = 0>
+template <class RXC, class RXR, int MODE, int TS = 0, int ZB0 = 0>
 __global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(XCX_DUAL_WAVES, XCX_DUAL_WAVES)))
 void k_wpair_dual(WDualArgs a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
@@ -1072,7 +1118,7 @@ void k_wpair_dual(WDualArgs a) {
     if (ci >= per || item >= (N2h + 1) * a.Bc) return;
     const int k2 = item / a.Bc;
     const int pwl = item - k2 * a.Bc;
-    pair_col_body<RXC, MODE, TS>(lds, a.X, a.spec_pitch, a.pw_c[pwl], a.nstack, k2,
+    pair_col_body<RXC, MODE, TS, ZB0>(lds, a.X, a.spec_pitch, a.pw_c[pwl], a.nstack, k2,
                                   a.Tc + (size_t)pwl * N1 * (N2h + 1), a.tw_N1, a.tw_N, g XCX_ST_ARG, a.tq);
   } else {
     const int ri = grp * PG::RWX + (pos - PG::CWX);

@@ -22,6 +22,7 @@ XCX_WROW_LIST(XCX_DECL_WROW)
 #define XCX_DECL_WFUSED(C, R) \
   hipError_t launch_wdual_##C##_##R(const WDualArgs& a, hipStream_t s);              \
   int wdual_q24_##C##_##R();                                                         \
+  int wdual_zskip_##C##_##R(const Geom& g);                                          \
   hipError_t launch_wflow_##C##_##R(const WFlowArgs& a, hipStream_t s);
 XCX_WFUSED_LIST(XCX_DECL_WFUSED)
 struct WFusedEntry {
@@ -29,6 +30,7 @@ struct WFusedEntry {
   hipError_t (*dual)(const WDualArgs&, hipStream_t);
   hipError_t (*flow)(const WFlowArgs&, hipStream_t);
   int (*q24)();      // 1: the dual kernel has a q24 (24-bit fixed-point T) instantiation
+  int (*zskip)(const Geom&);   // instantiated zero-stretch skip (ZB0 of the column body) for a plan's band, 0: none
 };
 
 struct WColEntry {

@@ -48,7 +48,7 @@ static const WColEntry kWCols[] = {XCX_WCOL_LIST(XCX_WCOL_ROW)};
 static const WRowEntry kWRows[] = {XCX_WROW_LIST(XCX_WROW_ROW)};
 static const int kNWCols = sizeof(kWCols) / sizeof(kWCols[0]);
 static const int kNWRows = sizeof(kWRows) / sizeof(kWRows[0]);
-#define XCX_WFUSED_ROW(C, R) {C, R, launch_wdual_##C##_##R, launch_wflow_##C##_##R, wdual_q24_##C##_##R},
+#define XCX_WFUSED_ROW(C, R) {C, R, launch_wdual_##C##_##R, launch_wflow_##C##_##R, wdual_q24_##C##_##R, wdual_zskip_##C##_##R},
 static const WFusedEntry kWFused[] = {XCX_WFUSED_LIST(XCX_WFUSED_ROW)};
 static const int kNWFused = sizeof(kWFused) / sizeof(kWFused[0]);
 // default T storage of whitened plans: q24 after the error table of profiles/r05_t24_error_table.txt
@@ -682,6 +682,17 @@ extern "C" int xcx_plan_t_storage(xcx_plan* p, int* ts) {
   return XCX_OK;
 }
 
+extern "C" int xcx_plan_zero_skip(xcx_plan* p, int* out2) {
+  if (!p || !out2) return set_err(XCX_EINVAL, "null argument");
+  const xcx_plan* q = (p->seg && p->seg->sub) ? p->seg->sub : p;
+  int ts = 0;
+  (void)xcx_plan_t_storage(p, &ts);
+  static const bool zs = !(getenv("XCX_ZSKIP") && atoi(getenv("XCX_ZSKIP")) == 0);
+  out2[0] = (ts && zs && q->dual && q->dual->zskip) ? q->dual->zskip(q->g) : 0;
+  out2[1] = q->g.N1 / kWNT;
+  return XCX_OK;
+}
+
 extern "C" int xcx_plan_counters(xcx_plan* p, long long* launches, long long* pw) {
   if (!p) return set_err(XCX_EINVAL, "null plan");
   if (launches) *launches = p->launches;
@@ -877,6 +888,7 @@ static int dual_launch(xcx_plan* p, int chain, size_t d0, int Bc, int nstack, fl
   // -- decided ONCE per run (dual_run): the launch that drains a pipeline carries nstack = 1 whatever the run was
   a.ts = p->run_ts;
   a.tq = p->tq; a.tqi = p->tqi;
+  a.zb0 = p->run_ts ? p->run_zb0 : 0;
   if (Bc == 0 && a.Br == 0) return XCX_OK;
 #ifdef XCX_STAMPS
   {
@@ -928,6 +940,12 @@ static int dual_run(xcx_plan* p, size_t first, size_t count, int nstack, float* 
     ch.B = 0;
   }
   p->run_ts = (p->t_q24 && nstack == 1 && !Xsrc && (p->g.flags & XCX_F_WHITEN) && !(p->g.flags & XCX_F_STACK) && p->whiten_set) ? 1 : 0;
+  {
+    // q24 runs read the plan's own band-limited spectra: the column waves do not issue the loads of the blocks that
+    // are zero in every column (XCX_ZSKIP=0: the generic kernel, for A/B)
+    static const bool zs = !(getenv("XCX_ZSKIP") && atoi(getenv("XCX_ZSKIP")) == 0);
+    p->run_zb0 = (p->run_ts && zs && p->dual->zskip) ? p->dual->zskip(p->g) : 0;
+  }
   if (!p->ev_fwd) HIP_TRY(hipEventCreateWithFlags(&p->ev_fwd, hipEventDisableTiming));
   // wall time of the whole pair phase on the main stream (the pipelines overlap,
   // so per-launch durations do not add up)

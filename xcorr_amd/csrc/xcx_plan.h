@@ -82,6 +82,7 @@ struct xcx_plan {
   float tq = 0.f, tqi = 0.f;
   bool t_q24 = false;        // the dual launches of plain pair products store T as 2 x 24 bits
   int run_ts = 0;            // T storage of the dual_run in progress (every launch of a run agrees, the draining ones too)
+  int run_zb0 = 0;           // ... and its zero-stretch skip (ZB0 of the column body, wave_kernels.h; 0: none)
   // tables
   DevBuf tw_N1, tw_N2h, tw_unt, tw_N;
   // workspaces

@@ -420,6 +420,14 @@ class CCPlan:
         check(_ffi.lib().xcx_plan_t_storage(self.handle, C.byref(ts)))
         return 'q24' if ts.value == 1 else 'f32'
 
+    @property
+    def zero_skip(self):
+        """(first, count): the 64-point blocks first .. count - 1 - first of every spectrum column that the pair pass's
+        column kernel knows to be zero and does not load (band-limited q24 plans); first = 0: none."""
+        o = (C.c_int * 2)()
+        check(_ffi.lib().xcx_plan_zero_skip(self.handle, o))
+        return int(o[0]), int(o[1])
+
     def counters(self):
         a, b = C.c_longlong(), C.c_longlong()
         check(_ffi.lib().xcx_plan_counters(self.handle, C.byref(a), C.byref(b)))
