@@ -570,5 +570,14 @@ XCX_DEV cf twN_lookup(const cf* __restrict__ tab, unsigned q) {
   const cf hi = *uoff(tab, kTwQL + (q >> 9));
   return cmul(lo, hi);
 }
+// the same for a WAVE-UNIFORM q (the caller guarantees it): two scalar loads through the constant address space
+// instead of two vector loads that would fetch one value sixty-four times
+XCX_DEV cf twN_lookup_uniform(const cf* __restrict__ tab, unsigned q) {
+  typedef const __attribute__((address_space(4))) float cfloat;
+  const unsigned qs = (unsigned)__builtin_amdgcn_readfirstlane((int)q);
+  cfloat* lo = (cfloat*)(const float*)uoff(tab, qs & (kTwQL - 1));
+  cfloat* hi = (cfloat*)(const float*)uoff(tab, kTwQL + (qs >> 9));
+  return cmul(make_float2(lo[0], lo[1]), make_float2(hi[0], hi[1]));
+}
 
 }  // namespace xcx

@@ -554,7 +554,7 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
     f0[it] = twN_lookup(twN, (unsigned)((j - k) * CG::RL + k) * kk);
     if constexpr (TS == 1) f0[it] = cscale(f0[it], tq);         // the four-step factor carries the fixed-point scale
   }
-  const cf gstep = twN_lookup(twN, (unsigned)CG::NSL * kk);
+  const cf gstep = twN_lookup_uniform(twN, (unsigned)CG::NSL * kk);      // k2 is wave-uniform: two scalar loads
   // Band-limited spectra (whitened plans, Geom::band_hi): column k2 is exactly zero for k1 in [za, zb],
   // i.e. where both k = k1 N2 + k2 and N - k lie above the band (60 % of a 0.1-10 Hz band at 50 Hz).
   // A wave instruction whose points ALL fall inside that range (kb .. kb + span - 1, kb = lane 0's point,

@@ -789,7 +789,7 @@ static int forward(xcx_plan* p, const float* traces, long stride_s, long stride_
     f1.g = g;
     if (n_valid > 0) f1.g.n = n_valid;
     // a launch whose Tf (written here, read back by the column pass) is beyond what stays cache-resident streams
-    static const int nt_env = getenv("XCX_FWD_NT") ? atoi(getenv("XCX_FWD_NT")) : -1;    // A/B: 0 never, 1 always
+    const int nt_env = getenv("XCX_FWD_NT") ? atoi(getenv("XCX_FWD_NT")) : -1;    // A/B and tests (read per call): 0 never, 1 always
     const int nt = nt_env >= 0 ? (nt_env != 0) : (sizeof(cf) * tf_per * (size_t)cnt >= kFwdNtBytes);
     f1.nt = nt;
     {
