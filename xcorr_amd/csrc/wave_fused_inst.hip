@@ -18,14 +18,6 @@ template <int I> static bool launch_zskip(const WDualArgs& a, dim3 grid, size_t 
   using ZL = ZSkipList<RXC::L>;
   if constexpr (I < ZL::n) {
     if (a.zb0 == ZL::v[I]) {
-#if !defined(XCX_STAMPS)
-      if constexpr (RXC::S == 3) {
-        if (a.x2) {
-          hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, 0, 1, ZL::v[I], 2>), grid, dim3(kWNT * kWPB), lds, s, a);
-          return true;
-        }
-      }
-#endif
       hipLaunchKernelGGL((k_wpair_dual<RXC, RXR, 0, 1, ZL::v[I]>), grid, dim3(kWNT * kWPB), lds, s, a);
       return true;
     }

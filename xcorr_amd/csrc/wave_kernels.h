@@ -161,81 +161,12 @@ template <class RX> struct ColRot {
 // Used for the first 2 x 64 butterflies of stage 0 when the column has at least that many
 // (lane l takes butterflies 2l and 2l+1); see pair_src_index.
 struct NoIn2 {};
-template <class RX, class In2> struct ColWide {
-  static constexpr bool value = !std::is_same<In2, NoIn2>::value && (StageGeom<RX::L, RX::R0, 1, 1, kWNT>::NBF % kWNT == 0) &&
-                                (StageGeom<RX::L, RX::R0, 1, 1, kWNT>::IT >= 2);
-};
-// the INPUTS of the first stage alone, in the register layout wave_col_fft uses (no butterflies): the two-item column
-// body issues the loads of both its items through this before it transforms the first one (wave_col_fft_v)
-template <class RX, class In, class In2>
-XCX_DEV void wave_col_inputs(In in, In2 in2, cf (&v0)[StageGeom<RX::L, RX::R0, 1, 1, kWNT>::IT][RX::R0]) {
-  constexpr int L = RX::L, R0 = RX::R0;
-  using G0 = StageGeom<L, R0, 1, 1, kWNT>;
-  if constexpr (ColWide<RX, In2>::value) {
-#pragma unroll
-    for (int t = 0; t < R0; ++t) in2(2 * tid_of<kWNT>() + t * (L / R0), v0[0][t], v0[1][t], t * (L / R0));
-#pragma unroll
-    for (int it = 2; it < G0::IT; ++it) {
-      const int j = tid_of<kWNT>() + it * kWNT;
-#pragma unroll
-      for (int t = 0; t < R0; ++t) v0[it][t] = in(j + t * (L / R0), it * kWNT + t * (L / R0));
-    }
-  } else {
-#pragma unroll
-    for (int it = 0; it < G0::IT; ++it) {
-      const int j = tid_of<kWNT>() + it * kWNT;
-      if (!G0::GUARD || j < G0::NBF) {
-#pragma unroll
-        for (int t = 0; t < R0; ++t) v0[it][t] = in(j + t * (L / R0), it * kWNT + t * (L / R0));
-      } else {
-#pragma unroll
-        for (int t = 0; t < R0; ++t) v0[it][t] = make_float2(0.f, 0.f);
-      }
-    }
-  }
-}
-// ... and the transform of inputs that are already in registers (WIDE0: they came through in2's lane mapping)
-// `mid()` runs between the first exchange and the second stage, where the register pressure is lowest
-struct NoMid { XCX_DEV void operator()() const {} };
-template <class RX, bool INV, bool WIDE0, class Epi, class Mid = NoMid>
-XCX_DEV void wave_col_fft_v(cf* __restrict__ lds, const cf* __restrict__ tw,
-                            cf (&v0)[StageGeom<RX::L, RX::R0, 1, 1, kWNT>::IT][RX::R0], Epi epi, int ltid, Mid mid = Mid()) {
-  constexpr int L = RX::L;
-  constexpr int R0 = RX::R0, R1 = RX::R1, R2 = RX::R2;
-  static_assert(RX::S == 3, "the two-item column body exists for the three-stage columns");
-  float* __restrict__ ldsf = reinterpret_cast<float*>(lds);
-  using G0 = StageGeom<L, R0, 1, 1, kWNT>;
-  using G1 = StageGeom<L, R1, R0, 1, kWNT>;
-  using G2 = StageGeom<L, R2, R0 * R1, 1, kWNT>;
-  cf b1[G1::IT], b2[G2::IT];
-  stage_tw_base<L, R1, R0, 1, kWNT>(tw, b1, tid_of<kWNT>());
-  stage_tw_base<L, R2, R0 * R1, 1, kWNT>(tw, b2, ltid);
-#pragma unroll
-  for (int it = 0; it < G0::IT; ++it) {
-    const int j = tid_of<kWNT>() + it * kWNT;
-    if (!G0::GUARD || j < G0::NBF) Bfly<R0, INV>::run(v0[it]);
-  }
-  cf v1[G1::IT][R1];
-  stage_exchange_pad8<L, R0, 1, R1, kWNT, WIDE0>(ldsf, v0, v1);
-  mid();
-  stage_compute<L, R1, R0, 1, kWNT, INV>(v1, b1);
-  cf v2[G2::IT][R2];
-  stage_exchange_pad8<L, R1, R0, R2, kWNT>(ldsf, v1, v2, ltid);
-  stage_compute<L, R2, R0 * R1, 1, kWNT, INV>(v2, b2);
-#pragma unroll
-  for (int it = 0; it < G2::IT; ++it) {
-    const int j = ltid + it * kWNT;
-    if (!G2::GUARD || j < G2::NBF) {
-      const int k = j % (R0 * R1);
-      epi(it, (j - k) * R2 + k, 0, v2[it]);
-    }
-  }
-}
 template <class RX, bool INV, class In, class Epi, class In2 = NoIn2>
 XCX_DEV void wave_col_fft(cf* __restrict__ lds, const cf* __restrict__ tw, In in, Epi epi, int ltid XCX_ST_PARAM, In2 in2 = In2()) {
   constexpr int L = RX::L;
   constexpr int R0 = RX::R0, R1 = RX::R1, R2 = RX::R2;
-  constexpr bool WIDE0 = ColWide<RX, In2>::value;
+  constexpr bool WIDE0 = !std::is_same<In2, NoIn2>::value && (StageGeom<L, R0, 1, 1, kWNT>::NBF % kWNT == 0) &&
+                         (StageGeom<L, R0, 1, 1, kWNT>::IT >= 2);
   static_assert(RX::S == 2 || RX::S == 3, "column configs have two or three stages");
   float* __restrict__ ldsf = reinterpret_cast<float*>(lds);
   using G0 = StageGeom<L, R0, 1, 1, kWNT>;
@@ -589,16 +520,11 @@ template <class RX> struct ColPairStore {
 // folds away and the butterflies that follow see literal zeros.  With ZB0 = 0 such loads go to the zero chunk (L1 hits
 // that still cost a register pair and a slot in the memory pipeline each): 14 of the 24 blocks of a 0.1-10 Hz column
 // at 50 Hz, +3.7 % on the headline (profiles/r05_session2_notes.txt).
-// NI = 2 (zero-skip kernels, round 5): the wave takes TWO pair-windows of its column, (d, T) and (d1, T1; `has1`), and
-// issues the spectrum loads of both before it transforms the first -- the second item's loads are in flight under the
-// first item's transform, and the column's twiddles are fetched once.  A diagnostic build without any spectrum loads
-// ran 24 % faster (profiles/r05_session2_notes.txt): the L2-hit loads at the head of every column wave are worth
-// hiding, and since the zero-stretch skip an item's loads hold 44 VGPRs instead of 96.
-template <class RX, int MODE, int TS = 0, int ZB0 = 0, int NI = 1>
+template <class RX, int MODE, int TS = 0, int ZB0 = 0>
 XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_t spec_pitch,
                            const PwDesc d, int nstack, int k2, cf* __restrict__ T,
                            const cf* __restrict__ tw_sub, const cf* __restrict__ twN, const Geom& g XCX_ST_PARAM,
-                           float tq = 0.f, const PwDesc d1 = PwDesc(), cf* __restrict__ T1 = nullptr, bool has1 = false) {
+                           float tq = 0.f) {
   constexpr int N1 = RX::L;
   const int N2h = g.N2h;
   const cf* __restrict__ A = X + (size_t)d.slot_a * spec_pitch + (size_t)k2 * N1;
@@ -665,12 +591,11 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
     }
   };
   constexpr int TC = t_chunk(N1);
-  cf* Tcur = T;                                // the item the epilogue stores (NI = 2: switched between the two)
+  cf* __restrict__ Tc = T + k2 * TC;
   const int crow = (N2h + 1) * TC;            // float2 per chunk of TC rows
   // Pair stores: every lane ends up with two adjacent rows and stores 16 bytes; lanes 0..31 cover one
   // 64-row half chunk, lanes 32..63 the next one, in lane order.
-  auto epi = [&](int it, int j0, int, cf (&v)[CG::RL]) {
-    cf* __restrict__ Tc = Tcur + k2 * TC;
+  auto epi = [=](int it, int j0, int, cf (&v)[CG::RL]) {
     cf g8 = gstep, f = f0[it];
     if constexpr (CG::RL > 8) g8 = csq(csq(csq(gstep)));
     static_for<CG::RL>([&](auto tc) {                                 // four-step factors, in place
@@ -715,7 +640,7 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
           typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
           unsigned q[3];
           q24_pack(sx[0], sy[0], sx[1], sy[1], q);
-          char* tb = reinterpret_cast<char*>(Tcur) + (size_t)((unsigned)(k2 * TC) * 6u);
+          char* tb = reinterpret_cast<char*>(T) + (size_t)((unsigned)(k2 * TC) * 6u);
           *reinterpret_cast<u32x3*>(tb + (size_t)(o * 6u)) = u32x3{q[0], q[1], q[2]};
         } else {
           *reinterpret_cast<float4*>(uoff(Tc, o)) =
@@ -732,50 +657,6 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
     }
   };
 #if !defined(XCX_STAMPS)
-  if constexpr (NI == 2) {
-    static_assert(MODE == 0 && ZB0 > 0, "two items per column wave: zero-skip kernels of plain pair products");
-    using G0 = StageGeom<N1, RX::R0, 1, 1, kWNT>;
-    typedef float f32x4 __attribute__((ext_vector_type(4)));
-    // raw loads of ONE spectrum column (no product yet): the same lane mapping and skip tests as in / in2 below
-    auto raw = [&](const cf* __restrict__ col, cf (&v)[G0::IT][RX::R0]) {
-      auto ld1 = [=](int k1, int kb) -> cf {
-        if (kb >= kZLo && kb + kWNT - 1 <= kZHi) return make_float2(0.f, 0.f);
-        return *uoff(zbase(col, kb, kWNT), (unsigned)k1);
-      };
-      auto ld2 = [=](int k1, cf& ra, cf& rb, int kb) {
-        if (kb >= kZLo && kb + 2 * kWNT - 1 <= kZHi) { ra = rb = make_float2(0.f, 0.f); return; }
-        const f32x4 q = *reinterpret_cast<const f32x4*>(uoff(zbase(col, kb, 2 * kWNT), (unsigned)k1));
-        ra = make_float2(q.x, q.y); rb = make_float2(q.z, q.w);
-      };
-      wave_col_inputs<RX>(ld1, ld2, v);
-    };
-    constexpr bool WIDE0 = ColWide<RX, int>::value;          // any In2 other than NoIn2
-    // the second item of a wave without one (odd batch) re-reads the first item's columns and stores nothing
-    const cf* __restrict__ A1 = has1 ? X + (size_t)d1.slot_a * spec_pitch + (size_t)k2 * N1 : A;
-    const cf* __restrict__ B1 = has1 ? X + (size_t)d1.slot_b * spec_pitch + (size_t)k2 * N1 : Bp;
-    cf a0[G0::IT][RX::R0], b0[G0::IT][RX::R0], a1[G0::IT][RX::R0], b1[G0::IT][RX::R0];
-    raw(A, a0); raw(Bp, b0);
-    raw(A1, a1); raw(B1, b1);                                  // in flight under the first transform
-    cf v[G0::IT][RX::R0], p1[G0::IT][RX::R0];
-#pragma unroll
-    for (int it = 0; it < G0::IT; ++it)
-#pragma unroll
-      for (int t = 0; t < RX::R0; ++t) v[it][t] = cmulc(a0[it][t], b0[it][t]);
-    // the second item's products are formed in the middle of the first transform (its loads have had a stage and an
-    // LDS exchange to arrive; 44 registers of loaded values become 22 of products before the register-hungry last stage)
-    auto mid = [&]() {
-#pragma unroll
-      for (int it = 0; it < G0::IT; ++it)
-#pragma unroll
-        for (int t = 0; t < RX::R0; ++t) p1[it][t] = cmulc(a1[it][t], b1[it][t]);
-    };
-    wave_col_fft_v<RX, true, WIDE0>(lds, tw_sub, v, epi, ltid, mid);
-    if (has1) {                                                 // wave-uniform
-      Tcur = T1;
-      wave_col_fft_v<RX, true, WIDE0>(lds, tw_sub, p1, epi, ltid);
-    }
-    return;
-  }
   // 16-byte spectrum loads for the first 2 x 64 butterflies (+0.9 %, profiles/r02_ablation.txt)
   if constexpr (MODE != 1) {
     auto in2 = [=](int k1, cf& ra, cf& rb, int kb) {
@@ -1132,7 +1013,6 @@ struct WDualArgs {
   int ts;                          // T storage: 0 float2, 1 q24 (whitened plans; tq = fixed-point scale, tqi = 1 / tq)
   float tq, tqi;
   int zb0;                         // q24 launches: instantiated ZB0 of the column body (0: none), from zskip_pick()
-  int x2;                          // ... and two pair-windows per column wave (NI = 2; three-stage columns)
 #ifdef XCX_STAMPS
   unsigned long long* stamps;      // [waves of the launch][kNStamp] or null
 #endif
@@ -1198,7 +1078,7 @@ template <class RXC, class RXR> struct PairGeom {
   static_assert(N1 % kTR == 0, "column lengths are multiples of 64");
 };
 
-template <class RXC, class RXR, int MODE, int TS = 0, int ZB0 = 0, int NI = 1>
+template <class RXC, class RXR, int MODE, int TS = 0, int ZB0 = 0>
 __global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(XCX_DUAL_WAVES, XCX_DUAL_WAVES)))
 void k_wpair_dual(WDualArgs a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
@@ -1233,20 +1113,6 @@ void k_wpair_dual(WDualArgs a) {
     // pair-windows, so a station column is re-read from the XCD's L2) are cut into 8 EQUAL shares,
     // one per XCD label: with k2 = x mod 8, XCD 0 had 16 columns of 121 and the others 15
     const int ci = (grp * PG::CWX + pos) * kWPB + wave;
-    if constexpr (NI == 2) {
-      // items = (column, PAIR of consecutive pair-windows): half as many column waves, each with two transforms
-      const int B2 = (a.Bc + 1) >> 1;
-      const int per = ((N2h + 1) * B2 + 7) >> 3;
-      const int item = x * per + ci;
-      if (ci >= per || item >= (N2h + 1) * B2) return;
-      const int k2 = item / B2;
-      const int pwl = 2 * (item - k2 * B2);
-      const bool has1 = pwl + 1 < a.Bc;
-      pair_col_body<RXC, MODE, TS, ZB0, 2>(lds, a.X, a.spec_pitch, a.pw_c[pwl], a.nstack, k2,
-                                          a.Tc + (size_t)pwl * N1 * (N2h + 1), a.tw_N1, a.tw_N, g XCX_ST_ARG, a.tq,
-                                          a.pw_c[has1 ? pwl + 1 : pwl], a.Tc + (size_t)(pwl + 1) * N1 * (N2h + 1), has1);
-      return;
-    }
     const int per = ((N2h + 1) * a.Bc + 7) >> 3;
     const int item = x * per + ci;
     if (ci >= per || item >= (N2h + 1) * a.Bc) return;

@@ -889,10 +889,6 @@ static int dual_launch(xcx_plan* p, int chain, size_t d0, int Bc, int nstack, fl
   a.ts = p->run_ts;
   a.tq = p->tq; a.tqi = p->tqi;
   a.zb0 = p->run_ts ? p->run_zb0 : 0;
-  {
-    static const bool x2 = !(getenv("XCX_COL_X2") && atoi(getenv("XCX_COL_X2")) == 0);      // A/B: 0 = one item per column wave
-    a.x2 = (a.zb0 && x2) ? 1 : 0;
-  }
   if (Bc == 0 && a.Br == 0) return XCX_OK;
 #ifdef XCX_STAMPS
   {
