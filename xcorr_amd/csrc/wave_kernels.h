@@ -88,6 +88,19 @@ constexpr int lds_frow_floats(int L) { return L * 16 * 2; }
 // s_load (scalar cache) and the data loads take the saddr + 32-bit voffset form instead of
 // per-lane 64-bit addresses
 XCX_DEV int wave_in_group() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+// Pair-window descriptor `i` (wave-uniform index) through the CONSTANT address space: scalar loads.  The descriptors
+// are written by the host before the launch, but the kernels store through other pointers, so the compiler cannot prove
+// them unclobbered and loads them with a VECTOR instruction (all lanes one address) followed by v_readfirstlane -- a
+// round trip through the CU's congested vector-memory pipeline that the wave sat out before it could issue its first
+// spectrum load (generated code until round 5: global_load_dwordx2, s_waitcnt vmcnt, v_readfirstlane, then the loads).
+XCX_DEV PwDesc pw_desc(const PwDesc* __restrict__ base, int i) {
+  typedef const __attribute__((address_space(4))) int cint;
+  cint* p = (cint*)(const int*)(base + __builtin_amdgcn_readfirstlane(i));
+  PwDesc d;
+  d.slot_a = p[0]; d.slot_b = p[1];
+  d.out_off = (long long)(((unsigned long long)(unsigned)p[3] << 32) | (unsigned)p[2]);
+  return d;
+}
 
 // element offset of residue `res` inside a pair-window's T for k2 = 0 (add k2 * TC)
 XCX_DEV unsigned t_off(int res, int TC, int N2h) {
@@ -696,7 +709,7 @@ void k_wpair_cols(WI1Args a) {
 #ifdef XCX_STAMPS
   StampArr xst;
 #endif
-  pair_col_body<RX, MODE>(lds, a.X, a.spec_pitch, a.pw[pwl], a.nstack, k2,
+  pair_col_body<RX, MODE>(lds, a.X, a.spec_pitch, pw_desc(a.pw, pwl), a.nstack, k2,
                            a.T + (size_t)pwl * RX::L * (N2h + 1), a.tw_sub, a.tw_N, g XCX_ST_ARG);
 }
 
@@ -766,17 +779,22 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
   //   sm = h + conj g,  ed = e (h - conj g)
   //   U_j [t]     = sm + i ed
   //   U_j'[R-1-t] = conj(sm) + i conj(ed)      (because e_{N2h-k} = -conj e_k)
-  auto untangle = [&](int it, int j, bool single, cf (&av)[R], cf (&bv)[R], float ny) {
-    if (single) {
-      if (j == 0) {
+  auto untangle = [&](int it, int j, bool single, cf (&av)[R], cf (&bv)[R], float ny, cf ej) {
+    {
+      // selects, not branches: the optimiser sinks the mirror loads into the arm of a branch that needs them, and a
+      // load inside a branch waits alone
+      const bool m0 = single && j == 0, m1 = single && j != 0;
+      cf sel[R];
 #pragma unroll
-        for (int t = 0; t < R; ++t) bv[t] = av[(t + 1) % R];   // mirror of S*t' is S*(R-t')
-      } else {
-#pragma unroll
-        for (int t = 0; t < R; ++t) bv[t] = av[t];             // j = S/2 mirrors inside itself
+      for (int t = 0; t < R; ++t) {
+        const cf a0 = av[(t + 1) % R];                         // j = 0: mirror of S*t' is S*(R-t')
+        const cf a1 = av[t];                                   // j = S/2 mirrors inside itself
+        sel[t].x = m0 ? a0.x : (m1 ? a1.x : bv[t].x);
+        sel[t].y = m0 ? a0.y : (m1 ? a1.y : bv[t].y);
       }
+#pragma unroll
+      for (int t = 0; t < R; ++t) bv[t] = sel[t];
     }
-    const cf ej = cconj(*uoff(twu, (unsigned)j));
     cf uj[R], ujp[R];
     static_for<R>([&](auto tc) {
       constexpr int t = decltype(tc)::value;
@@ -791,13 +809,22 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
       uj[0] = make_float2(dc + ny, dc - ny);
     }
     Bfly<R, true>::run(uj);
-    if (!single) Bfly<R, true>::run(ujp);
+    Bfly<R, true>::run(ujp);        // also for `single` lanes (result unused): a branch here is where the optimiser sinks the mirror loads
     // Stockham positions of stage 0 (NS = 1): butterfly j -> j*R + t; real and
     // imaginary parts go through the half-size LDS buffer in two rounds below
 #pragma unroll
     for (int t = 0; t < R; ++t) { s0a[it][t] = uj[t]; s0b[it][t] = ujp[t]; }
   };
   {
+    // Every load of an item is issued without a branch in between, the untangle twiddles first (round 5).  Until then
+    // the mirror loads sat under `if (!single)`, the Nyquist load under `if (j == 0)` and the twiddle load inside the
+    // untangle: the generated code waited for the first loads before the branch, for the Nyquist load inside it and
+    // for the twiddle after it -- three to four dependent round trips through a congested memory pipeline per item.
+    // Lanes of a `single` butterfly (j = 0: its mirror is itself) now fetch the same rows twice inside the same
+    // instructions, every lane fetches the Nyquist bin of its row; the values are discarded where they do not apply.
+    cf ejs[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) ejs[it] = cconj(*uoff(twu, (unsigned)((lane + it * kWNT) / kWRB)));
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
       const int w = lane + it * kWNT;
@@ -824,21 +851,17 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
         };
 #pragma unroll
         for (int t = 0; t < R; ++t) av[t] = ld6(j + S * t);
-        if (!single) {
 #pragma unroll
-          for (int t = 0; t < R; ++t) bv[t] = ld6(jp + S * t);
-        }
-        if (j == 0) ny = ld6(N2h).x;
+        for (int t = 0; t < R; ++t) bv[t] = ld6(jp + S * t);
+        ny = ld6(N2h).x;
       } else {
 #pragma unroll
-      for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(uoff(Tt, (unsigned)((j + S * t) * TC + r)));
-      if (!single) {
+        for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(uoff(Tt, (unsigned)((j + S * t) * TC + r)));
 #pragma unroll
         for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(uoff(Tt, (unsigned)((jp + S * t) * TC + r)));
+        ny = load_t<SC1>(uoff(Tt, (unsigned)(N2h * TC + r))).x;
       }
-      if (j == 0) ny = load_t<SC1>(uoff(Tt, (unsigned)(N2h * TC + r))).x;
-      }
-      untangle(it, j, single, av, bv, ny);
+      untangle(it, j, single, av, bv, ny, ejs[it]);
     }
     XCX_STAMP(2, s0a[0][0].x);
   }
@@ -992,9 +1015,9 @@ void k_wpair_rows(WI2Args a) {
   StampArr xst;
 #endif
   if (g.flags & XCX_F_UNBIAS)
-    pair_row_body<RX, false, true>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, stg, g XCX_ST_ARG);
+    pair_row_body<RX, false, true>(lds, Tt, a.out + pw_desc(a.pw, pwl).out_off, blk, a.tw_sub, a.tw_unt, stg, g XCX_ST_ARG);
   else
-    pair_row_body<RX, false, false>(lds, Tt, a.out + a.pw[pwl].out_off, blk, a.tw_sub, a.tw_unt, stg, g XCX_ST_ARG);
+    pair_row_body<RX, false, false>(lds, Tt, a.out + pw_desc(a.pw, pwl).out_off, blk, a.tw_sub, a.tw_unt, stg, g XCX_ST_ARG);
 }
 
 // ---------------------------------------------------------------------------
@@ -1118,7 +1141,7 @@ void k_wpair_dual(WDualArgs a) {
     if (ci >= per || item >= (N2h + 1) * a.Bc) return;
     const int k2 = item / a.Bc;
     const int pwl = item - k2 * a.Bc;
-    pair_col_body<RXC, MODE, TS, ZB0>(lds, a.X, a.spec_pitch, a.pw_c[pwl], a.nstack, k2,
+    pair_col_body<RXC, MODE, TS, ZB0>(lds, a.X, a.spec_pitch, pw_desc(a.pw_c, pwl), a.nstack, k2,
                                   a.Tc + (size_t)pwl * N1 * (N2h + 1), a.tw_N1, a.tw_N, g XCX_ST_ARG, a.tq);
   } else {
     const int ri = grp * PG::RWX + (pos - PG::CWX);
@@ -1130,9 +1153,9 @@ void k_wpair_dual(WDualArgs a) {
         t_rows16_b<TS>(a.Tr + (size_t)pwl * N1 * (N2h + 1), blk, N2h, t_chunk(N1)));
     float* stg = reinterpret_cast<float*>(lds_all);
     if (g.flags & XCX_F_UNBIAS)
-      pair_row_body<RXR, false, true, t_chunk(N1), TS>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG, a.tqi);
+      pair_row_body<RXR, false, true, t_chunk(N1), TS>(lds, Tt, a.out + pw_desc(a.pw_r, pwl).out_off, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG, a.tqi);
     else
-      pair_row_body<RXR, false, false, t_chunk(N1), TS>(lds, Tt, a.out + a.pw_r[pwl].out_off, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG, a.tqi);
+      pair_row_body<RXR, false, false, t_chunk(N1), TS>(lds, Tt, a.out + pw_desc(a.pw_r, pwl).out_off, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG, a.tqi);
   }
 }
 
@@ -1240,7 +1263,7 @@ void k_wpair_flow(WFlowArgs a) {
       if (!flow_wait8(a.rdone + (size_t)bp * 8 * kFlowShardInts, tgt, a.err)) return;
     }
     cf* Tb = a.T + (size_t)(b % a.R) * B * N1 * (N2h + 1);
-    pair_col_body<RXC, MODE>(lds, a.X, a.spec_pitch, a.pw[b * B + pwl], a.nstack, k2,
+    pair_col_body<RXC, MODE>(lds, a.X, a.spec_pitch, pw_desc(a.pw, b * B + pwl), a.nstack, k2,
                               Tb + (size_t)pwl * N1 * (N2h + 1), a.tw_N1, a.tw_N, g XCX_ST_ARG);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // T stores acknowledged
     if (lane == 0)
@@ -1259,7 +1282,7 @@ void k_wpair_flow(WFlowArgs a) {
     const int ctgt = ncx * Br;
     if (!flow_wait8(a.cdone + (size_t)b * 8 * kFlowShardInts, ctgt, a.err)) return;
     const cf* __restrict__ Tt = t_rows16(a.T + ((size_t)(b % a.R) * B + pwl) * (size_t)N1 * (N2h + 1), blk, N2h, t_chunk(N1));
-    float* o = a.out + a.pw[b * B + pwl].out_off;
+    float* o = a.out + pw_desc(a.pw, b * B + pwl).out_off;
     float* stg = reinterpret_cast<float*>(lds_all);
     if (g.flags & XCX_F_UNBIAS)
       pair_row_body<RXR, true, true, t_chunk(N1)>(lds, Tt, o, blk, a.tw_N2h, a.tw_unt, stg, g XCX_ST_ARG);
