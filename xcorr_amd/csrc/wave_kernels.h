@@ -843,23 +843,51 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
         const unsigned sel_re = odd ? 0x0403020cu : 0x0201000cu;       // three bytes to the top of a dword, low byte 0
         const unsigned sel_im = odd ? 0x0706050cu : 0x0504030cu;
         const float qs = tqi * (1.f / 256.f);
-        auto ld6 = [&](int k2) -> cf {
-          const uint2 q = *reinterpret_cast<const uint2*>(Tb + (size_t)((unsigned)(k2 * TC) * 6u + boff));
+        // addresses as (uniform base per slot, laundered through scalar registers) + (one per-lane 32-bit offset for the
+        // direct rows, one for the mirror rows): written with a per-lane element index, the optimiser reassociates
+        // base + constant + offset into (base + offset) + constant and builds a 64-bit vector address per load
+        typedef const __attribute__((address_space(1))) char* gchar;
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        typedef const __attribute__((address_space(1))) u32x2* gu2;
+        auto ld6 = [&](int slot_k2, unsigned voff) -> cf {
+          gchar ub = (gchar)(Tb + (size_t)slot_k2 * (size_t)TC * 6u);
+          asm volatile("" : "+s"(ub));
+          const u32x2 q = *(gu2)(ub + (size_t)voff);
           const int re = (int)__builtin_amdgcn_perm(q.y, q.x, sel_re);
           const int im = (int)__builtin_amdgcn_perm(q.y, q.x, sel_im);
           return make_float2((float)re * qs, (float)im * qs);
         };
+        const unsigned va = (unsigned)(j * TC) * 6u + boff, vb = (unsigned)(jp * TC) * 6u + boff;
 #pragma unroll
-        for (int t = 0; t < R; ++t) av[t] = ld6(j + S * t);
+        for (int t = 0; t < R; ++t) av[t] = ld6(S * t, va);
 #pragma unroll
-        for (int t = 0; t < R; ++t) bv[t] = ld6(jp + S * t);
-        ny = ld6(N2h).x;
+        for (int t = 0; t < R; ++t) bv[t] = ld6(S * t, vb);
+        ny = ld6(N2h, boff).x;
       } else {
+        if constexpr (SC1) {
 #pragma unroll
-        for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(uoff(Tt, (unsigned)((j + S * t) * TC + r)));
+          for (int t = 0; t < R; ++t) av[t] = load_t<SC1>(uoff(Tt, (unsigned)((j + S * t) * TC + r)));
 #pragma unroll
-        for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(uoff(Tt, (unsigned)((jp + S * t) * TC + r)));
-        ny = load_t<SC1>(uoff(Tt, (unsigned)(N2h * TC + r))).x;
+          for (int t = 0; t < R; ++t) bv[t] = load_t<SC1>(uoff(Tt, (unsigned)((jp + S * t) * TC + r)));
+          ny = load_t<SC1>(uoff(Tt, (unsigned)(N2h * TC + r))).x;
+        } else {
+          // the same addressing as the q24 loads above: scalar base per slot, one per-lane offset per row set
+          typedef const __attribute__((address_space(1))) char* gchar;
+          typedef float f32x2 __attribute__((ext_vector_type(2)));
+          typedef const __attribute__((address_space(1))) f32x2* gf2;
+          auto ld8 = [&](int slot_k2, unsigned voff) -> cf {
+            gchar ub = (gchar)(Tt + (size_t)slot_k2 * (size_t)TC);
+            asm volatile("" : "+s"(ub));
+            const f32x2 v = *(gf2)(ub + (size_t)voff);
+            return make_float2(v.x, v.y);
+          };
+          const unsigned va = (unsigned)(j * TC + r) * 8u, vb = (unsigned)(jp * TC + r) * 8u;
+#pragma unroll
+          for (int t = 0; t < R; ++t) av[t] = ld8(S * t, va);
+#pragma unroll
+          for (int t = 0; t < R; ++t) bv[t] = ld8(S * t, vb);
+          ny = ld8(N2h, (unsigned)r * 8u).x;
+        }
       }
       untangle(it, j, single, av, bv, ny, ejs[it]);
     }
