@@ -857,7 +857,8 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
           const int im = (int)__builtin_amdgcn_perm(q.y, q.x, sel_im);
           return make_float2((float)re * qs, (float)im * qs);
         };
-        const unsigned va = (unsigned)(j * TC) * 6u + boff, vb = (unsigned)(jp * TC) * 6u + boff;
+        unsigned va = (unsigned)(j * TC) * 6u + boff, vb = (unsigned)(jp * TC) * 6u + boff;
+        asm volatile("" : "+v"(va), "+v"(vb));       // opaque 32-bit offsets: merged with other index arithmetic they come back as 64-bit pairs
 #pragma unroll
         for (int t = 0; t < R; ++t) av[t] = ld6(S * t, va);
 #pragma unroll
@@ -881,7 +882,8 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
             const f32x2 v = *(gf2)(ub + (size_t)voff);
             return make_float2(v.x, v.y);
           };
-          const unsigned va = (unsigned)(j * TC + r) * 8u, vb = (unsigned)(jp * TC + r) * 8u;
+          unsigned va = (unsigned)(j * TC + r) * 8u, vb = (unsigned)(jp * TC + r) * 8u;
+          asm volatile("" : "+v"(va), "+v"(vb));
 #pragma unroll
           for (int t = 0; t < R; ++t) av[t] = ld8(S * t, va);
 #pragma unroll
