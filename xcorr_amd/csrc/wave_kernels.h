@@ -533,13 +533,13 @@ template <class RX> struct ColPairStore {
 // folds away and the butterflies that follow see literal zeros.  With ZB0 = 0 such loads go to the zero chunk (L1 hits
 // that still cost a register pair and a slot in the memory pipeline each): 14 of the 24 blocks of a 0.1-10 Hz column
 // at 50 Hz, +3.7 % on the headline (profiles/r05_session2_notes.txt).
-template <class RX, int MODE, int TS = 0, int ZB0 = 0>
+template <class RX, int MODE, int TS = 0, int ZB0 = 0, int N2HC = 0>      // N2HC: the row length when the caller knows it at compile time
 XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_t spec_pitch,
                            const PwDesc d, int nstack, int k2, cf* __restrict__ T,
                            const cf* __restrict__ tw_sub, const cf* __restrict__ twN, const Geom& g XCX_ST_PARAM,
                            float tq = 0.f) {
   constexpr int N1 = RX::L;
-  const int N2h = g.N2h;
+  const int N2h = N2HC ? N2HC : g.N2h;            // compile time in the dual kernels: the T tile offsets fold into shifts and adds
   const cf* __restrict__ A = X + (size_t)d.slot_a * spec_pitch + (size_t)k2 * N1;
   const cf* __restrict__ Bp = X + (size_t)d.slot_b * spec_pitch + (size_t)k2 * N1;
   const unsigned sstride = (unsigned)spec_pitch;   // consecutive slots = consecutive windows
@@ -646,15 +646,16 @@ XCX_DEV void pair_col_body(cf* __restrict__ lds, const cf* __restrict__ X, size_
         const auto sy = __builtin_amdgcn_permlane32_swap(__float_as_uint(w[2 * u].y), __float_as_uint(w[2 * u + 1].y), false, false);
         int tile = a0 + 2 * u + up;
         if (tile >= NT) tile -= NT;
-        const unsigned o = (TC == 128) ? (unsigned)(tile >> 1) * (unsigned)crow + (unsigned)((tile & 1) * 64 + 2 * (lane & 31))
-                                       : (unsigned)tile * (unsigned)crow + (unsigned)(2 * (lane & 31));
+        // 24-bit multiplies (full rate; v_mul_lo_u32 is a quarter-rate instruction): tile < 64, crow and o < 2^24
+        const unsigned o = (TC == 128) ? __umul24((unsigned)(tile >> 1), (unsigned)crow) + (unsigned)((tile & 1) * 64 + 2 * (lane & 31))
+                                       : __umul24((unsigned)tile, (unsigned)crow) + (unsigned)(2 * (lane & 31));
         // plain global stores: sc1 / nt policies for T measured slower
         if constexpr (TS == 1) {
           typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
           unsigned q[3];
           q24_pack(sx[0], sy[0], sx[1], sy[1], q);
           char* tb = reinterpret_cast<char*>(T) + (size_t)((unsigned)(k2 * TC) * 6u);
-          *reinterpret_cast<u32x3*>(tb + (size_t)(o * 6u)) = u32x3{q[0], q[1], q[2]};
+          *reinterpret_cast<u32x3*>(tb + (size_t)__umul24(o, 6u)) = u32x3{q[0], q[1], q[2]};
         } else {
           *reinterpret_cast<float4*>(uoff(Tc, o)) =
               make_float4(__uint_as_float(sx[0]), __uint_as_float(sy[0]), __uint_as_float(sx[1]), __uint_as_float(sy[1]));
@@ -1171,7 +1172,7 @@ void k_wpair_dual(WDualArgs a) {
     if (ci >= per || item >= (N2h + 1) * a.Bc) return;
     const int k2 = item / a.Bc;
     const int pwl = item - k2 * a.Bc;
-    pair_col_body<RXC, MODE, TS, ZB0>(lds, a.X, a.spec_pitch, pw_desc(a.pw_c, pwl), a.nstack, k2,
+    pair_col_body<RXC, MODE, TS, ZB0, PG::N2h>(lds, a.X, a.spec_pitch, pw_desc(a.pw_c, pwl), a.nstack, k2,
                                   a.Tc + (size_t)pwl * N1 * (N2h + 1), a.tw_N1, a.tw_N, g XCX_ST_ARG, a.tq);
   } else {
     const int ri = grp * PG::RWX + (pos - PG::CWX);
