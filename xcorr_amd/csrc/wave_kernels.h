@@ -323,6 +323,21 @@ template <bool NT> XCX_DEV cf fwd_ld(const cf* p) {
     return *p;
   }
 }
+// ... addressed as (uniform base in scalar registers) + (32-bit per-lane byte offset): written as pointer + index the
+// forward row kernel built a 64-bit vector address for each of its 64 sample loads and 31 Tf stores (v_lshl_add_u64)
+typedef const __attribute__((address_space(1))) char* fwd_gchar;
+typedef __attribute__((address_space(1))) char* fwd_gchar_w;
+template <bool NT> XCX_DEV float fwd_ld_off(fwd_gchar base, unsigned byte_off) {
+  typedef const __attribute__((address_space(1))) float* gf;
+  if constexpr (NT) return __builtin_nontemporal_load((gf)(base + (size_t)byte_off));
+  else return *(gf)(base + (size_t)byte_off);
+}
+template <bool NT> XCX_DEV void fwd_st_off(fwd_gchar_w base, unsigned byte_off, cf v) {
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef __attribute__((address_space(1))) f32x2* gf2;
+  if constexpr (NT) __builtin_nontemporal_store(f32x2{v.x, v.y}, (gf2)(base + (size_t)byte_off));
+  else *(gf2)(base + (size_t)byte_off) = f32x2{v.x, v.y};
+}
 template <bool NT> XCX_DEV void fwd_st(cf* p, cf v) {
   if constexpr (NT) {
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -372,10 +387,12 @@ void k_wfwd_rows(WF1Args a) {
   // branch-free gather of the zero-padded window: indices beyond the window
   // are clamped (the load hits the cached last sample) and the value zeroed,
   // so all loads of a lane are in flight together
+  fwd_gchar xb = (fwd_gchar)x;
+  asm volatile("" : "+s"(xb));                                 // the window's first sample: wave-uniform, kept in scalar registers
   auto in = [=](int m, int r) -> cf {
     const int i0 = row0 + r + N1 * (2 * m);
     const int i1 = i0 + N1;
-    const float x0 = fwd_ld<NT>(x + (i0 < n ? i0 : n - 1)), x1 = fwd_ld<NT>(x + (i1 < n ? i1 : n - 1));
+    const float x0 = fwd_ld_off<NT>(xb, 4u * (unsigned)(i0 < n ? i0 : n - 1)), x1 = fwd_ld_off<NT>(xb, 4u * (unsigned)(i1 < n ? i1 : n - 1));
     float v0, v1;
     if constexpr (ONEBIT) {
       v0 = onebit_of(x0, mean_d);
@@ -418,6 +435,8 @@ void k_wfwd_rows(WF1Args a) {
     const cf du = *uoff(a.tw_unt, 4u);                     // w_N2^4
     const cf dn = twN_lookup(a.tw_N, 4u * (unsigned)m1);   // w_N^(4 m1)
     cf tu = su[0], tn = sn[0];
+    fwd_gchar_w Tfb = (fwd_gchar_w)Tf;
+    asm volatile("" : "+s"(Tfb));
     static_for<EIT>([&](auto ic) {
       constexpr int it = decltype(ic)::value;
       const int k = kq + 4 * it;
@@ -429,7 +448,7 @@ void k_wfwd_rows(WF1Args a) {
       const cf e = cmul(tu, df);
       cf H = make_float2(0.5f * (sm.x + e.y), 0.5f * (sm.y - e.x));
       H = cmul(H, tn);
-      fwd_st<NT>(Tf + (k * N1 + m1), H);
+      fwd_st_off<NT>(Tfb, 8u * (unsigned)(k * N1 + m1), H);
     });
   }
   if (tid_of<kWNT>() < kWRB) {
@@ -483,6 +502,8 @@ void k_wfwd_cols(WF2Args a) {
   int za, zb;
   band_zero_stretch(g, k2, za, zb);
   const unsigned zlen = (whiten && zb >= za) ? (unsigned)(zb - za + 1) : 0u;
+  fwd_gchar_w dstb = (fwd_gchar_w)dst;
+  asm volatile("" : "+s"(dstb));                               // uniform base of the spectrum column, 32-bit per-lane offsets
   auto epi = [=](int, int j0, int, cf (&v)[CG::RL]) {
 #pragma unroll
     for (int t = 0; t < CG::RL; ++t) {
@@ -496,7 +517,7 @@ void k_wfwd_cols(WF2Args a) {
         const float mag = sqrtf(o.x * o.x + o.y * o.y);
         o = cscale(o, (mag > 0.f) ? gain / mag : 0.f);
       }
-      fwd_st<NT>(dst + k1, cscale(o, scale));
+      fwd_st_off<NT>(dstb, 8u * (unsigned)k1, cscale(o, scale));
     }
   };
 #ifdef XCX_STAMPS
