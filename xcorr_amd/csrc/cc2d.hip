@@ -249,8 +249,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(INV ? XCX_C2
   }
 }
 
-// inverse rows + fftshift map + arg-max: grid (P1, pairs)
-template <class RX>
+// inverse rows + fftshift map + arg-max: grid (P1, pairs).  FULL = false (the timelapse case: only the peak is kept):
+// the 32 conditional map stores per thread, their exec-mask bookkeeping and 64-bit addresses are not compiled in
+// (the kernel is VALU-issue-bound: 1 700 vector and 870 scalar instructions per thread and row with them).
+template <class RX, bool FULL>
 __global__ __launch_bounds__(NT) void k2d_rows_inv(const cf* __restrict__ T2, G2 g, float inv_n,
                                                    float* __restrict__ full, const int* __restrict__ oidx,
                                                    float* __restrict__ rowbest,
@@ -300,7 +302,7 @@ __global__ __launch_bounds__(NT) void k2d_rows_inv(const cf* __restrict__ T2, G2
   float best = -INFINITY;
   int bestj = 0x7fffffff;                      // column of the row maximum (first occurrence)
   // the pass runs the pairs in tile-group order; the full map goes to the caller's pair index
-  float* __restrict__ frow = (full && row_ok) ? full + ((size_t)oidx[q] * OH + i) * OW : nullptr;
+  float* __restrict__ frow = (FULL && full && row_ok) ? full + ((size_t)oidx[q] * OH + i) * OW : nullptr;
   auto out_f = [&](int m, int, cf u) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(NT) void k2d_rows_inv(const cf* __restrict__ T2, G2
       if (j >= P2) j -= P2;
       const bool ok = row_ok && j < OW;
       const float v = (h ? u.y : u.x) * inv_n;
-      if (frow && ok) frow[j] = v;
+      if constexpr (FULL) { if (frow && ok) frow[j] = v; }
       const bool better = ok && (v > best || (v == best && j < bestj));
       best = better ? v : best;
       bestj = better ? j : bestj;
@@ -442,7 +444,8 @@ int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const PairOrder
   hipStream_t s = ctx->stream;
   const size_t lds_r = sizeof(cf) * (rp_c(R) + 1);
   HIP_TRY(big_lds(k2d_rows_fwd<RXR>, lds_r));
-  HIP_TRY(big_lds(k2d_rows_inv<RXR>, lds_r));
+  HIP_TRY(big_lds((k2d_rows_inv<RXR, true>), lds_r));
+  HIP_TRY(big_lds((k2d_rows_inv<RXR, false>), lds_r));
   hipLaunchKernelGGL(k2d_rows_fwd<RXR>, dim3(g.F, T), dim3(NT), lds_r, s, dtiles, g, (cf*)S1.ptr, rowss, tw_r, tw_u);
   const size_t lds_c = (RXC::S > 1) ? sizeof(cf) * P1 * CB : 0;
   const size_t lds_ci = kColsRegs<RXC> ? cols_regs_lds_bytes(P1) : lds_c;      // pair pass: half-size exchange buffer
@@ -478,8 +481,12 @@ int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const PairOrder
     hipLaunchKernelGGL((k2d_cols<RXC, true>), dim3(8u * ncx * (g1 - g0) * kGS), dim3(NT), lds_ci, s, (const cf*)S2.ptr,
                        (const cf*)S2.ptr, g, (const double*)nullptr, 0, ord.dsorted + p0, (cf*)T2.ptr, tw_c,
                        (const int*)ord.dslots + (size_t)g0 * kGS, ncb);
-    hipLaunchKernelGGL(k2d_rows_inv<RXR>, dim3(P1, cnt), dim3(NT), lds_r, s, (const cf*)T2.ptr, g, inv_n,
-                       dfull, ord.dorig + p0, rowbest, rowidx, tw_r, tw_u);
+    if (dfull)
+      hipLaunchKernelGGL((k2d_rows_inv<RXR, true>), dim3(P1, cnt), dim3(NT), lds_r, s, (const cf*)T2.ptr, g, inv_n,
+                         dfull, ord.dorig + p0, rowbest, rowidx, tw_r, tw_u);
+    else
+      hipLaunchKernelGGL((k2d_rows_inv<RXR, false>), dim3(P1, cnt), dim3(NT), lds_r, s, (const cf*)T2.ptr, g, inv_n,
+                         dfull, ord.dorig + p0, rowbest, rowidx, tw_r, tw_u);
     hipLaunchKernelGGL(k2d_peak, dim3(cnt), dim3(NT), 0, s, rowbest, rowidx, P1, (int)OW, dpeak_val + p0,
                        dpeak_idx + 2 * (size_t)p0);
     HIP_TRY(hipGetLastError());
