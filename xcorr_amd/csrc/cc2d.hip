@@ -175,7 +175,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(INV ? XCX_C2
     };
     subfft<RX, CB, CB, NT, false, false>(lds, tw_sub, in, o);
   } else {
-    const int2 pr = pairs[q];
+    // the pair through scalar loads (constant address space: q is workgroup-uniform, but the compiler will not prove
+    // the list unclobbered and would fetch it with a vector load + v_readfirstlane in front of every spectrum load)
+    typedef const __attribute__((address_space(4))) int cint;
+    cint* prp = (cint*)(const int*)(pairs + __builtin_amdgcn_readfirstlane(q));
+    const int2 pr = make_int2(prp[0], prp[1]);
     const cf* __restrict__ a = A + (size_t)pr.x * P1 * pitch;
     const cf* __restrict__ b = B2 + (size_t)pr.y * P1 * pitch;
     cf* __restrict__ dst = out + (size_t)q * P1 * pitch;
@@ -196,6 +200,23 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(INV ? XCX_C2
       // once would hold 2 x IT x R0 complex registers (194 VGPRs at P1 = 512: two waves per SIMD)
       typename G0::Regs va;
       constexpr int HB = G0::IT >= 2 ? 2 : 1;
+      // addresses = (uniform base per butterfly input t, in scalar registers) + (one 32-bit per-lane byte offset per
+      // iteration): written as a[o2 + t * stride] every one of the 64 loads and 32 stores of a thread got a 64-bit
+      // vector address of its own (97 v_lshl_add_u64, a register pair each, in a kernel that spills at 168 VGPRs)
+      typedef const __attribute__((address_space(1))) char* gchar;
+      typedef __attribute__((address_space(1))) char* gchar_w;
+      typedef float f32x2 __attribute__((ext_vector_type(2)));
+      gchar ua[R0], ub2[R0];
+#pragma unroll
+      for (int t = 0; t < R0; ++t) {
+        ua[t] = (gchar)(a + (size_t)(t * (P1 / R0)) * (size_t)pitch);
+        ub2[t] = (gchar)(b + (size_t)(t * (P1 / R0)) * (size_t)pitch);
+        asm volatile("" : "+s"(ua[t]), "+s"(ub2[t]));
+      }
+      auto ldg = [](gchar base, unsigned off) -> cf {
+        const f32x2 v = *(const __attribute__((address_space(1))) f32x2*)(base + (size_t)off);
+        return make_float2(v.x, v.y);
+      };
 #pragma unroll
       for (int h0 = 0; h0 < G0::IT; h0 += HB) {
         cf vb[HB][R0];
@@ -203,11 +224,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(INV ? XCX_C2
         for (int hh = 0; hh < HB; ++hh) {
           const int it = h0 + hh;
           const int bq = threadIdx.x + it * NT;
-          const unsigned o2 = (unsigned)(bq / CB) * (unsigned)pitch + (unsigned)(col0 + bq % CB);
+          unsigned o2 = 8u * ((unsigned)(bq / CB) * (unsigned)pitch + (unsigned)(col0 + bq % CB));
+          asm volatile("" : "+v"(o2));
 #pragma unroll
           for (int t = 0; t < R0; ++t) {
-            va[it][t] = a[o2 + (unsigned)(t * (P1 / R0)) * (unsigned)pitch];
-            vb[hh][t] = b[o2 + (unsigned)(t * (P1 / R0)) * (unsigned)pitch];
+            va[it][t] = ldg(ua[t], o2);
+            vb[hh][t] = ldg(ub2[t], o2);
           }
         }
 #pragma unroll
@@ -230,14 +252,28 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(INV ? XCX_C2
       typename G2s::Regs v2;
       stage_exchange<P1, R1, R0, R2, CB, NT>(ldsf, idx, v1, v2);
       stage_compute<P1, R2, R0 * R1, CB, NT, true>(v2, b2);
+      {
+        gchar_w ud[R2];
 #pragma unroll
-      for (int it = 0; it < G2s::IT; ++it) {
-        const int bq = threadIdx.x + it * NT;
-        const int c = bq % CB, j = bq / CB;
-        const int k = j % (R0 * R1);
-        const int j0 = (j - k) * R2 + k;
+        for (int t = 0; t < R2; ++t) {
+          ud[t] = (gchar_w)(dst + (size_t)(t * (R0 * R1)) * (size_t)pitch);
+          asm volatile("" : "+s"(ud[t]));
+        }
 #pragma unroll
-        for (int t = 0; t < R2; ++t) o(j0 + t * (R0 * R1), c, v2[it][t]);
+        for (int it = 0; it < G2s::IT; ++it) {
+          const int bq = threadIdx.x + it * NT;
+          const int c = bq % CB, j = bq / CB;
+          const int k = j % (R0 * R1);
+          const int j0 = (j - k) * R2 + k;
+          const int col = col0 + c;
+          unsigned od = 8u * ((unsigned)j0 * (unsigned)pitch + (unsigned)col);
+          asm volatile("" : "+v"(od));
+          if (col < ncol) {
+#pragma unroll
+            for (int t = 0; t < R2; ++t)
+              *(__attribute__((address_space(1))) f32x2*)(ud[t] + (size_t)od) = f32x2{v2[it][t].x, v2[it][t].y};
+          }
+        }
       }
     } else {
       auto in = [=](int k1, int c) -> cf {
