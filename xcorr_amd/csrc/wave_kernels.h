@@ -1173,7 +1173,7 @@ template <class RXC, class RXR> struct PairGeom {
 };
 
 template <class RXC, class RXR, int MODE, int TS = 0, int ZB0 = 0>
-__global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(XCX_DUAL_WAVES, XCX_DUAL_WAVES)))
+__global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(RXC::L > 2048 ? 2 : XCX_DUAL_WAVES, RXC::L > 2048 ? 2 : XCX_DUAL_WAVES)))
 void k_wpair_dual(WDualArgs a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   const Geom g = a.g;
@@ -1295,7 +1295,7 @@ XCX_DEV bool flow_wait8(const int* shards, int target_lane, int* err) {
 }
 
 template <class RXC, class RXR, int MODE>
-__global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(XCX_DUAL_WAVES, XCX_DUAL_WAVES)))
+__global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(RXC::L > 2048 ? 2 : XCX_DUAL_WAVES, RXC::L > 2048 ? 2 : XCX_DUAL_WAVES)))
 void k_wpair_flow(WFlowArgs a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   const Geom g = a.g;

@@ -18,7 +18,7 @@ XCX_WCOL_LIST(XCX_DECL_WCOL)
 XCX_WROW_LIST(XCX_DECL_WROW)
 
 // fused XCD-local pair kernel: instantiated (N1, N2h) combinations
-#define XCX_WFUSED_LIST(X) X(64, 16) X(256, 16) X(512, 16) X(1536, 16) X(1536, 120) X(2048, 120) X(1024, 120) X(1536, 64) X(768, 120) X(512, 120) X(1536, 128) X(2048, 64) X(2048, 128)
+#define XCX_WFUSED_LIST(X) X(64, 16) X(256, 16) X(512, 16) X(1536, 16) X(1536, 120) X(2048, 120) X(1024, 120) X(1536, 64) X(768, 120) X(512, 120) X(1536, 128) X(2048, 64) X(2048, 128) X(3072, 120)
 #define XCX_DECL_WFUSED(C, R) \
   hipError_t launch_wdual_##C##_##R(const WDualArgs& a, hipStream_t s);              \
   int wdual_q24_##C##_##R();                                                         \
