@@ -477,8 +477,11 @@ struct WF2Args {
   int nt;                    // 1: non-temporal accesses (large launches, see fwd_ld)
 };
 
+#ifndef XCX_FWDC_WAVES
+#define XCX_FWDC_WAVES 3      // the kernel needs 121 VGPRs: at 4 its launches are 8 % shorter (218 -> 201 us), the step is not (r05_session2_notes.txt)
+#endif
 template <class RX, bool NT = false>
-__global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(RX::L > 2048 ? 1 : 3, RX::L > 2048 ? 2 : 3)))
+__global__ __launch_bounds__(kWNT * kWPB) __attribute__((amdgpu_waves_per_eu(RX::L > 2048 ? 1 : XCX_FWDC_WAVES, RX::L > 2048 ? 2 : XCX_FWDC_WAVES)))
 void k_wfwd_cols(WF2Args a) {
   extern __shared__ __attribute__((aligned(16))) cf lds_all[];
   constexpr int N1 = RX::L;
