@@ -367,6 +367,23 @@ template <int R, bool INV> XCX_DEV void apply_tw_chain(cf (&v)[R], cf w1) {
   });
 }
 
+// ... and the same with every output scaled by `sc` at the price of six multiplies per butterfly: the chain's seeds
+// (t = 1, 8) carry the factor, v[0] takes it directly (the q24 row waves fold their fixed-point scale in here instead of
+// multiplying each of their 70 unpacked numbers)
+template <int R, bool INV> XCX_DEV void apply_tw_chain_scaled(cf (&v)[R], cf w1, float sc) {
+  static_assert(R <= 16, "seeds at t = 1 and t = 8 only");
+  cf w8 = w1, wt = w1;
+  if constexpr (R > 8) w8 = cscale(csq(csq(csq(w1))), sc);
+  v[0] = cscale(v[0], sc);
+  static_for<R - 1>([&](auto tc) {
+    constexpr int t = decltype(tc)::value + 1;
+    if constexpr (t == 1) wt = cscale(w1, sc);
+    else if constexpr (t == 8) wt = w8;
+    else wt = cmul(wt, w1);
+    v[t] = ctw<INV>(v[t], wt);
+  });
+}
+
 template <int L, int R, int NS, int NB, int NT, bool INV, bool SYNC, bool VEC_ST,
           class LoadF, class StoreF>
 XCX_DEV void fft_stage_c(const cf (&base)[StageGeom<L, R, NS, NB, NT>::IT], LoadF ld, StoreF st) {
@@ -521,6 +538,19 @@ XCX_DEV void stage_compute(typename StageGeom<L, R, NS, NB, NT>::Regs& v,
   for (int it = 0; it < G::IT; ++it) {
     if (!G::GUARD || (tid_of<NT>() + it * NT) < G::NBF) {
       if constexpr (NS > 1) apply_tw_chain<R, INV>(v[it], base[it]);
+      Bfly<R, INV>::run(v[it]);
+    }
+  }
+}
+template <int L, int R, int NS, int NB, int NT, bool INV>
+XCX_DEV void stage_compute_scaled(typename StageGeom<L, R, NS, NB, NT>::Regs& v,
+                                  const typename StageGeom<L, R, NS, NB, NT>::Base& base, float sc) {
+  using G = StageGeom<L, R, NS, NB, NT>;
+  static_assert(NS > 1, "the scale rides on the twiddle chain");
+#pragma unroll
+  for (int it = 0; it < G::IT; ++it) {
+    if (!G::GUARD || (tid_of<NT>() + it * NT) < G::NBF) {
+      apply_tw_chain_scaled<R, INV>(v[it], base[it], sc);
       Bfly<R, INV>::run(v[it]);
     }
   }

@@ -867,7 +867,6 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
         const unsigned boff = 6u * (unsigned)r - 2u * odd;
         const unsigned sel_re = odd ? 0x0403020cu : 0x0201000cu;       // three bytes to the top of a dword, low byte 0
         const unsigned sel_im = odd ? 0x0706050cu : 0x0504030cu;
-        const float qs = tqi * (1.f / 256.f);
         // addresses as (uniform base per slot, laundered through scalar registers) + (one per-lane 32-bit offset for the
         // direct rows, one for the mirror rows): written with a per-lane element index, the optimiser reassociates
         // base + constant + offset into (base + offset) + constant and builds a 64-bit vector address per load
@@ -880,7 +879,7 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
           const u32x2 q = *(gu2)(ub + (size_t)voff);
           const int re = (int)__builtin_amdgcn_perm(q.y, q.x, sel_re);
           const int im = (int)__builtin_amdgcn_perm(q.y, q.x, sel_im);
-          return make_float2((float)re * qs, (float)im * qs);
+          return make_float2((float)re, (float)im);          // x 256 tq: the scale rides on the second stage's twiddle chain
         };
         unsigned va = (unsigned)(j * TC) * 6u + boff, vb = (unsigned)(jp * TC) * 6u + boff;
         asm volatile("" : "+v"(va), "+v"(vb));       // opaque 32-bit offsets: merged with other index arithmetic they come back as 64-bit pairs
@@ -964,7 +963,9 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
     group_sync<kWNT>();
   }
   XCX_STAMP(3, v1[G1::IT - 1][RX::R1 - 1].y);
-  stage_compute<N2h, RX::R1, RX::R0, kWRB, kWNT, true>(v1, b1);
+  static_assert(TS != 1 || RX::R1 <= 16, "q24: the scale rides on a twiddle chain with seeds at 1 and 8");
+  if constexpr (TS == 1) stage_compute_scaled<N2h, RX::R1, RX::R0, kWRB, kWNT, true>(v1, b1, tqi * (1.f / 256.f));
+  else stage_compute<N2h, RX::R1, RX::R0, kWRB, kWNT, true>(v1, b1);
   XCX_STAMP(4, v1[G1::IT - 1][RX::R1 - 1].y);
   // ---- second stage + output ---------------------------------------------
   const int idx_min = g.idx_min;
