@@ -808,14 +808,20 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
     {
       // selects, not branches: the optimiser sinks the mirror loads into the arm of a branch that needs them, and a
       // load inside a branch waits alone
-      const bool m0 = single && j == 0, m1 = single && j != 0;
+      // (j = S/2 exists for even S only: for odd S, N2h = 120 among them, the second select is not compiled in)
+      const bool m0 = single && j == 0, m1 = (S % 2 == 0) && single && j != 0;
       cf sel[R];
 #pragma unroll
       for (int t = 0; t < R; ++t) {
         const cf a0 = av[(t + 1) % R];                         // j = 0: mirror of S*t' is S*(R-t')
         const cf a1 = av[t];                                   // j = S/2 mirrors inside itself
-        sel[t].x = m0 ? a0.x : (m1 ? a1.x : bv[t].x);
-        sel[t].y = m0 ? a0.y : (m1 ? a1.y : bv[t].y);
+        if constexpr (S % 2 == 0) {
+          sel[t].x = m0 ? a0.x : (m1 ? a1.x : bv[t].x);
+          sel[t].y = m0 ? a0.y : (m1 ? a1.y : bv[t].y);
+        } else {
+          sel[t].x = m0 ? a0.x : bv[t].x;
+          sel[t].y = m0 ? a0.y : bv[t].y;
+        }
       }
 #pragma unroll
       for (int t = 0; t < R; ++t) bv[t] = sel[t];
@@ -1044,19 +1050,31 @@ XCX_DEV void pair_row_body(cf* __restrict__ lds, const cf* __restrict__ Tt, floa
             vq[qq] = *reinterpret_cast<const float4*>(stg + (ic >> 4) * kTR + 4 * (ic & 15));
           }
         }
-        const int i = tid + q * (kWNT * kWPB);
-        if (i >= kGroups) continue;
-        const int sl = i >> 4, gq = i & 15;
+        // Per thread and pass only the lag block moves (sl = sl0 + 16 q: the residues r0 .. r0 + 3 of a thread's groups are
+        // the same for every q), so everything but one literal add, the circular wrap and one unsigned range compare is
+        // computed once per thread (round 5: as written per group it cost a 64-bit multiply-add and ~20 instructions for
+        // each of the 16 groups, a tenth of a row wave's instructions -- and the pass runs at the power cap)
+        constexpr int kPerIt = kWNT * kWPB;
+        static_assert(kPerIt % (kTR / 4) == 0, "a thread keeps its residues from one group to the next");
+        const int i = tid + q * kPerIt;
+        if ((q + 1) * kPerIt > kGroups && i >= kGroups) continue;      // only the last trip is ragged
+        const int gq = tid & 15, sl0 = tid >> 4;
+        const int sl = sl0 + q * (kPerIt >> 4);
         const int s = sl + half * KH;
         const float4 v = vq[q];
         const int r0 = res0 + 4 * gq;                          // residues r0 .. r0 + 3
-        int o = r0 + N1 * (s + q0);
+        const int ob = r0 + N1 * (sl0 + q0);                   // q = 0, first pass, before the wrap
+        int o = ob + N1 * (q * (kPerIt >> 4) + half * KH);     // a literal away from it
         if (o >= wrap_at) o -= N;                          // N, N1, r0 are multiples of 4: never splits a group
         // element e is real data iff its row has kk = s - wr_e inside this pass, and retained iff
         // 0 <= o + e < Lout
         const int wr0 = (r0 < shift) ? 1 : 0, wr3 = (r0 + 3 < shift) ? 1 : 0;
-        const bool uniform = wr0 == wr3 && (s - wr0) >= half * KH && (s - wr0) < (half + 1) * KH;
-        if (uniform && o >= 0 && (unsigned)(o + 3) < Lout) {
+        // kk = sl - wr in [0, KH): only the first and the last lag blocks of a pass can miss it
+        const bool edge = (q == 0) || ((q + 1) * (kPerIt >> 4) > KH);
+        const bool in_pass = !edge || ((sl - wr0) >= 0 && (sl - wr0) < KH);
+        const bool uniform = wr0 == wr3 && in_pass;
+        const unsigned lim = Lout >= 3u ? Lout - 3u : 0u;       // o >= 0 && o + 3 < Lout as one unsigned compare
+        if (uniform && (unsigned)o < lim) {
           typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
           const u32x4 w4 = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
           __builtin_amdgcn_raw_buffer_store_b128(w4, rsrc, o * 4, 0, XCX_CCF_AUX);
