@@ -287,7 +287,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(INV ? XCX_C2
 
 // inverse rows + fftshift map + arg-max: grid (P1, pairs).  FULL = false (the timelapse case: only the peak is kept):
 // the 32 conditional map stores per thread, their exec-mask bookkeeping and 64-bit addresses are not compiled in
-// (the kernel is VALU-issue-bound: 1 700 vector and 870 scalar instructions per thread and row with them).
+// (the kernel is VALU-issue-bound: 1 285 vector and 200 scalar instructions per thread and row at R = 4096 -- 1 646 and
+// 653 before the arg-max went value-first, see below).
 template <class RX, bool FULL>
 __global__ __launch_bounds__(NT) void k2d_rows_inv(const cf* __restrict__ T2, G2 g, float inv_n,
                                                    float* __restrict__ full, const int* __restrict__ oidx,
@@ -296,7 +297,7 @@ __global__ __launch_bounds__(NT) void k2d_rows_inv(const cf* __restrict__ T2, G2
                                                    const cf* __restrict__ tw_unt) {
   extern __shared__ __attribute__((aligned(16))) cf lds[];
   __shared__ float bv[NT / 64];
-  __shared__ long long bi[NT / 64];
+  __shared__ unsigned long long bi;
   constexpr int R = RX::L;
   const int m1 = blockIdx.x, q = blockIdx.y;
   const int P1 = g.P1, P2 = 2 * R;
@@ -335,21 +336,45 @@ __global__ __launch_bounds__(NT) void k2d_rows_inv(const cf* __restrict__ T2, G2
     const cf e = cmulc(df, tw_unt[k]);
     return make_float2(sm.x - e.y, sm.y + e.x);
   };
+  // The arg-max of the row in two steps (the per-output compare / tie-break / index bookkeeping was 280 compare-select
+  // and 520 scalar mask instructions per thread, most of them behind branches): every thread keeps its outputs in
+  // registers and a running maximum of the valid ones (one range test, one select, one v_max per output); the row
+  // maximum goes through the workgroup by value alone; only the threads that hold it then look up the smallest
+  // shifted column among their matching outputs.  Output u = 2m + h lands in column (u + L - 1) mod P2, which is one
+  // of the 2L - 1 lags unless L <= u <= P2 - L.
+  constexpr int RL = (RX::S == 2) ? RX::R1 : RX::R2;
+  constexpr int NSL = (RX::S == 2) ? RX::R0 : RX::R0 * RX::R1;
+  using GL = StageGeom<R, RL, NSL, 1, NT>;
+  float keep[GL::IT][2 * RL];
+  int m0[GL::IT];
+#pragma unroll
+  for (int it = 0; it < GL::IT; ++it) {
+    m0[it] = 0;
+#pragma unroll
+    for (int t = 0; t < 2 * RL; ++t) keep[it][t] = __builtin_nanf("");      // never equal to the maximum
+  }
   float best = -INFINITY;
-  int bestj = 0x7fffffff;                      // column of the row maximum (first occurrence)
+  const unsigned span = row_ok ? (unsigned)(P2 - 2 * L) : 0xffffffffu;       // u - L <= span: outside the lags
   // the pass runs the pairs in tile-group order; the full map goes to the caller's pair index
   float* __restrict__ frow = (FULL && full && row_ok) ? full + ((size_t)oidx[q] * OH + i) * OW : nullptr;
-  auto out_f = [&](int m, int, cf u) {
+  auto out_v = [&](int it, int j0, int, const cf (&v)[RL]) {
+    m0[it] = j0;
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      int j = 2 * m + h + L - 1;             // shifted column
-      if (j >= P2) j -= P2;
-      const bool ok = row_ok && j < OW;
-      const float v = (h ? u.y : u.x) * inv_n;
-      if constexpr (FULL) { if (frow && ok) frow[j] = v; }
-      const bool better = ok && (v > best || (v == best && j < bestj));
-      best = better ? v : best;
-      bestj = better ? j : bestj;
+    for (int t = 0; t < RL; ++t) {
+      const unsigned u0 = (unsigned)(2 * (j0 + t * NSL) - L);
+      keep[it][2 * t] = v[t].x; keep[it][2 * t + 1] = v[t].y;
+      best = fmaxf(best, u0 > span ? v[t].x : -INFINITY);
+      best = fmaxf(best, u0 + 1u > span ? v[t].y : -INFINITY);
+      if constexpr (FULL) {
+        if (frow) {
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            int j = 2 * (j0 + t * NSL) + h + L - 1;             // shifted column
+            if (j >= P2) j -= P2;
+            if (j < OW) frow[j] = (h ? v[t].y : v[t].x) * inv_n;
+          }
+        }
+      }
     }
   };
   // first stage reads the untangled spectrum from LDS (barrier before it is overwritten)
@@ -359,28 +384,42 @@ __global__ __launch_bounds__(NT) void k2d_rows_inv(const cf* __restrict__ T2, G2
   if constexpr (RX::S == 2) {
     fft_stage_c<R, RX::R0, 1, 1, NT, true, true, false>(b0, in, lds_st);
     __syncthreads();
-    fft_stage_c<R, RX::R1, RX::R0, 1, NT, true, false, false>(b1, lds_ld, out_f);
+    fft_stage_c<R, RX::R1, RX::R0, 1, NT, true, false, true>(b1, lds_ld, out_v);
   } else {
     fft_stage_c<R, RX::R0, 1, 1, NT, true, true, false>(b0, in, lds_st);
     __syncthreads();
     fft_stage_c<R, RX::R1, RX::R0, 1, NT, true, true, false>(b1, lds_ld, lds_st);
     __syncthreads();
-    fft_stage_c<R, RX::R2, RX::R0 * RX::R1, 1, NT, true, false, false>(b2, lds_ld, out_f);
+    fft_stage_c<R, RX::R2, RX::R0 * RX::R1, 1, NT, true, false, true>(b2, lds_ld, out_v);
   }
-  // first maximum of the row: lanes by shuffles, the four waves through LDS (one barrier instead of nine)
-  long long bix = bestj == 0x7fffffff ? 0x7fffffffffffffffLL : (long long)i * OW + bestj;
+  // row maximum: lanes by shuffles, the four waves through LDS
+  float wmax = best;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float v2 = __shfl_down(best, o);
-    const long long i2 = __shfl_down(bix, o);
-    if (v2 > best || (v2 == best && i2 < bix)) { best = v2; bix = i2; }
+  for (int o = 32; o > 0; o >>= 1) wmax = fmaxf(wmax, __shfl_xor(wmax, o));
+  if ((threadIdx.x & 63) == 0) bv[threadIdx.x >> 6] = wmax;
+  if (threadIdx.x == 0) bi = 0x7fffffffffffffffULL;
+  __syncthreads();
+  float rowmax = bv[0];
+#pragma unroll
+  for (int w = 1; w < NT / 64; ++w) rowmax = fmaxf(rowmax, bv[w]);
+  if (row_ok && best == rowmax) {              // this thread holds a maximum of the row: its first column
+    int bj = 0x7fffffff;
+#pragma unroll
+    for (int it = 0; it < GL::IT; ++it)
+#pragma unroll
+      for (int t = 0; t < 2 * RL; ++t) {
+        const int u = 2 * (m0[it] + (t >> 1) * NSL) + (t & 1);
+        int j = u + L - 1;
+        if (j >= P2) j -= P2;
+        const bool hit = ((unsigned)(u - L) > span) & (keep[it][t] == rowmax);
+        bj = min(bj, hit ? j : 0x7fffffff);
+      }
+    if (bj != 0x7fffffff) atomicMin(&bi, (unsigned long long)((long long)i * OW + bj));
   }
-  if ((threadIdx.x & 63) == 0) { bv[threadIdx.x >> 6] = best; bi[threadIdx.x >> 6] = bix; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    for (int w = 1; w < NT / 64; ++w)
-      if (bv[w] > best || (bv[w] == best && bi[w] < bix)) { best = bv[w]; bix = bi[w]; }
-    rowbest[(size_t)q * P1 + m1] = best; rowidx[(size_t)q * P1 + m1] = bix;
+    rowbest[(size_t)q * P1 + m1] = rowmax * inv_n;       // inv_n > 0: the maximum of the scaled values
+    rowidx[(size_t)q * P1 + m1] = (long long)bi;
   }
 }
 
@@ -471,7 +510,18 @@ int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const PairOrder
   static const size_t pass_bytes = getenv("XCX_CC2D_PASS_MB") ? (size_t)std::max(1, atoi(getenv("XCX_CC2D_PASS_MB"))) << 20
                                                                 : (size_t)1 << 30;      // (tests force several passes)
   const int PB = (int)std::max<size_t>(kGS, std::min<size_t>((size_t)P, pass_bytes / (rowb * P1)));
-  if ((rc = T2.ensure(ctx, rowb * P1 * PB))) return rc;
+  // Two passes in flight (round 5): the column kernel of pass i + 1 runs on one pipeline stream beside the row
+  // kernel of pass i on the other, each pass in its own half of T2 (2 x pass_bytes).  The column kernel is latency-
+  // bound (a wave lives 45 k cycles and issues vector instructions for 5.5 k of them, three waves per SIMD: 36 % of
+  // the vector issue slots, 3.2 TB/s of HBM traffic), the row kernel issue-bound (four waves per SIMD keep the
+  // vector unit busy, 3.6 TB/s); side by side: +3 ... +8 % (76.5 -> 79.0 k and 74.7 -> 81.1 k tile-pairs/s on two
+  // boxes, profiles/r05_session3_notes.txt) -- less than the sum of the idle slots, because three column waves of
+  // 144 registers leave a SIMD no room for a row wave of 96, so the kernels mix only where a CU happens to drain.
+  // XCX_CC2D_OVERLAP=0: one pass at a time on the context's stream (A/B, and what a single pass does anyway).
+  static const bool overlap = !(getenv("XCX_CC2D_OVERLAP") && atoi(getenv("XCX_CC2D_OVERLAP")) == 0);
+  const bool two = overlap && P > PB && ctx->pipe[0] && ctx->pipe[1];
+  const size_t t2_half = rowb * P1 * PB;
+  if ((rc = T2.ensure(ctx, t2_half * (two ? 2 : 1)))) return rc;
   if ((rc = misc.ensure(ctx, sizeof(double) * (size_t)T * g.F + (sizeof(float) + sizeof(long long)) * (size_t)P1 * PB + 64)))
     return rc;
   double* rowss = (double*)misc.ptr;
@@ -511,21 +561,50 @@ int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const PairOrder
   pass_g0.push_back(ngroups);
   HIP_TRY(hipMemcpyAsync(ord.dslots, slots.data(), sizeof(int) * slots.size(), hipMemcpyHostToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));                         // `slots` goes out of scope with this function
+  struct Ev {
+    hipEvent_t e = nullptr;
+    ~Ev() { if (e) (void)hipEventDestroy(e); }
+    hipError_t make() { return hipEventCreateWithFlags(&e, hipEventDisableTiming); }
+  };
+  Ev start, done, coldone[2], rowdone[2];
+  hipStream_t sc = s, sr = s;
+  if (two) {
+    sc = ctx->pipe[0]; sr = ctx->pipe[1];
+    HIP_TRY(start.make()); HIP_TRY(done.make());
+    for (int h = 0; h < 2; ++h) { HIP_TRY(coldone[h].make()); HIP_TRY(rowdone[h].make()); }
+    HIP_TRY(hipEventRecord(start.e, s));                    // spectra S2, slot tables: ready on the context's stream
+    HIP_TRY(hipStreamWaitEvent(sc, start.e, 0));
+    HIP_TRY(hipStreamWaitEvent(sr, start.e, 0));
+  }
   for (size_t ip = 0; ip + 1 < pass_g0.size(); ++ip) {
     const int g0 = pass_g0[ip], g1 = pass_g0[ip + 1];
     const int p0 = ord.gfirst[g0], cnt = ord.gfirst[g1] - p0;
-    hipLaunchKernelGGL((k2d_cols<RXC, true>), dim3(8u * ncx * (g1 - g0) * kGS), dim3(NT), lds_ci, s, (const cf*)S2.ptr,
-                       (const cf*)S2.ptr, g, (const double*)nullptr, 0, ord.dsorted + p0, (cf*)T2.ptr, tw_c,
+    const int h = two ? (int)(ip & 1) : 0;
+    cf* t2 = (cf*)((char*)T2.ptr + (size_t)h * t2_half);
+    if (two && ip >= 2) HIP_TRY(hipStreamWaitEvent(sc, rowdone[h].e, 0));       // this half has been read
+    hipLaunchKernelGGL((k2d_cols<RXC, true>), dim3(8u * ncx * (g1 - g0) * kGS), dim3(NT), lds_ci, sc, (const cf*)S2.ptr,
+                       (const cf*)S2.ptr, g, (const double*)nullptr, 0, ord.dsorted + p0, t2, tw_c,
                        (const int*)ord.dslots + (size_t)g0 * kGS, ncb);
+    if (two) {
+      HIP_TRY(hipEventRecord(coldone[h].e, sc));
+      HIP_TRY(hipStreamWaitEvent(sr, coldone[h].e, 0));
+    }
+    // (rowbest / rowidx are shared by the passes: row kernel and peak kernel of every pass queue on ONE stream)
     if (dfull)
-      hipLaunchKernelGGL((k2d_rows_inv<RXR, true>), dim3(P1, cnt), dim3(NT), lds_r, s, (const cf*)T2.ptr, g, inv_n,
+      hipLaunchKernelGGL((k2d_rows_inv<RXR, true>), dim3(P1, cnt), dim3(NT), lds_r, sr, (const cf*)t2, g, inv_n,
                          dfull, ord.dorig + p0, rowbest, rowidx, tw_r, tw_u);
     else
-      hipLaunchKernelGGL((k2d_rows_inv<RXR, false>), dim3(P1, cnt), dim3(NT), lds_r, s, (const cf*)T2.ptr, g, inv_n,
+      hipLaunchKernelGGL((k2d_rows_inv<RXR, false>), dim3(P1, cnt), dim3(NT), lds_r, sr, (const cf*)t2, g, inv_n,
                          dfull, ord.dorig + p0, rowbest, rowidx, tw_r, tw_u);
-    hipLaunchKernelGGL(k2d_peak, dim3(cnt), dim3(NT), 0, s, rowbest, rowidx, P1, (int)OW, dpeak_val + p0,
+    hipLaunchKernelGGL(k2d_peak, dim3(cnt), dim3(NT), 0, sr, rowbest, rowidx, P1, (int)OW, dpeak_val + p0,
                        dpeak_idx + 2 * (size_t)p0);
     HIP_TRY(hipGetLastError());
+    if (two) HIP_TRY(hipEventRecord(rowdone[h].e, sr));
+  }
+  if (two) {
+    // the row stream's last kernels wait for the column stream's last: its end is the end of both
+    HIP_TRY(hipEventRecord(done.e, sr));
+    HIP_TRY(hipStreamWaitEvent(s, done.e, 0));
   }
   return XCX_OK;
 }
