@@ -1,0 +1,19 @@
+# round 5 (third session): cc2d column blocks of 8 columns (64-byte segments, half the registers: 90 instead of 144)
+set -o pipefail
+for l in libxcx_cb8w5.so; do
+XCX_LIB_PATH=$PWD/xcorr_amd/lib/$l timeout -k 10 300 python -m pytest tests/test_gpu_cc2d.py -x -q > gpurun_out/q4_pytest.log 2>&1; rc=$?; tail -2 gpurun_out/q4_pytest.log
+[ $rc -ne 0 ] && exit 1
+XCX_LIB_PATH=$PWD/xcorr_amd/lib/$l timeout -k 10 200 python tools/check_cc2d.py 30 21 > gpurun_out/q4_check_a.log 2>&1 || { tail -5 gpurun_out/q4_check_a.log; exit 1; }
+XCX_CC2D_PASS_MB=1 XCX_LIB_PATH=$PWD/xcorr_amd/lib/$l timeout -k 10 200 python tools/check_cc2d.py 30 22 > gpurun_out/q4_check_b.log 2>&1 || { tail -5 gpurun_out/q4_check_b.log; exit 1; }
+done
+tail -q -n 1 gpurun_out/q4_check_*.log
+rm -f gpurun_out/q4_ab.log
+for rep in 1 2 3; do
+  for l in libxcx.so libxcx_cb8w3.so libxcx_cb8w4.so libxcx_cb8w5.so; do
+    XCX_LIB_PATH=$PWD/xcorr_amd/lib/$l timeout -k 10 200 python tools/bench_timelapse.py --steps 5 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$l', round(d['value']), round(d['roofline']['us_per_tile_pair'],2))" >> gpurun_out/q4_ab.log || exit 1
+  done
+done
+for l in libxcx.so libxcx_cb8w5.so; do
+XCX_CC2D_OVERLAP=0 XCX_LIB_PATH=$PWD/xcorr_amd/lib/$l timeout -k 10 200 python tools/bench_timelapse.py --steps 5 --no-cpu-baseline 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$l OVERLAP=0', round(d['value']), round(d['roofline']['us_per_tile_pair'],2))" >> gpurun_out/q4_ab.log
+done
+cat gpurun_out/q4_ab.log

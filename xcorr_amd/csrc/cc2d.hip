@@ -43,7 +43,8 @@ constexpr int NT = 256;
 #define XCX_C2_WAVES 3      // waves per SIMD of the pair column pass (register budget 168; 4 -> 128 spills 60 registers)
 #endif
 constexpr int kGS = 16;  // pair slots per tile group of the pair pass (4 x 4 tiles)
-constexpr int CB = 16;   // columns per workgroup: 8 (64-byte segments, 4 workgroups per CU) measured +3 %, 32 (1 per CU) -28 %
+constexpr int CB = 16;   // columns per workgroup: 32 (1 per CU) -28 %; 8 (64-byte segments; round 5: 90 registers instead of 144,
+                         // both halves of a 128-byte line on one XCD back to back) -6 % at 4 waves per SIMD, -10 % at 5, -13 % at 3
 
 // LDS index padding of the row kernels: one extra slot per 16 keeps the stride-16 /
 // stride-256 stage writes off a single bank group
