@@ -39,6 +39,9 @@ using namespace xcx;
 namespace {
 
 constexpr int NT = 256;
+#ifndef XCX_C2_NT
+#define XCX_C2_NT 256
+#endif
 #ifndef XCX_C2_WAVES
 #define XCX_C2_WAVES 3      // waves per SIMD of the pair column pass (register budget 168; 4 -> 128 spills 60 registers)
 #endif
@@ -56,6 +59,28 @@ struct G2 {
   int P1, R;       // column transform length, complex row length (P2 = 2R)
   int pitch;       // complex elements per spectrum row (>= R+1)
 };
+
+// Layout of the pair pass's intermediate T2 (one [P1][pitch] block per pair): rows in groups of kT2RB, inside a group the
+// 128-byte pieces (16 columns) of the group's rows lie together -- element (m1, k2) at
+//   ((m1 / RB) (pitch / 16) + k2 / 16) (16 RB) + (m1 % RB) 16 + k2 % 16.
+// RB = 1 is the plain row-major block.  A column workgroup owns 16 columns of every row: it writes RB x 128 contiguous
+// bytes per row group instead of 128-byte pieces one row pitch (32.9 KB) apart; a row workgroup reads its row as
+// 128-byte pieces RB x 128 bytes apart, the RB workgroups of a group (consecutive blockIdx.x) sharing each stretch.
+#ifndef XCX_T2_RB
+#define XCX_T2_RB 512          // >= every P1: one group = the whole column block, [k2 / 16][m1][k2 % 16]
+#endif
+constexpr int kT2RB = XCX_T2_RB;
+static_assert((kT2RB & (kT2RB - 1)) == 0, "row groups are powers of two");
+// rows per group for a column length P1 (a power of two >= 16): the groups tile the P1 rows exactly
+__host__ __device__ constexpr int t2_rb(int P1) { return kT2RB < P1 ? kT2RB : P1; }
+// the spectra S2 are read by column workgroups only: one group = the whole column block, [k2 / 16][k1][k2 % 16]
+__host__ __device__ constexpr int s2_rb(int P1) { return P1; }
+__device__ __forceinline__ unsigned t2_off(int m1, int k2, int pitch, int rb) {
+  if (rb == 1) return (unsigned)m1 * (unsigned)pitch + (unsigned)k2;
+  return __umul24((unsigned)(m1 / rb) * (unsigned)(pitch >> 4) + (unsigned)(k2 >> 4), 16u * (unsigned)rb) +      // both < 2^24
+         (unsigned)(m1 % rb) * 16u + (unsigned)(k2 & 15);
+}
+// (additive over the butterfly strides: t2_off(j + t S, k2) = t2_off(j, k2) + t2_off(t S, 0) for j < S, S and rb powers of two)
 
 // forward rows: grid (F, T)
 template <class RX>
@@ -114,15 +139,15 @@ __global__ __launch_bounds__(NT) void k2d_rows_fwd(const float* __restrict__ til
 
 // three-stage column configurations whose stages all fill whole 256-thread iterations take the register path of
 // the pair pass (k2d_cols<INV>); LDS floats of its half-size exchange buffer
-template <class RX>
-constexpr bool kColsRegs = RX::S == 3 && (RX::L / RX::R0) * CB % NT == 0 && (RX::L / RX::R1) * CB % NT == 0 &&
-                           (RX::L / RX::R2) * CB % NT == 0;
+template <class RX, int NTC = NT>
+constexpr bool kColsRegs = RX::S == 3 && (RX::L / RX::R0) * CB % NTC == 0 && (RX::L / RX::R1) * CB % NTC == 0 &&
+                           (RX::L / RX::R2) * CB % NTC == 0;
 constexpr size_t cols_regs_lds_bytes(int P1) { return sizeof(float) * (size_t)(P1 + (P1 >> 3) + 1) * CB; }
 
 // columns: grid (ceil((R+1)/16), T or pairs).  INV = false: forward transform of
 // the F rows of S1 (zero rows beyond), scaled; INV = true: A conj(B), inverse.
-template <class RX, bool INV>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(INV ? XCX_C2_WAVES : 1, INV ? XCX_C2_WAVES : 8))) void k2d_cols(const cf* __restrict__ A, const cf* __restrict__ B2, G2 g,
+template <class RX, bool INV, int NTC = NT>
+__global__ __launch_bounds__(NTC) __attribute__((amdgpu_waves_per_eu(INV ? XCX_C2_WAVES : 1, INV ? XCX_C2_WAVES : 8))) void k2d_cols(const cf* __restrict__ A, const cf* __restrict__ B2, G2 g,
                                                const double* __restrict__ rowss, int normalize,
                                                const int2* __restrict__ pairs,
                                                cf* __restrict__ out, const cf* __restrict__ tw_sub,
@@ -154,10 +179,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(INV ? XCX_C2
     const int F = g.F;
     float sc = 1.f;
     if (normalize) {                       // 1/||tile||_F from the row sums (same order in every workgroup)
-      __shared__ double red[NT];
-      red[threadIdx.x] = (int)threadIdx.x < F ? rowss[(size_t)q * F + threadIdx.x] : 0.0;   // F <= NT
+      __shared__ double red[NTC];
+      red[threadIdx.x] = (int)threadIdx.x < F ? rowss[(size_t)q * F + threadIdx.x] : 0.0;   // F <= NTC
       __syncthreads();
-      for (int o = NT / 2; o > 0; o >>= 1) {
+      for (int o = NTC / 2; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
       }
@@ -170,11 +195,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(INV ? XCX_C2
       const cf v = src[(size_t)(f < F ? f : F - 1) * pitch + col];
       return (f < F && col < ncol) ? v : make_float2(0.f, 0.f);
     };
-    auto o = [=](int k1, int c, cf v) {
+    auto o = [=](int k1, int c, cf v) {            // spectra S2 in the row-group layout too (read by the pair pass)
       const int col = col0 + c;
-      if (col < ncol) dst[(size_t)k1 * pitch + col] = cscale(v, sc);
+      if (col < ncol) dst[t2_off(k1, col, pitch, s2_rb(P1))] = cscale(v, sc);
     };
-    subfft<RX, CB, CB, NT, false, false>(lds, tw_sub, in, o);
+    subfft<RX, CB, CB, NTC, false, false>(lds, tw_sub, in, o);
   } else {
     // the pair through scalar loads (constant address space: q is workgroup-uniform, but the compiler will not prove
     // the list unclobbered and would fetch it with a vector load + v_readfirstlane in front of every spectrum load)
@@ -186,17 +211,17 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(INV ? XCX_C2
     cf* __restrict__ dst = out + (size_t)q * P1 * pitch;
     auto o = [=](int m1, int c, cf v) {
       const int col = col0 + c;
-      if (col < ncol) dst[(size_t)m1 * pitch + col] = v;
+      if (col < ncol) dst[t2_off(m1, col, pitch, t2_rb(P1))] = v;
     };
-    if constexpr (kColsRegs<RX>) {
+    if constexpr (kColsRegs<RX, NTC>) {
       // every load of the slab first (the pitch is a multiple of CB: columns beyond ncol are padding inside the
       // row, their products are never stored), then the products, then the transform with register-resident
       // stages that exchange through a HALF-SIZE LDS buffer (real parts, then imaginary parts: 37 KB instead of
       // 64 KB per workgroup at P1 = 512, four workgroups per CU instead of two)
       constexpr int R0 = RX::R0, R1 = RX::R1, R2 = RX::R2;
-      using G0 = StageGeom<P1, R0, 1, CB, NT>;
-      using G1 = StageGeom<P1, R1, R0, CB, NT>;
-      using G2s = StageGeom<P1, R2, R0 * R1, CB, NT>;
+      using G0 = StageGeom<P1, R0, 1, CB, NTC>;
+      using G1 = StageGeom<P1, R1, R0, CB, NTC>;
+      using G2s = StageGeom<P1, R2, R0 * R1, CB, NTC>;
       // loads in batches of two butterflies per thread (2 x 2 x R0 loads in flight): a and b of ALL iterations at
       // once would hold 2 x IT x R0 complex registers (194 VGPRs at P1 = 512: two waves per SIMD)
       typename G0::Regs va;
@@ -210,8 +235,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(INV ? XCX_C2
       gchar ua[R0], ub2[R0];
 #pragma unroll
       for (int t = 0; t < R0; ++t) {
-        ua[t] = (gchar)(a + (size_t)(t * (P1 / R0)) * (size_t)pitch);
-        ub2[t] = (gchar)(b + (size_t)(t * (P1 / R0)) * (size_t)pitch);
+        ua[t] = (gchar)(a + (size_t)t2_off(t * (P1 / R0), 0, pitch, s2_rb(P1)));
+        ub2[t] = (gchar)(b + (size_t)t2_off(t * (P1 / R0), 0, pitch, s2_rb(P1)));
         asm volatile("" : "+s"(ua[t]), "+s"(ub2[t]));
       }
       auto ldg = [](gchar base, unsigned off) -> cf {
@@ -224,8 +249,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(INV ? XCX_C2
 #pragma unroll
         for (int hh = 0; hh < HB; ++hh) {
           const int it = h0 + hh;
-          const int bq = threadIdx.x + it * NT;
-          unsigned o2 = 8u * ((unsigned)(bq / CB) * (unsigned)pitch + (unsigned)(col0 + bq % CB));
+          const int bq = threadIdx.x + it * NTC;
+          unsigned o2 = 8u * t2_off(bq / CB, col0 + bq % CB, pitch, s2_rb(P1));
           asm volatile("" : "+v"(o2));
 #pragma unroll
           for (int t = 0; t < R0; ++t) {
@@ -244,30 +269,30 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(INV ? XCX_C2
       float* __restrict__ ldsf = reinterpret_cast<float*>(lds);
       auto idx = [](int p, int c) { return (p + (p >> 3)) * CB + c; };       // one pad row every 8 positions
       typename G1::Base b1;                       // twiddle bases: loaded where their registers are free
-      stage_tw_base<P1, R1, R0, CB, NT>(tw_sub, b1);
+      stage_tw_base<P1, R1, R0, CB, NTC>(tw_sub, b1);
       typename G1::Regs v1;
-      stage_exchange<P1, R0, 1, R1, CB, NT>(ldsf, idx, va, v1);
-      stage_compute<P1, R1, R0, CB, NT, true>(v1, b1);
+      stage_exchange<P1, R0, 1, R1, CB, NTC>(ldsf, idx, va, v1);
+      stage_compute<P1, R1, R0, CB, NTC, true>(v1, b1);
       typename G2s::Base b2;
-      stage_tw_base<P1, R2, R0 * R1, CB, NT>(tw_sub, b2);
+      stage_tw_base<P1, R2, R0 * R1, CB, NTC>(tw_sub, b2);
       typename G2s::Regs v2;
-      stage_exchange<P1, R1, R0, R2, CB, NT>(ldsf, idx, v1, v2);
-      stage_compute<P1, R2, R0 * R1, CB, NT, true>(v2, b2);
+      stage_exchange<P1, R1, R0, R2, CB, NTC>(ldsf, idx, v1, v2);
+      stage_compute<P1, R2, R0 * R1, CB, NTC, true>(v2, b2);
       {
         gchar_w ud[R2];
 #pragma unroll
         for (int t = 0; t < R2; ++t) {
-          ud[t] = (gchar_w)(dst + (size_t)(t * (R0 * R1)) * (size_t)pitch);
+          ud[t] = (gchar_w)(dst + (size_t)t2_off(t * (R0 * R1), 0, pitch, t2_rb(P1)));
           asm volatile("" : "+s"(ud[t]));
         }
 #pragma unroll
         for (int it = 0; it < G2s::IT; ++it) {
-          const int bq = threadIdx.x + it * NT;
+          const int bq = threadIdx.x + it * NTC;
           const int c = bq % CB, j = bq / CB;
           const int k = j % (R0 * R1);
           const int j0 = (j - k) * R2 + k;
           const int col = col0 + c;
-          unsigned od = 8u * ((unsigned)j0 * (unsigned)pitch + (unsigned)col);
+          unsigned od = 8u * t2_off(j0, col, pitch, t2_rb(P1));
           asm volatile("" : "+v"(od));
           if (col < ncol) {
 #pragma unroll
@@ -278,10 +303,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(INV ? XCX_C2
       }
     } else {
       auto in = [=](int k1, int c) -> cf {
-        const size_t o2 = (size_t)k1 * pitch + col0 + c;          // inside the padded row
+        const size_t o2 = t2_off(k1, col0 + c, pitch, s2_rb(P1));          // inside the padded row
         return cmulc(a[o2], b[o2]);
       };
-      subfft<RX, CB, CB, NT, true, false>(lds, tw_sub, in, o);
+      subfft<RX, CB, CB, NTC, true, false>(lds, tw_sub, in, o);
     }
   }
 }
@@ -302,7 +327,14 @@ __global__ __launch_bounds__(NT) void k2d_rows_inv(const cf* __restrict__ T2, G2
   constexpr int R = RX::L;
   const int m1 = blockIdx.x, q = blockIdx.y;
   const int P1 = g.P1, P2 = 2 * R;
-  const cf* __restrict__ src = T2 + ((size_t)q * P1 + m1) * g.pitch;
+  // the pair's block of T2 in row groups (t2_off): element (m1, k) = row_base + ((k >> 4) << (4 + rbl)) + (k & 15); the
+  // loads of a thread (k = tid + it NT) are one per-lane offset plus a uniform stride
+  const cf* __restrict__ src = T2 + (size_t)q * P1 * g.pitch;
+  const int rbl = 31 - __builtin_clz((unsigned)t2_rb(P1));              // log2 of the rows per group (uniform)
+  const unsigned row_base = (((unsigned)(m1 >> rbl) * (unsigned)(g.pitch >> 4)) << (4 + rbl)) +
+                            (((unsigned)m1 & ((1u << rbl) - 1u)) << 4);
+  const unsigned lane_off = row_base + ((threadIdx.x >> 4) << (4 + rbl)) + (threadIdx.x & 15u);
+  const unsigned it_stride = (unsigned)(NT >> 4) << (4 + rbl);
   typename StageGeom<R, RX::R1, RX::R0, 1, NT>::Base b1;
   typename StageGeom<R, RX::R2, RX::R0 * RX::R1, 1, NT>::Base b2;
   stage_tw_base<R, RX::R1, RX::R0, 1, NT>(tw_sub, b1);
@@ -313,9 +345,9 @@ __global__ __launch_bounds__(NT) void k2d_rows_inv(const cf* __restrict__ T2, G2
 #pragma unroll
     for (int it = 0; it < NL; ++it) {
       const int k = threadIdx.x + it * NT;
-      stage[it] = (R % NT == 0 || k < R) ? src[k] : make_float2(0.f, 0.f);
+      stage[it] = (R % NT == 0 || k < R) ? src[lane_off + (unsigned)it * it_stride] : make_float2(0.f, 0.f);
     }
-    const cf ny = threadIdx.x == 0 ? src[R] : make_float2(0.f, 0.f);
+    const cf ny = threadIdx.x == 0 ? src[row_base + ((unsigned)(R >> 4) << (4 + rbl))] : make_float2(0.f, 0.f);
 #pragma unroll
     for (int it = 0; it < NL; ++it) {
       const int k = threadIdx.x + it * NT;
@@ -535,9 +567,10 @@ int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const PairOrder
   HIP_TRY(big_lds((k2d_rows_inv<RXR, false>), lds_r));
   hipLaunchKernelGGL(k2d_rows_fwd<RXR>, dim3(g.F, T), dim3(NT), lds_r, s, dtiles, g, (cf*)S1.ptr, rowss, tw_r, tw_u);
   const size_t lds_c = (RXC::S > 1) ? sizeof(cf) * P1 * CB : 0;
-  const size_t lds_ci = kColsRegs<RXC> ? cols_regs_lds_bytes(P1) : lds_c;      // pair pass: half-size exchange buffer
+  constexpr int NTP = kColsRegs<RXC, XCX_C2_NT> ? XCX_C2_NT : NT;      // threads of a pair-pass column workgroup
+  const size_t lds_ci = kColsRegs<RXC, NTP> ? cols_regs_lds_bytes(P1) : lds_c;      // pair pass: half-size exchange buffer
   HIP_TRY(big_lds((k2d_cols<RXC, false>), lds_c));
-  HIP_TRY(big_lds((k2d_cols<RXC, true>), lds_ci));
+  HIP_TRY(big_lds((k2d_cols<RXC, true, NTP>), lds_ci));
   const int ncb = (g.R + 1 + CB - 1) / CB;
   hipLaunchKernelGGL((k2d_cols<RXC, false>), dim3(ncb, T), dim3(NT), lds_c, s, (const cf*)S1.ptr, (const cf*)nullptr, g,
                      (const double*)rowss, normalize, (const int2*)nullptr, (cf*)S2.ptr, tw_c);
@@ -583,7 +616,7 @@ int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const PairOrder
     const int h = two ? (int)(ip & 1) : 0;
     cf* t2 = (cf*)((char*)T2.ptr + (size_t)h * t2_half);
     if (two && ip >= 2) HIP_TRY(hipStreamWaitEvent(sc, rowdone[h].e, 0));       // this half has been read
-    hipLaunchKernelGGL((k2d_cols<RXC, true>), dim3(8u * ncx * (g1 - g0) * kGS), dim3(NT), lds_ci, sc, (const cf*)S2.ptr,
+    hipLaunchKernelGGL((k2d_cols<RXC, true, NTP>), dim3(8u * ncx * (g1 - g0) * kGS), dim3(NTP), lds_ci, sc, (const cf*)S2.ptr,
                        (const cf*)S2.ptr, g, (const double*)nullptr, 0, ord.dsorted + p0, t2, tw_c,
                        (const int*)ord.dslots + (size_t)g0 * kGS, ncb);
     if (two) {
