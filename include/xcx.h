@@ -384,7 +384,15 @@ int xcx_timeshift_fft(xcx_ctx* ctx, const float* x, float* y, long batch, long s
  * its (i, j), first occurrence in row-major order (numpy.argmax).  full, when
  * non-NULL, receives all [P][2F-1][2L-1] values (host or device per on_device).
  * Computed at the padded size P1 x P2 >= (2F-1) x (2L-1) with P1, P2 powers of
- * two; F <= XCX_CC2D_MAX_F, L <= XCX_CC2D_MAX_L (XCX_EUNSUPPORTED beyond). */
+ * two; F <= XCX_CC2D_MAX_F, L <= XCX_CC2D_MAX_L (XCX_EUNSUPPORTED beyond).
+ * Every tile is transformed once per call; a pair costs one inverse 2-D
+ * transform of the product spectrum (column pass, row pass with the arg-max).
+ * The pairs run in passes of whole 4 x 4 tile groups; two passes are in flight
+ * on the context's pipeline streams (the column pass of one beside the row
+ * pass of the other), the context's stream waits for both before the call
+ * returns its results.  Workspace on the context (grow-only): the T padded
+ * spectra (8 P1 (P2/2 + 16) bytes each) and two halves of the intermediate,
+ * 1 GiB each when the pair list needs more than one pass. */
 int xcx_cc2d(xcx_ctx* ctx, const float* tiles, int T, int F, int L,
              const int* pairs, int P, int normalize, float* peak_val,
              int* peak_idx, float* full, int on_device);

@@ -127,6 +127,26 @@ assert worst < 1e-5
     assert out.returncode == 0, out.stdout[-500:] + out.stderr[-1500:]
 
 
+def test_randomised_peak_positions():
+    """tools/check_cc2d.py: peak value and POSITION against numpy's arg-max of the oracle map over random tile shapes on
+    either side of the padded sizes (the row kernel keeps a running maximum by value and looks the position up only
+    in the threads that hold it; the padding columns L <= u <= P2 - L must never win), all-negative maps, peak-only
+    and full-map kernels.  A short run in this process (two passes in flight on the pipeline streams where the pair
+    list needs several) and one with a single pass at a time, 1 MiB passes (XCX_CC2D_OVERLAP=0)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, 'tools'))
+    import check_cc2d
+    cases, worst, _ = check_cc2d.run(6.0, seed=5)
+    assert cases > 20 and worst <= 1e-5
+    env = dict(os.environ, XCX_CC2D_PASS_MB='1', XCX_CC2D_OVERLAP='0', PYTHONPATH=root)
+    out = subprocess.run([sys.executable, os.path.join(root, 'tools', 'check_cc2d.py'), '5', '6'], capture_output=True,
+                         text=True, timeout=300, cwd=root, env=env)
+    assert out.returncode == 0 and 'calls clean' in out.stdout, out.stdout[-500:] + out.stderr[-1500:]
+
+
 def test_signal_mirror_and_errors(ctx):
     rng = np.random.default_rng(4)
     x = rng.standard_normal((2, 3, 10, 50)).astype(np.float32)

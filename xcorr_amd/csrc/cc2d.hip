@@ -39,9 +39,6 @@ using namespace xcx;
 namespace {
 
 constexpr int NT = 256;
-#ifndef XCX_C2_NT
-#define XCX_C2_NT 256
-#endif
 #ifndef XCX_C2_WAVES
 #define XCX_C2_WAVES 3      // waves per SIMD of the pair column pass (register budget 168; 4 -> 128 spills 60 registers)
 #endif
@@ -567,7 +564,9 @@ int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const PairOrder
   HIP_TRY(big_lds((k2d_rows_inv<RXR, false>), lds_r));
   hipLaunchKernelGGL(k2d_rows_fwd<RXR>, dim3(g.F, T), dim3(NT), lds_r, s, dtiles, g, (cf*)S1.ptr, rowss, tw_r, tw_u);
   const size_t lds_c = (RXC::S > 1) ? sizeof(cf) * P1 * CB : 0;
-  constexpr int NTP = kColsRegs<RXC, XCX_C2_NT> ? XCX_C2_NT : NT;      // threads of a pair-pass column workgroup
+  // threads of a pair-pass column workgroup (template parameter NTC of k2d_cols): 512 (two butterflies per thread, 79-90
+  // registers, one load batch, 16-24 waves per CU) measured equal at 6 waves per SIMD and -3.5 % at 4 (round 5)
+  constexpr int NTP = NT;
   const size_t lds_ci = kColsRegs<RXC, NTP> ? cols_regs_lds_bytes(P1) : lds_c;      // pair pass: half-size exchange buffer
   HIP_TRY(big_lds((k2d_cols<RXC, false>), lds_c));
   HIP_TRY(big_lds((k2d_cols<RXC, true, NTP>), lds_ci));
