@@ -387,12 +387,12 @@ int xcx_timeshift_fft(xcx_ctx* ctx, const float* x, float* y, long batch, long s
  * two; F <= XCX_CC2D_MAX_F, L <= XCX_CC2D_MAX_L (XCX_EUNSUPPORTED beyond).
  * Every tile is transformed once per call; a pair costs one inverse 2-D
  * transform of the product spectrum (column pass, row pass with the arg-max).
- * The pairs run in passes of whole 4 x 4 tile groups; two passes are in flight
+ * The pairs run in passes of whole 8 x 8 tile groups; two passes are in flight
  * on the context's pipeline streams (the column pass of one beside the row
  * pass of the other), the context's stream waits for both before the call
  * returns its results.  Workspace on the context (grow-only): the T padded
  * spectra (8 P1 (P2/2 + 16) bytes each) and two halves of the intermediate,
- * 1 GiB each when the pair list needs more than one pass. */
+ * 2.2 GB each when the pair list needs more than one pass. */
 int xcx_cc2d(xcx_ctx* ctx, const float* tiles, int T, int F, int L,
              const int* pairs, int P, int normalize, float* peak_val,
              int* peak_idx, float* full, int on_device);

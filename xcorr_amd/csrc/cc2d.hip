@@ -42,7 +42,10 @@ constexpr int NT = 256;
 #ifndef XCX_C2_WAVES
 #define XCX_C2_WAVES 3      // waves per SIMD of the pair column pass (register budget 168; 4 -> 128 spills 60 registers)
 #endif
-constexpr int kGS = 16;  // pair slots per tile group of the pair pass (4 x 4 tiles)
+// tile block (a / kGA, b / kGB) of a tile group: 8 x 8 tiles = up to 64 pairs on 16 slabs, 0.25 slab reads per pair cross the
+// fabric (4 x 4 until round 5: 0.5; 8 x 8 with passes of two groups +2.7 %, 4 x 8 / 8 x 4 +1 %, notes section 10)
+constexpr int kGA = 8, kGB = 8;
+constexpr int kGS = kGA * kGB;  // pair slots per tile group of the pair pass
 constexpr int CB = 16;   // columns per workgroup: 32 (1 per CU) -28 %; 8 (64-byte segments; round 5: 90 registers instead of 144,
                          // both halves of a 128-byte line on one XCD back to back) -6 % at 4 waves per SIMD, -10 % at 5, -13 % at 3
 
@@ -158,9 +161,9 @@ __global__ __launch_bounds__(NTC) __attribute__((amdgpu_waves_per_eu(INV ? XCX_C
   if constexpr (INV) {
     // XCD-aware order of the pair pass (1-D grid; blockIdx % 8 labels the XCD under round-robin dispatch, used
     // for locality only): XCD x takes the column blocks cb = x (mod 8); inside an XCD the kGS pair slots of one
-    // tile group (a 4 x 4 biclique of tiles, pair_groups2d below) run back to back for one column block, so the
-    // group's 8 tile slabs (64 KB each at P1 = 512) are fetched into that L2 once and re-read there by the other
-    // pairs of the group: 0.5 instead of 2 slab reads per pair across the fabric.
+    // tile group (a kGA x kGB biclique of tiles, pair_groups2d below) run back to back for one column block, so the
+    // group's 16 tile slabs (64 KB each at P1 = 512) are fetched into that L2 once and re-read there by the other
+    // pairs of the group: 0.25 instead of 2 slab reads per pair across the fabric.
     const int x = blockIdx.x & 7, sq = (int)(blockIdx.x >> 3);
     const int ncx = (slot_ncb + 7) >> 3;
     const int pg = sq % kGS, cbi = (sq / kGS) % ncx, grp = sq / (kGS * ncx);
@@ -495,8 +498,8 @@ template <class K> hipError_t big_lds(K kernel, size_t bytes) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 
-// Pair order of the pair pass: pairs are grouped by the 4 x 4 tile block (a / 4, b / 4) they fall in -- at most kGS
-// pairs on at most 8 tiles per group -- and run in that order (k2d_cols<INV>); `orig` maps back to the caller's index.
+// Pair order of the pair pass: pairs are grouped by the kGA x kGB tile block (a / kGA, b / kGB) they fall in -- at most kGS
+// pairs on at most kGA + kGB tiles per group -- and run in that order (k2d_cols<INV>); `orig` maps back to the caller's index.
 struct PairOrder {
   std::vector<int2> sorted;        // pairs in run order
   std::vector<int> orig;           // run order -> caller's pair index
@@ -507,10 +510,10 @@ struct PairOrder {
 };
 
 void pair_groups2d(const int* pairs, int P, int T, PairOrder& o) {
-  const long nb = (T + 3) / 4;
+  const long nb = (T + kGB - 1) / kGB;
   static const bool grouped = !(getenv("XCX_CC2D_GROUPS") && atoi(getenv("XCX_CC2D_GROUPS")) == 0);   // 0: caller's order (A/B)
   std::vector<std::pair<long, int>> key(P);
-  for (int i = 0; i < P; ++i) key[i] = {grouped ? (long)(pairs[2 * i] / 4) * nb + pairs[2 * i + 1] / 4 : (long)(i / kGS), i};
+  for (int i = 0; i < P; ++i) key[i] = {grouped ? (long)(pairs[2 * i] / kGA) * nb + pairs[2 * i + 1] / kGB : (long)(i / kGS), i};
   std::stable_sort(key.begin(), key.end(), [](const std::pair<long, int>& a, const std::pair<long, int>& b) { return a.first < b.first; });
   o.sorted.resize(P); o.orig.resize(P); o.gfirst.clear();
   for (int r = 0; r < P; ++r) {
@@ -532,13 +535,12 @@ int run2d(xcx_ctx* ctx, const float* dtiles, int T, const G2& g, const PairOrder
   const size_t rowb = sizeof(cf) * (size_t)g.pitch;
   if ((rc = S1.ensure(ctx, rowb * g.F * T))) return rc;
   if ((rc = S2.ensure(ctx, rowb * P1 * T))) return rc;
-  // pairs per pass: 1 GiB of intermediate T2 (three tile groups of 16 pairs at 512 x 8192; 512 MiB until round 4) (larger passes amortise the launch tails; keeping
-  // T2 inside the 256 MiB Infinity Cache measured 5-10% slower, not faster -- and two overlapped
-  // chains of 4-6 pair passes on their own streams, T2 cache-resident, measured the same 51 k
-  // pairs/s as this single stream (round 3): the two kernels are not HBM-bound)
+  // pairs per pass: 2.2 GB of intermediate T2 (two tile groups of 64 pairs at 512 x 8192; 1 GiB = three groups of 16 until
+  // round 5, 512 MiB until round 4) (larger passes amortise the launch tails; keeping T2 inside the 256 MiB Infinity
+  // Cache measured 5-10 % slower, not faster, in rounds 3, 4 and 5)
   // (whole tile groups per pass: at least one group of kGS pairs)
   static const size_t pass_bytes = getenv("XCX_CC2D_PASS_MB") ? (size_t)std::max(1, atoi(getenv("XCX_CC2D_PASS_MB"))) << 20
-                                                                : (size_t)1 << 30;      // (tests force several passes)
+                                                                : (size_t)2200 << 20;      // (tests force several passes)
   const int PB = (int)std::max<size_t>(kGS, std::min<size_t>((size_t)P, pass_bytes / (rowb * P1)));
   // Two passes in flight (round 5): the column kernel of pass i + 1 runs on one pipeline stream beside the row
   // kernel of pass i on the other, each pass in its own half of T2 (2 x pass_bytes).  The column kernel is latency-
