@@ -133,6 +133,23 @@ def main():
                 'implementation_frac_of_hbm_peak': impl_bytes_pair / us_pair * 1e-3 / 8000.0,
                 'flop_per_tile_pair_executed': flop_pair, 'flop_per_tile_pair_reference_form': flop_ref_pair,
                 'reference_form_TFLOPs_equivalent': flop_ref_pair / us_pair * 1e-6}
+        # HBM traffic per tile pair from the PMC passes of THIS library build (profiles/cc2d_pmc_latest.json, made from
+        # tools/pmc_cc2d.sh's FETCH_SIZE / WRITE_SIZE counters), null for any other build -- the rule of bench.py
+        roof['traffic_source'] = 'no profiles/cc2d_pmc_latest.json'
+        try:
+            import hashlib
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            pmc = json.load(open(os.path.join(root, 'profiles', 'cc2d_pmc_latest.json')))
+            lib_sha = hashlib.sha256(open(_ffi.LIB_PATH, 'rb').read()).hexdigest()
+            if pmc.get('_stamp', {}).get('lib_sha256') == lib_sha and (T, F, L) == (64, 256, 4096):
+                roof['traffic'] = pmc['hbm_bytes_per_tile_pair']
+                roof['traffic_unit'] = 'bytes per tile pair (FETCH_SIZE x 2 + WRITE_SIZE of k2d_cols<inv>, k2d_rows_inv and the amortised tile transforms)'
+                roof['traffic_GBps'] = pmc['hbm_bytes_per_tile_pair'] / us_pair * 1e-3
+                roof['traffic_source'] = f"rocprofv3 --pmc passes of {pmc['_stamp'].get('tag')} (tools/pmc_cc2d.sh)"
+            else:
+                roof['traffic_source'] = 'cc2d_pmc_latest.json was measured on another libxcx.so build or workload'
+        except (OSError, ValueError, KeyError) as e:
+            roof['traffic_source'] = f'cc2d_pmc_latest.json unreadable: {e}'
         cpu = None if a.no_cpu_baseline else cpu_baseline(F, L)
         print(json.dumps({
             'roofline': roof, 'cpu_baseline': cpu,
