@@ -18,16 +18,18 @@ for ctrs in "FETCH_SIZE" "WRITE_SIZE" \
   timeout -k 10 240 rocprofv3 --pmc $ctrs --output-format csv -d $out/p$i -- python3 $B > $out/p$i.log 2>&1 || { tail -5 $out/p$i.log; echo "pass $i ($ctrs) failed"; continue; }
 done
 cd $root
-python3 - $out <<'PY'
-import csv, glob, sys, os, re
+python3 - $out $root <<'PY'
+import csv, glob, hashlib, json, sys, os, re
 from collections import defaultdict
-out = sys.argv[1]
+out, root = sys.argv[1], sys.argv[2]
 acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(int)
 for f in glob.glob(os.path.join(out, 'p*', '**', '*counter_collection.csv'), recursive=True):
     for r in csv.DictReader(open(f)):
-        m = re.search(r'(k2d_[a-z_]+(<[^>]*>)?)', r['Kernel_Name'])
+        m = re.search(r'(k2d_[a-z_]+)(<.*>)?', r['Kernel_Name'])
         if not m: continue
-        k = m.group(1)[:40] + (' inv' if 'true>(' in r['Kernel_Name'] or 'Lb1' in r['Kernel_Name'] else '')
+        k = m.group(1)
+        if k == 'k2d_cols':                                  # template arguments: <Radices<...>, INV, threads>
+            k += '<inv>' if re.search(r'>, true', r['Kernel_Name']) else '<fwd>'
         acc[k][r['Counter_Name']] += float(r['Counter_Value']); cnt[(k, r['Counter_Name'])] += 1
 with open(os.path.join(out, 'counters.txt'), 'w') as fo:
     for k in sorted(acc):
@@ -36,6 +38,25 @@ with open(os.path.join(out, 'counters.txt'), 'w') as fo:
             n = cnt[(k, c)]
             print(f'   {c:28s} avg/launch {acc[k][c]/n:18.1f}   launches {n}', file=fo)
 print(open(os.path.join(out, 'counters.txt')).read())
+# HBM bytes per tile pair, stamped with the library's hash (tools/bench_timelapse.py fills roofline.traffic from it when
+# the hash matches): FETCH_SIZE / WRITE_SIZE are KiB, fetch x 2 on gfx950; 3 runs of 2016 pairs (--steps 2 --warmup 1)
+pairs = 3 * 2016.0
+def per_pair(k, c, f=1.0): return acc[k].get(c, 0.0) * 1024.0 * f / pairs
+if 'FETCH_SIZE' in acc.get('k2d_cols<inv>', {}) and 'WRITE_SIZE' in acc.get('k2d_cols<inv>', {}):
+    sys.path.insert(0, root)
+    import bench
+    lib = os.environ.get('XCX_LIB_PATH') or os.path.join(root, 'xcorr_amd', 'lib', 'libxcx.so')
+    d = {'_stamp': {'tag': os.path.basename(out).replace('cc2d_', ''), 'lib_sha256': hashlib.sha256(open(lib, 'rb').read()).hexdigest(),
+                    'src_sha256': bench.src_sha256(), 'workload': 'configs[4] timelapse: 64 tiles 256x4096 -> 2016 tile pairs',
+                    'source': 'tools/pmc_cc2d.sh: separate rocprofv3 --pmc passes for FETCH_SIZE and WRITE_SIZE (KiB; fetch x 2 on gfx950)'},
+         'k2d_cols_inv': {'fetch_bytes_per_tile_pair_corrected_x2': per_pair('k2d_cols<inv>', 'FETCH_SIZE', 2.0),
+                          'write_bytes_per_tile_pair': per_pair('k2d_cols<inv>', 'WRITE_SIZE')},
+         'k2d_rows_inv': {'fetch_bytes_per_tile_pair_corrected_x2': per_pair('k2d_rows_inv', 'FETCH_SIZE', 2.0),
+                          'write_bytes_per_tile_pair': per_pair('k2d_rows_inv', 'WRITE_SIZE')},
+         'tile_transforms_bytes_per_tile_pair': sum(per_pair(k, 'FETCH_SIZE', 2.0) + per_pair(k, 'WRITE_SIZE') for k in ('k2d_rows_fwd', 'k2d_cols<fwd>'))}
+    d['hbm_bytes_per_tile_pair'] = (sum(v for k in ('k2d_cols_inv', 'k2d_rows_inv') for v in d[k].values()) + d['tile_transforms_bytes_per_tile_pair'])
+    json.dump(d, open(os.path.join(out, 'cc2d_pmc_latest.json'), 'w'), indent=1)
+    print('cc2d_pmc_latest.json:', round(d['hbm_bytes_per_tile_pair'] / 1e6, 2), 'MB per tile pair  (copy it to profiles/ with the run\'s other files)')
 PY
 cut -c1-60,200- $out/kernel_stats.csv | head -8
 rm -rf $out/kt $out/p?
